@@ -1,0 +1,221 @@
+"""Drop-in for the reference's ``cbench.ans`` extension (csrc/ans/lib.cpp:10-33,
+csrc/ans/rans64.hpp:127-149) backed by the HIP kernels in libbasic_hip.so.
+
+Same classes, constructor defaults, method names, argument meaning and error behaviour:
+arrays are converted to C-contiguous int32 like pybind11's ``py::array_t<int32_t>``
+(forcecast), ``ValueError`` is raised where the reference raises ``py::value_error``.
+The coding itself runs on the GPU (one wavefront per stream); there is no CPU path.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+
+def _i32(a):
+    return np.ascontiguousarray(np.asarray(a), dtype=np.int32)
+
+
+def pmf_to_quantized_cdf(pmf, precision=16):
+    """csrc/ans/rans64.cpp:69-126 -- returns a list of ints of length len(pmf)+1."""
+    pmf = np.ascontiguousarray(np.asarray(pmf, dtype=np.float32)).reshape(-1)
+    out = np.zeros(pmf.size + 1, dtype=np.int32)
+    _lib.check(_lib.lib().basic_pmf_to_quantized_cdf(pmf.ctypes.data, pmf.size, int(precision), out.ctypes.data))
+    return out.tolist()
+
+
+class _Rans64Base:
+    def __init__(self, freq_precision=16, bypass_coding=True, bypass_precision=4):
+        self._freq_precision = int(freq_precision)
+        self._bypass_coding = bool(bypass_coding)
+        self._bypass_precision = int(bypass_precision)
+        self._tables = None
+        self._ar_order = 0
+
+    def __del__(self):
+        self._free()
+
+    def _free(self):
+        t, self._tables = getattr(self, "_tables", None), None
+        if t:
+            try:
+                _lib.lib().basic_rans_tables_destroy(t)
+            except Exception:
+                pass
+
+    def __reduce__(self):  # the reference's pybind11 objects are not picklable either
+        raise TypeError("cannot pickle '%s' object" % type(self).__name__)
+
+    def init_params(self, freqs, num_symbols, offsets):
+        freqs, nsym, offsets = _i32(freqs), _i32(num_symbols).reshape(-1), _i32(offsets).reshape(-1)
+        if freqs.ndim != 2 or freqs.shape[0] != nsym.size:
+            raise ValueError("freqs should be 2-dimensional with shape (num_symbols.size(), >num_symbols.max())")
+        if offsets.size < nsym.size:
+            raise ValueError("offsets should have one entry per distribution")
+        h = ctypes.c_void_p()
+        _lib.check(_lib.lib().basic_rans_tables_from_freqs(
+            freqs.ctypes.data, freqs.shape[0], freqs.shape[1], nsym.ctypes.data, offsets.ctypes.data,
+            self._freq_precision, int(self._bypass_coding), self._bypass_precision, ctypes.byref(h)))
+        self._free()
+        self._tables = h
+
+    def init_cdf_params(self, cdfs, cdfs_sizes, offsets):
+        cdfs, sizes, offsets = _i32(cdfs), _i32(cdfs_sizes).reshape(-1), _i32(offsets).reshape(-1)
+        if cdfs.ndim != 2 or cdfs.shape[0] != sizes.size:
+            raise ValueError("cdfs should be 2-dimensional with shape (cdfs_sizes.size(), >cdfs_sizes.max())")
+        h = ctypes.c_void_p()
+        _lib.check(_lib.lib().basic_rans_tables_from_cdfs(
+            cdfs.ctypes.data, cdfs.shape[0], cdfs.shape[1], sizes.ctypes.data, offsets.ctypes.data,
+            self._freq_precision, int(self._bypass_coding), self._bypass_precision, ctypes.byref(h)))
+        self._free()
+        self._tables = h
+
+    def init_ar_params(self, ar_table, ar_offsets):
+        """ANSBase::init_ar_params, csrc/ans/ans_interface.cpp:75-137."""
+        tab = _i32(ar_table)
+        ar_offsets = np.asarray(ar_offsets)
+        order = tab.ndim - 2
+        if ar_offsets.ndim != 3 or ar_offsets.shape[1] != order or ar_offsets.shape[0] != tab.shape[0]:
+            raise ValueError("ar_offset should be 3-dimensional with shape (ar_tables_size, ar_order, <=data_dims)")
+        if order <= 0:
+            raise ValueError("ar_tables should be at least 3-dimensional with shape (ar_tables_size, index_dim, *ar_order_dims)")
+        if order > 2:
+            raise ValueError("Too many dimensions!")
+        if self._tables is None:
+            raise ValueError("ANS not initialized!")
+        _lib.check(_lib.lib().basic_rans_tables_set_ar(self._tables, tab.ctypes.data, tab.shape[0], tab.shape[1], order, tab.shape[2]))
+        self._ar_order = order
+
+    def init_custom_ar_ops(self, ops):
+        if len(ops) > 0:
+            raise NotImplementedError("custom AR ops (csrc/ans/ar_funcs.hpp) are outside the MI355X hot path")
+
+    def get_cdfs(self):
+        if self._tables is None:
+            return np.zeros((0,), dtype=np.int32)
+        rows, mx = ctypes.c_int(), ctypes.c_int()
+        _lib.check(_lib.lib().basic_rans_tables_info(self._tables, ctypes.byref(rows), ctypes.byref(mx)))
+        out = np.zeros((rows.value, mx.value), dtype=np.int32)
+        _lib.check(_lib.lib().basic_rans_tables_get_cdfs(self._tables, out.ctypes.data, mx.value))
+        return out
+
+    def _ar_args(self, ar_indexes, ar_offsets, n):
+        if not self._ar_order:
+            return None, None, None, ()
+        if ar_offsets is None:
+            raise ValueError("ar_offsets is required for ar coding!")
+        off = _i32(ar_offsets).reshape(self._ar_order, n)
+        ai = _i32(ar_indexes).reshape(-1) if ar_indexes is not None else None
+        o1 = off[1].ctypes.data if self._ar_order == 2 else None
+        return (ai.ctypes.data if ai is not None else None), off[0].ctypes.data, o1, (off, ai)
+
+
+class Rans64Encoder(_Rans64Base):
+    def __init__(self, freq_precision=16, bypass_coding=True, bypass_precision=4):
+        super().__init__(freq_precision, bypass_coding, bypass_precision)
+        self._cache = []
+
+    def encode_with_indexes(self, symbols, indexes, ar_indexes=None, ar_offsets=None, cache=0):
+        """csrc/ans/rans64.cpp:203-361.  With ``cache`` truthy the call only buffers and returns b""."""
+        if self._tables is None:
+            raise ValueError("ANS not initialized!")
+        symbols, indexes = _i32(symbols).reshape(-1), _i32(indexes).reshape(-1)
+        if cache:
+            if self._ar_order:
+                raise NotImplementedError("cached AR encoding")
+            # reference semantics (rans64.cpp:332,343): symbols are appended in REVERSE order and
+            # flush() codes the buffer front-to-back, i.e. last call's symbols are decoded first.
+            self._cache.append((symbols.copy(), indexes.copy()))
+            return b""
+        n = indexes.size
+        ai, o0, o1, keep = self._ar_args(ar_indexes, ar_offsets, n)
+        cap = _lib.lib().basic_rans_encode_bound(n)
+        out = np.empty(cap, dtype=np.uint8)
+        out_len = ctypes.c_int64()
+        _lib.check(_lib.lib().basic_rans_encode_host(self._tables, symbols.ctypes.data, indexes.ctypes.data, n, ai, o0, o1,
+                                                     out.ctypes.data, cap, ctypes.byref(out_len)))
+        return out[: out_len.value].tobytes()
+
+    def flush(self):
+        """csrc/ans/rans64.cpp:363-386."""
+        if self._tables is None:
+            raise ValueError("ANS not initialized!")
+        # _syms = [rev(call1), rev(call2), ...] coded front-to-back == one encode call over
+        # concat(callN, ..., call1) coded back-to-front.
+        chunks, self._cache = self._cache[::-1], []
+        if chunks:
+            symbols = np.concatenate([c[0] for c in chunks])
+            indexes = np.concatenate([c[1] for c in chunks])
+        else:
+            symbols = indexes = np.zeros(0, dtype=np.int32)
+        return self.encode_with_indexes(symbols, indexes)
+
+    def peek_cache(self):
+        raise NotImplementedError("peek_cache is a debugging aid of the reference (rans64.hpp:78-86)")
+
+
+class Rans64Decoder(_Rans64Base):
+    def __init__(self, freq_precision=16, bypass_coding=True, bypass_precision=4):
+        super().__init__(freq_precision, bypass_coding, bypass_precision)
+        self._stream = None
+
+    def _close_stream(self):
+        s, self._stream = getattr(self, "_stream", None), None
+        if s:
+            try:
+                _lib.lib().basic_rans_stream_close(s)
+            except Exception:
+                pass
+
+    def __del__(self):
+        self._close_stream()
+        super().__del__()
+
+    def decode_with_indexes(self, encoded, indexes, ar_indexes=None, ar_offsets=None):
+        """csrc/ans/rans64.cpp:389-499 -- int32 array shaped like ``indexes``."""
+        if self._tables is None:
+            raise ValueError("ANS not initialized!")
+        indexes = _i32(indexes)
+        n = indexes.size
+        out = np.empty(indexes.shape, dtype=np.int32)
+        buf = np.frombuffer(bytes(encoded), dtype=np.uint8)
+        ai, o0, o1, keep = self._ar_args(ar_indexes, ar_offsets, n)
+        _lib.check(_lib.lib().basic_rans_decode_host(self._tables, buf.ctypes.data, buf.size, indexes.ctypes.data, n, ai, o0, o1,
+                                                     out.ctypes.data))
+        return out
+
+    def set_stream(self, stream):
+        """csrc/ans/rans64.hpp:104-111."""
+        if self._tables is None:
+            raise ValueError("ANS not initialized!")
+        buf = np.frombuffer(bytes(stream), dtype=np.uint8)
+        h = ctypes.c_void_p()
+        _lib.check(_lib.lib().basic_rans_stream_open(self._tables, buf.ctypes.data, buf.size, ctypes.byref(h)))
+        self._close_stream()
+        self._stream = h
+
+    def decode_stream(self, indexes, ar_indexes=None, ar_offsets=None):
+        """csrc/ans/rans64.cpp:501-598 (AR arguments are ignored there too, :529,:537)."""
+        if self._tables is None:
+            raise ValueError("ANS not initialized!")
+        if self._stream is None:
+            raise ValueError("set_stream must be called before decode_stream")
+        indexes = _i32(indexes)
+        out = np.empty(indexes.shape, dtype=np.int32)
+        _lib.check(_lib.lib().basic_rans_stream_decode(self._stream, indexes.ctypes.data, indexes.size, out.ctypes.data))
+        return out
+
+
+def _unsupported(name):
+    class _Unsupported:
+        def __init__(self, *a, **k):
+            raise NotImplementedError(
+                f"{name}: tANS (csrc/ans/tans.cpp) is out of scope of the MI355X hot path "
+                "(coder_type defaults to 'rans64', torch_ans.py:23)")
+    _Unsupported.__name__ = name
+    return _Unsupported
+
+
+TansEncoder = _unsupported("TansEncoder")
+TansDecoder = _unsupported("TansDecoder")

@@ -1,0 +1,36 @@
+// Internal helpers shared by the translation units of libbasic_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/basic_hip.h"
+
+namespace basic {
+
+void set_error(const std::string &msg);
+int hip_fail(hipError_t e, const char *what, const char *file, int line);
+
+#define BASIC_HIP_TRY(expr)                                                      \
+    do {                                                                         \
+        hipError_t _e = (expr);                                                  \
+        if (_e != hipSuccess) return ::basic::hip_fail(_e, #expr, __FILE__, __LINE__); \
+    } while (0)
+
+#define BASIC_REQUIRE(cond, msg)            \
+    do {                                    \
+        if (!(cond)) {                      \
+            ::basic::set_error(msg);        \
+            return BASIC_ERR_INVALID;       \
+        }                                   \
+    } while (0)
+
+// Fails (BASIC_ERR_NO_DEVICE) unless a HIP device is usable.  Never falls back to the CPU.
+int require_device();
+
+inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+constexpr int kWave = 64;  // CDNA wavefront
+
+}  // namespace basic

@@ -1,0 +1,453 @@
+// Analysis / synthesis transforms: tap-list implicit-GEMM convolution on the fp32 matrix core
+// (v_mfma_f32_32x32x2_f32) with LDS-staged activation patches and a fused
+// bias + {ReLU, LeakyReLU, GDN, IGDN} epilogue.
+//
+// Replaces the ATen calls behind nn/models/google.py:25-101 (compressai conv/deconv/GDN) and
+// nn/layers/slimmable_layers.py:157-183,258-282 (weight slicing = plan of the active slice).
+//
+// Formulation.  Every layer is a sum over TAPS of 1x1 GEMMs on a shifted input grid:
+//     out[co][s_out*m + o0] = bias[co] + sum_t sum_ci W_t[co][ci] * in[ci][s_in*m + d_t]
+//   * Conv2d(k, s, p):           one launch, taps = all k*k, s_in = s, s_out = 1, d = k_idx - p.
+//   * ConvTranspose2d(k, s, p):  s*s launches (sub-pixel phases); phase (py,px) keeps the taps
+//                                with ky = (py+p) mod s, s_in = 1, s_out = s, d = (py+p-ky)/s,
+//                                so no multiply-by-zero work is ever issued.
+// GEMM mapping (M = output channels, N = 128 output positions per workgroup, K = taps x Cin):
+//   * workgroup = 4 wavefronts; each wave owns ALL output channels x 32 positions, i.e. MT 32x32
+//     accumulator tiles.  Owning every channel of its pixels is what lets the GDN normalisation
+//     norm = beta + gamma . x^2 run as a SECOND MFMA GEMM straight from the accumulators:
+//     the C/D layout (column = lane, rows in registers) of x^2 IS the B-operand layout of the
+//     next 32x32x2 MFMA, with k-pairs (c, c+4) -- no LDS round trip, no lane shuffles.
+//   * K is walked CK input channels at a time: the input patch [TB][CK][PH][PW] and the packed
+//     weight slab [taps][CK][Cout] are staged in LDS; B fragments are patch reads at
+//     (s_in*pos + tap shift), A fragments are 32 consecutive output channels of one (tap, ci).
+//   * fp32 MFMA issues one 32x32x2 per 64 cycles per SIMD and each B fragment feeds MT of them,
+//     so LDS bandwidth is irrelevant here; the kernel is MFMA-issue bound by design.
+#include "common.h"
+
+#include <cstring>
+#include <new>
+#include <vector>
+
+using namespace basic;
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kCK = 4;        // input channels per LDS stage (2 MFMA k-pairs)
+constexpr int kMaxTaps = 25;  // 5x5
+constexpr int kThreads = 256;
+constexpr int kTilePos = 128;  // output positions per workgroup
+
+struct TapLaunch {
+    const float *in;
+    float *out;
+    const float *wpack;   // [cin_pad/CK][ntaps][CK][coutp]
+    const float *bias;    // [coutp] (zero padded) or nullptr
+    const float *gammaT;  // [coutp(k)][coutp(i)] effective gamma transposed, zero padded
+    const float *beta;    // [coutp]
+    int batch, cin, cin_pad, cout, coutp;
+    int in_h, in_w, out_h, out_w;
+    int mh, mw;  // m-grid of this launch
+    int s_in, s_out, oy0, ox0;
+    int ntaps, dymin, dxmin;
+    int tb_log, th_log, tw_log;  // tile = 2^tb images x 2^th x 2^tw positions (product 128)
+    int ph, pw, pwp;             // LDS patch rows / cols / padded cols
+    int act;
+    int tiles_y, tiles_x;
+    signed char dy[kMaxTaps], dx[kMaxTaps];  // relative to (dymin, dxmin)
+};
+
+__device__ __forceinline__ float apply_act(float v, int act)
+{
+    if (act == BASIC_ACT_RELU) return v > 0.f ? v : 0.f;
+    if (act == BASIC_ACT_LEAKY_RELU) return v > 0.f ? v : 0.01f * v;
+    return v;
+}
+
+template <int MT>
+__global__ __launch_bounds__(kThreads) void conv_tap_mfma_kernel(const TapLaunch g)
+{
+    extern __shared__ float lds[];
+    const int wl_floats = g.ntaps * kCK * g.coutp;
+    const int gam_floats = 32 * g.coutp;
+    float *wl = lds;                                                  // weight slab / gamma slab
+    float *patch = lds + (wl_floats > gam_floats ? wl_floats : gam_floats);  // input patch
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int khalf = lane >> 5, col = lane & 31;
+
+    // tile origin
+    int bid = blockIdx.x;
+    const int tx_i = bid % g.tiles_x; bid /= g.tiles_x;
+    const int ty_i = bid % g.tiles_y; bid /= g.tiles_y;
+    const int TB = 1 << g.tb_log, TH = 1 << g.th_log, TW = 1 << g.tw_log;
+    const int b0 = bid * TB, my0 = ty_i * TH, mx0 = tx_i * TW;
+
+    // this lane's output position inside the tile
+    const int q = wave * 32 + col;
+    const int tx = q & (TW - 1);
+    const int ty = (q >> g.tw_log) & (TH - 1);
+    const int tb = q >> (g.tw_log + g.th_log);
+
+    const int chan_stride = g.ph * g.pwp;
+    const int lane_b_base = ((tb * kCK + khalf) * g.ph + ty * g.s_in) * g.pwp + tx * g.s_in;
+    const int lane_a_base = khalf * g.coutp + col;
+
+    f32x16 acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+
+    const int patch_elems = TB * kCK * chan_stride;
+    const int gy0 = my0 * g.s_in + g.dymin, gx0 = mx0 * g.s_in + g.dxmin;
+    const int64_t in_plane = static_cast<int64_t>(g.in_h) * g.in_w;
+    const int64_t in_img = static_cast<int64_t>(g.cin) * in_plane;
+    const float *in_b0 = g.in + static_cast<int64_t>(b0) * in_img;
+
+    // Gather table, built once per workgroup: for every patch element its global offset (relative to
+    // image b0, channel 0 of the stage) packed with the in-stage channel, or -1 for zero fill.
+    int *gtab = reinterpret_cast<int *>(patch + patch_elems);
+    for (int i = tid; i < patch_elems; i += kThreads) {
+        int r = i;
+        const int px = r % g.pwp; r /= g.pwp;
+        const int py = r % g.ph; r /= g.ph;
+        const int ci = r % kCK;
+        const int pb = r / kCK;
+        const int gy = gy0 + py, gx = gx0 + px;
+        int e = -1;
+        if (px < g.pw && gy >= 0 && gy < g.in_h && gx >= 0 && gx < g.in_w && b0 + pb < g.batch)
+            e = ((pb * static_cast<int>(in_img) + gy * g.in_w + gx) << 2) | ci;
+        gtab[i] = e;
+    }
+
+    for (int c0 = 0; c0 < g.cin_pad; c0 += kCK) {
+        __syncthreads();
+        // ---- stage the weight slab (contiguous, 16 B per lane)
+        {
+            const float4 *src = reinterpret_cast<const float4 *>(g.wpack + static_cast<int64_t>(c0 / kCK) * wl_floats);
+            float4 *dst = reinterpret_cast<float4 *>(wl);
+            for (int i = tid; i < wl_floats / 4; i += kThreads) dst[i] = src[i];
+        }
+        // ---- stage the input patch (zero fill outside the image / channel range)
+        {
+            const float *in_c0 = in_b0 + static_cast<int64_t>(c0) * in_plane;
+            for (int i = tid; i < patch_elems; i += kThreads) {
+                const int e = gtab[i];
+                float v = 0.f;
+                if (e >= 0 && c0 + (e & 3) < g.cin) v = in_c0[(e >> 2) + (e & 3) * in_plane];
+                patch[i] = v;
+            }
+        }
+        __syncthreads();
+        // ---- MFMA over taps x channel pairs
+        for (int t = 0; t < g.ntaps; ++t) {
+            const int tap_off = g.dy[t] * g.pwp + g.dx[t];
+            const float *wt = wl + t * kCK * g.coutp + lane_a_base;
+#pragma unroll
+            for (int cp = 0; cp < kCK / 2; ++cp) {
+                const float bfrag = patch[lane_b_base + tap_off + cp * 2 * chan_stride];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const float afrag = wt[cp * 2 * g.coutp + m * 32];
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(afrag, bfrag, acc[m], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: bias
+    // accumulator register r of tile m, lane (khalf, col): channel 32m + 8(r>>2) + 4 khalf + (r&3)
+    if (g.bias) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][r] += g.bias[32 * m + 8 * (r >> 2) + 4 * khalf + (r & 3)];
+    }
+
+    if (g.act == BASIC_ACT_GDN || g.act == BASIC_ACT_IGDN) {
+        // norm[i][pos] = beta[i] + sum_k gammaT[k][i] * x[k][pos]^2 as a second MFMA GEMM.
+        f32x16 nrm[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) nrm[m][r] = 0.f;
+#pragma unroll
+        for (int mk = 0; mk < MT; ++mk) {  // k rows 32mk .. 32mk+31
+            __syncthreads();
+            {
+                const float4 *src = reinterpret_cast<const float4 *>(g.gammaT + static_cast<int64_t>(mk) * 32 * g.coutp);
+                float4 *dst = reinterpret_cast<float4 *>(wl);
+                for (int i = tid; i < gam_floats / 4; i += kThreads) dst[i] = src[i];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float x = acc[mk][r];
+                const float bfrag = x * x;  // k = 32mk + 8(r>>2) + (r&3) [+4 for lanes 32..63]
+                const float *gk = wl + (8 * (r >> 2) + (r & 3) + 4 * khalf) * g.coutp + col;
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+                    nrm[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(gk[m * 32], bfrag, nrm[m], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float nv = nrm[m][r] + g.beta[32 * m + 8 * (r >> 2) + 4 * khalf + (r & 3)];
+                const float s = sqrtf(nv);
+                acc[m][r] = (g.act == BASIC_ACT_GDN) ? acc[m][r] / s : acc[m][r] * s;
+            }
+    }
+
+    // ---- store
+    const int my = my0 + ty, mx = mx0 + tx, b = b0 + tb;
+    if (my < g.mh && mx < g.mw && b < g.batch) {
+        const int oy = my * g.s_out + g.oy0, ox = mx * g.s_out + g.ox0;
+        const int64_t plane = static_cast<int64_t>(g.out_h) * g.out_w;
+        float *o = g.out + static_cast<int64_t>(b) * g.cout * plane + static_cast<int64_t>(oy) * g.out_w + ox;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = 32 * m + 8 * (r >> 2) + 4 * khalf + (r & 3);
+                if (co < g.cout) o[co * plane] = apply_act(acc[m][r], g.act);
+            }
+    }
+}
+
+struct Phase {
+    int ntaps = 0, dymin = 0, dxmin = 0, span_y = 1, span_x = 1;
+    int oy0 = 0, ox0 = 0;
+    signed char dy[kMaxTaps], dx[kMaxTaps];
+    float *d_wpack = nullptr;
+};
+
+}  // namespace
+
+struct basic_conv_plan {
+    int cin = 0, cout = 0, ksize = 0, stride = 1, padding = 0, output_padding = 0, transposed = 0, act = 0;
+    int cin_pad = 0, coutp = 0, mt = 0;
+    int s_in = 1, s_out = 1;
+    std::vector<Phase> phases;
+    float *d_bias = nullptr, *d_gammaT = nullptr, *d_beta = nullptr;
+};
+
+extern "C" void basic_conv_plan_destroy(basic_conv_plan *p)
+{
+    if (!p) return;
+    for (auto &ph : p->phases)
+        if (ph.d_wpack) (void)hipFree(ph.d_wpack);
+    if (p->d_bias) (void)hipFree(p->d_bias);
+    if (p->d_gammaT) (void)hipFree(p->d_gammaT);
+    if (p->d_beta) (void)hipFree(p->d_beta);
+    delete p;
+}
+
+namespace {
+
+int upload(const std::vector<float> &h, float **d)
+{
+    BASIC_HIP_TRY(hipMalloc(d, h.size() * sizeof(float)));
+    BASIC_HIP_TRY(hipMemcpy(*d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+    return BASIC_OK;
+}
+
+}  // namespace
+
+extern "C" int basic_conv_plan_create(const float *weight, const float *bias, int cin, int cout, int ksize, int stride,
+                                      int padding, int output_padding, int transposed, int activation,
+                                      const float *gamma, const float *beta, int cin_active, int cout_active,
+                                      basic_conv_plan **out)
+{
+    BASIC_REQUIRE(weight && out && cin >= 1 && cout >= 1 && ksize >= 1 && ksize <= 5 && stride >= 1 && stride <= 2 &&
+                      padding >= 0 && padding <= ksize,
+                  "conv_plan_create: unsupported geometry (k<=5, stride<=2)");
+    BASIC_REQUIRE(cin_active >= 1 && cin_active <= cin && cout_active >= 1 && cout_active <= cout && cout_active <= 192,
+                  "conv_plan_create: active channel slice out of range (cout <= 192)");
+    BASIC_REQUIRE(activation >= BASIC_ACT_NONE && activation <= BASIC_ACT_IGDN, "conv_plan_create: bad activation");
+    const bool gdn = activation == BASIC_ACT_GDN || activation == BASIC_ACT_IGDN;
+    BASIC_REQUIRE(!gdn || (gamma && beta), "conv_plan_create: GDN needs gamma and beta");
+    int rc = require_device();
+    if (rc) return rc;
+
+    auto *p = new (std::nothrow) basic_conv_plan();
+    if (!p) { set_error("out of host memory"); return BASIC_ERR_INVALID; }
+    const int ci_n = cin_active, co_n = cout_active;
+    p->cin = ci_n; p->cout = co_n; p->ksize = ksize; p->stride = stride; p->padding = padding;
+    p->output_padding = output_padding; p->transposed = transposed ? 1 : 0; p->act = activation;
+    p->cin_pad = (ci_n + kCK - 1) / kCK * kCK;
+    p->mt = (co_n + 31) / 32;
+    p->coutp = p->mt * 32;
+    p->s_in = transposed ? 1 : stride;
+    p->s_out = transposed ? stride : 1;
+
+    // ---- tap lists
+    const int nph = transposed ? stride : 1;
+    for (int py = 0; py < nph; ++py)
+        for (int px = 0; px < nph; ++px) {
+            Phase ph;
+            ph.oy0 = py; ph.ox0 = px;
+            std::vector<int> kys, kxs, dys, dxs;
+            for (int k = 0; k < ksize; ++k) {
+                if (!transposed) { kys.push_back(k); dys.push_back(k - padding); }
+                else if ((py + padding - k) % stride == 0) { kys.push_back(k); dys.push_back((py + padding - k) / stride); }
+            }
+            for (int k = 0; k < ksize; ++k) {
+                if (!transposed) { kxs.push_back(k); dxs.push_back(k - padding); }
+                else if ((px + padding - k) % stride == 0) { kxs.push_back(k); dxs.push_back((px + padding - k) / stride); }
+            }
+            if (kys.empty() || kxs.empty()) {  // phase receives only the bias
+                ph.ntaps = 0;
+                p->phases.push_back(ph);
+                continue;
+            }
+            int dymin = dys[0], dymax = dys[0], dxmin = dxs[0], dxmax = dxs[0];
+            for (int v : dys) { dymin = v < dymin ? v : dymin; dymax = v > dymax ? v : dymax; }
+            for (int v : dxs) { dxmin = v < dxmin ? v : dxmin; dxmax = v > dxmax ? v : dxmax; }
+            ph.dymin = dymin; ph.dxmin = dxmin; ph.span_y = dymax - dymin + 1; ph.span_x = dxmax - dxmin + 1;
+            std::vector<std::pair<int, int>> taps;  // (ky, kx)
+            for (size_t a = 0; a < kys.size(); ++a)
+                for (size_t b = 0; b < kxs.size(); ++b) {
+                    ph.dy[ph.ntaps] = static_cast<signed char>(dys[a] - dymin);
+                    ph.dx[ph.ntaps] = static_cast<signed char>(dxs[b] - dxmin);
+                    taps.emplace_back(kys[a], kxs[b]);
+                    ++ph.ntaps;
+                }
+            // ---- pack weights: [cin_pad/CK][ntaps][CK][coutp]
+            std::vector<float> wp(static_cast<size_t>(p->cin_pad) * ph.ntaps * p->coutp, 0.f);
+            for (int c = 0; c < ci_n; ++c)
+                for (int t = 0; t < ph.ntaps; ++t)
+                    for (int o = 0; o < co_n; ++o) {
+                        const int ky = taps[t].first, kx = taps[t].second;
+                        const float w = transposed
+                            ? weight[((static_cast<size_t>(c) * cout + o) * ksize + ky) * ksize + kx]
+                            : weight[((static_cast<size_t>(o) * cin + c) * ksize + ky) * ksize + kx];
+                        wp[((static_cast<size_t>(c / kCK) * ph.ntaps + t) * kCK + (c % kCK)) * p->coutp + o] = w;
+                    }
+            rc = upload(wp, &ph.d_wpack);
+            p->phases.push_back(ph);
+            if (rc) { basic_conv_plan_destroy(p); return rc; }
+        }
+
+    std::vector<float> hb(p->coutp, 0.f);
+    if (bias) std::memcpy(hb.data(), bias, sizeof(float) * co_n);
+    rc = upload(hb, &p->d_bias);
+    if (!rc && gdn) {
+        // gamma [cout][cout] effective -> gammaT[k][i] = gamma[i][k], zero padded; beta padded with 1
+        std::vector<float> gt(static_cast<size_t>(p->coutp) * p->coutp, 0.f), bt(p->coutp, 1.f);
+        for (int i = 0; i < co_n; ++i) {
+            bt[i] = beta[i];
+            for (int k = 0; k < co_n; ++k) gt[static_cast<size_t>(k) * p->coutp + i] = gamma[static_cast<size_t>(i) * cout + k];
+        }
+        rc = upload(gt, &p->d_gammaT);
+        if (!rc) rc = upload(bt, &p->d_beta);
+    }
+    if (rc) { basic_conv_plan_destroy(p); return rc; }
+    *out = p;
+    return BASIC_OK;
+}
+
+extern "C" int basic_conv_plan_out_hw(const basic_conv_plan *p, int in_h, int in_w, int *out_h, int *out_w)
+{
+    BASIC_REQUIRE(p && in_h >= 1 && in_w >= 1, "conv_plan_out_hw: bad argument");
+    int oh, ow;
+    if (p->transposed) {
+        oh = (in_h - 1) * p->stride - 2 * p->padding + p->ksize + p->output_padding;
+        ow = (in_w - 1) * p->stride - 2 * p->padding + p->ksize + p->output_padding;
+    } else {
+        oh = (in_h + 2 * p->padding - p->ksize) / p->stride + 1;
+        ow = (in_w + 2 * p->padding - p->ksize) / p->stride + 1;
+    }
+    BASIC_REQUIRE(oh >= 1 && ow >= 1, "conv_plan_out_hw: empty output");
+    if (out_h) *out_h = oh;
+    if (out_w) *out_w = ow;
+    return BASIC_OK;
+}
+
+extern "C" int64_t basic_conv_plan_flops(const basic_conv_plan *p, int batch, int in_h, int in_w)
+{
+    int oh = 0, ow = 0;
+    if (!p || basic_conv_plan_out_hw(p, in_h, in_w, &oh, &ow)) return -1;
+    // conv MACs: every (input position, tap, ci, co) of a transposed conv / (output position, tap, ci, co) of a conv
+    int64_t macs = p->transposed
+        ? static_cast<int64_t>(in_h) * in_w * p->ksize * p->ksize * p->cin * p->cout
+        : static_cast<int64_t>(oh) * ow * p->ksize * p->ksize * p->cin * p->cout;
+    if (p->act == BASIC_ACT_GDN || p->act == BASIC_ACT_IGDN) macs += static_cast<int64_t>(oh) * ow * p->cout * p->cout;
+    return 2 * macs * batch;
+}
+
+namespace {
+
+template <int MT>
+int launch_mt(const TapLaunch &g, int blocks, size_t lds_bytes, hipStream_t st)
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        BASIC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_tap_mfma_kernel<MT>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(conv_tap_mfma_kernel<MT>, dim3(blocks), dim3(kThreads), lds_bytes, st, g);
+    BASIC_HIP_TRY(hipGetLastError());
+    return BASIC_OK;
+}
+
+int ilog2(int v) { int l = 0; while ((1 << (l + 1)) <= v) ++l; return l; }
+int pow2_ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+
+}  // namespace
+
+extern "C" int basic_conv_forward_dev(const basic_conv_plan *p, const float *d_in, int batch, int in_h, int in_w,
+                                      float *d_out, void *hip_stream)
+{
+    BASIC_REQUIRE(p && d_in && d_out && batch >= 1, "conv_forward: bad argument");
+    int oh = 0, ow = 0;
+    int rc = basic_conv_plan_out_hw(p, in_h, in_w, &oh, &ow);
+    if (rc) return rc;
+    for (const Phase &ph : p->phases) {
+        TapLaunch g{};
+        g.in = d_in; g.out = d_out; g.wpack = ph.d_wpack; g.bias = p->d_bias; g.gammaT = p->d_gammaT; g.beta = p->d_beta;
+        g.batch = batch; g.cin = p->cin; g.cin_pad = ph.ntaps ? p->cin_pad : 0; g.cout = p->cout; g.coutp = p->coutp;
+        g.in_h = in_h; g.in_w = in_w; g.out_h = oh; g.out_w = ow;
+        g.s_in = p->s_in; g.s_out = p->s_out; g.oy0 = ph.oy0; g.ox0 = ph.ox0;
+        g.mh = (oh - ph.oy0 + p->s_out - 1) / p->s_out;
+        g.mw = (ow - ph.ox0 + p->s_out - 1) / p->s_out;
+        if (g.mh <= 0 || g.mw <= 0) continue;
+        g.ntaps = ph.ntaps; g.dymin = ph.dymin; g.dxmin = ph.dxmin;
+        std::memcpy(g.dy, ph.dy, sizeof(g.dy));
+        std::memcpy(g.dx, ph.dx, sizeof(g.dx));
+        g.act = p->act;
+        // tile shape: 128 positions = TB images x TH x TW, powers of two, preferring wide rows
+        int tw = pow2_ceil(g.mw); if (tw > 16) tw = 16;
+        int th = pow2_ceil(g.mh); if (th > kTilePos / tw) th = kTilePos / tw;
+        int tb = kTilePos / (tw * th);
+        g.tw_log = ilog2(tw); g.th_log = ilog2(th); g.tb_log = ilog2(tb);
+        g.ph = (th - 1) * g.s_in + ph.span_y;
+        g.pw = (tw - 1) * g.s_in + ph.span_x;
+        g.pwp = g.pw | 1;  // odd row pitch
+        g.tiles_y = (g.mh + th - 1) / th;
+        g.tiles_x = (g.mw + tw - 1) / tw;
+        const int blocks = ((batch + tb - 1) / tb) * g.tiles_y * g.tiles_x;
+        const int wl_floats = g.ntaps * kCK * g.coutp, gam_floats = 32 * g.coutp;
+        const size_t lds_bytes = sizeof(float) * (static_cast<size_t>(wl_floats > gam_floats ? wl_floats : gam_floats) +
+                                                 2 * static_cast<size_t>(tb) * kCK * g.ph * g.pwp);
+        BASIC_REQUIRE(static_cast<int64_t>(tb) * p->cin * in_h * in_w < (1ll << 29), "conv_forward: input tile too large");
+        BASIC_REQUIRE(lds_bytes <= 160 * 1024, "conv_forward: LDS budget exceeded");
+        hipStream_t st = as_stream(hip_stream);
+        switch (p->mt) {
+            case 1: rc = launch_mt<1>(g, blocks, lds_bytes, st); break;
+            case 2: rc = launch_mt<2>(g, blocks, lds_bytes, st); break;
+            case 3: rc = launch_mt<3>(g, blocks, lds_bytes, st); break;
+            case 4: rc = launch_mt<4>(g, blocks, lds_bytes, st); break;
+            case 5: rc = launch_mt<5>(g, blocks, lds_bytes, st); break;
+            case 6: rc = launch_mt<6>(g, blocks, lds_bytes, st); break;
+            default: set_error("conv_forward: cout > 192 unsupported"); rc = BASIC_ERR_INVALID;
+        }
+        if (rc) return rc;
+    }
+    return BASIC_OK;
+}

@@ -1,0 +1,249 @@
+// Entropy-parameter kernels: fused quantise + table-index evaluation, coalesced over HBM.
+// These are pure streaming kernels (a few bytes in, 8 bytes out per latent): the only rules
+// that matter are full-width coalesced accesses and enough workgroups to cover 256 CUs.
+//
+// Reference semantics:
+//   GaussianConditional.build_indexes / quantize  (CompressAI 1.2.3, quoted at
+//       modules/prior_model/prior_coder/pgm_coder.py:814-818; call site compressai_coder.py:377-393)
+//   EntropyBottleneck.compress/decompress         (call site compressai_coder.py:230-245)
+//   GaussianPGMPriorCoderImpl._select_best_indexes pgm_coder.py:802-821
+//   TopoGroupPGMPriorCoder group step              pgm_coder.py:921-941, 962-978
+#include "common.h"
+
+using namespace basic;
+
+namespace {
+
+constexpr int kBlock = 256;
+
+inline int grid_for(int64_t n)
+{
+    int64_t g = (n + kBlock - 1) / kBlock;
+    if (g > 256 * 8) g = 256 * 8;  // grid-stride the rest
+    if (g < 1) g = 1;
+    return static_cast<int>(g);
+}
+
+// torch.round / rintf: round half to even (v_rndne_f32).
+__device__ __forceinline__ float round_even(float v) { return rintf(v); }
+
+__global__ void gc_quantize_index_kernel(const float *__restrict__ y, const float *__restrict__ scales, int64_t n,
+                                         const float *__restrict__ table, int table_len, float bound,
+                                         int32_t *__restrict__ symbols, int32_t *__restrict__ indexes,
+                                         float *__restrict__ yhat)
+{
+    extern __shared__ float s_table[];
+    for (int i = threadIdx.x; i < table_len; i += blockDim.x) s_table[i] = table[i];
+    __syncthreads();
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n;
+         i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        const float s = fmaxf(scales[i], bound);  // LowerBound
+        int idx = table_len - 1;
+        for (int j = 0; j < table_len - 1; ++j) idx -= (s <= s_table[j]) ? 1 : 0;
+        const float q = round_even(y[i]);
+        symbols[i] = static_cast<int32_t>(q);
+        indexes[i] = idx;
+        if (yhat) yhat[i] = q;
+    }
+}
+
+__global__ void eb_quantize_index_kernel(const float *__restrict__ z, const float *__restrict__ medians, int64_t total,
+                                         int channels, int hw, int32_t *__restrict__ symbols,
+                                         int32_t *__restrict__ indexes, float *__restrict__ zhat)
+{
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < total;
+         i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        const int c = static_cast<int>((i / hw) % channels);
+        const float m = medians[c];
+        const float q = round_even(z[i] - m);
+        symbols[i] = static_cast<int32_t>(q);
+        indexes[i] = c;
+        if (zhat) zhat[i] = q + m;
+    }
+}
+
+__global__ void eb_dequantize_kernel(const int32_t *__restrict__ symbols, const float *__restrict__ medians,
+                                     int64_t total, int channels, int hw, float *__restrict__ zhat)
+{
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < total;
+         i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        const int c = static_cast<int>((i / hw) % channels);
+        zhat[i] = static_cast<float>(symbols[i]) + medians[c];
+    }
+}
+
+__global__ void i32_to_f32_kernel(const int32_t *__restrict__ in, int64_t n, float *__restrict__ out)
+{
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n;
+         i += static_cast<int64_t>(gridDim.x) * blockDim.x)
+        out[i] = static_cast<float>(in[i]);
+}
+
+// argmin_j |s - table[j]|, first minimum (torch.argmin on CPU returns the first occurrence).
+__device__ __forceinline__ int nearest_scale(float s, const float *tab, int n)
+{
+    int best = 0;
+    float bd = fabsf(s - tab[0]);
+    for (int j = 1; j < n; ++j) {
+        const float d = fabsf(s - tab[j]);
+        if (d < bd) { bd = d; best = j; }
+    }
+    return best;
+}
+
+// MODE 0: encode (symbols + indexes + write-back), 1: indexes only, 2: scatter decoded symbols.
+template <int MODE>
+__global__ void pgm_gauss_group_kernel(const float *__restrict__ y, const float *__restrict__ params, int batch,
+                                       int channels, int hw, const int32_t *__restrict__ elems, int64_t n_elems,
+                                       const float *__restrict__ table, int table_len, int32_t *symbols,
+                                       int32_t *indexes, int64_t per_image, int64_t out_base, float *ybuf)
+{
+    extern __shared__ float s_table[];
+    if (MODE != 2) {
+        for (int i = threadIdx.x; i < table_len; i += blockDim.x) s_table[i] = table[i];
+        __syncthreads();
+    }
+    const int64_t total = static_cast<int64_t>(batch) * n_elems;
+    const int64_t chw = static_cast<int64_t>(channels) * hw;
+    for (int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; t < total;
+         t += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        const int64_t b = t / n_elems, k = t - b * n_elems;
+        const int32_t e = elems[k];  // c*hw + p
+        const int c = e / hw, p = e - c * hw;
+        // split_interleave: channel 2c = mean, 2c+1 = scale (pgm_coder.py:743-752)
+        const float *pb = params + (b * 2 * chw) + static_cast<int64_t>(2 * c) * hw + p;
+        const float mu = pb[0];
+        const int64_t o = b * per_image + out_base + k;
+        if (MODE == 0 || MODE == 1) indexes[o] = nearest_scale(pb[hw], s_table, table_len);
+        if (MODE == 0) {
+            const float q = round_even(y[b * chw + e] - mu);
+            symbols[o] = static_cast<int32_t>(q);
+            ybuf[b * chw + e] = q + mu;
+        }
+        if (MODE == 2) ybuf[b * chw + e] = static_cast<float>(symbols[o]) + mu;
+    }
+}
+
+__global__ void mse_per_image_kernel(const float *__restrict__ a, const float *__restrict__ b, int64_t elems,
+                                     float *__restrict__ mse)
+{
+    // one workgroup per image; pairwise tree in LDS (deterministic order)
+    __shared__ float red[kBlock];
+    const int img = blockIdx.x;
+    const float *pa = a + static_cast<int64_t>(img) * elems, *pb = b + static_cast<int64_t>(img) * elems;
+    float acc = 0.f;
+    for (int64_t i = threadIdx.x; i < elems; i += blockDim.x) {
+        const float d = pa[i] - pb[i];
+        acc += d * d;
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = kBlock / 2; s > 0; s >>= 1) {
+        if (static_cast<int>(threadIdx.x) < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) mse[img] = red[0] / static_cast<float>(elems);
+}
+
+}  // namespace
+
+extern "C" int basic_gc_quantize_index_dev(const float *d_y, const float *d_scales, int64_t n, const float *d_table,
+                                           int table_len, float scale_bound, int32_t *d_symbols, int32_t *d_indexes,
+                                           float *d_yhat, void *hip_stream)
+{
+    BASIC_REQUIRE(d_y && d_scales && d_table && d_symbols && d_indexes && n >= 0 && table_len >= 1 && table_len <= 4096,
+                  "gc_quantize_index: bad argument");
+    if (n == 0) return BASIC_OK;
+    hipLaunchKernelGGL(gc_quantize_index_kernel, dim3(grid_for(n)), dim3(kBlock), table_len * sizeof(float),
+                       as_stream(hip_stream), d_y, d_scales, n, d_table, table_len, scale_bound, d_symbols, d_indexes, d_yhat);
+    BASIC_HIP_TRY(hipGetLastError());
+    return BASIC_OK;
+}
+
+extern "C" int basic_eb_quantize_index_dev(const float *d_z, const float *d_medians, int batch, int channels, int hw,
+                                           int32_t *d_symbols, int32_t *d_indexes, float *d_zhat, void *hip_stream)
+{
+    BASIC_REQUIRE(d_z && d_medians && d_symbols && d_indexes && batch >= 1 && channels >= 1 && hw >= 1,
+                  "eb_quantize_index: bad argument");
+    const int64_t total = static_cast<int64_t>(batch) * channels * hw;
+    hipLaunchKernelGGL(eb_quantize_index_kernel, dim3(grid_for(total)), dim3(kBlock), 0, as_stream(hip_stream), d_z,
+                       d_medians, total, channels, hw, d_symbols, d_indexes, d_zhat);
+    BASIC_HIP_TRY(hipGetLastError());
+    return BASIC_OK;
+}
+
+extern "C" int basic_eb_dequantize_dev(const int32_t *d_symbols, const float *d_medians, int batch, int channels,
+                                       int hw, float *d_zhat, void *hip_stream)
+{
+    BASIC_REQUIRE(d_symbols && d_medians && d_zhat && batch >= 1 && channels >= 1 && hw >= 1, "eb_dequantize: bad argument");
+    const int64_t total = static_cast<int64_t>(batch) * channels * hw;
+    hipLaunchKernelGGL(eb_dequantize_kernel, dim3(grid_for(total)), dim3(kBlock), 0, as_stream(hip_stream), d_symbols,
+                       d_medians, total, channels, hw, d_zhat);
+    BASIC_HIP_TRY(hipGetLastError());
+    return BASIC_OK;
+}
+
+extern "C" int basic_i32_to_f32_dev(const int32_t *d_in, int64_t n, float *d_out, void *hip_stream)
+{
+    BASIC_REQUIRE(d_in && d_out && n >= 0, "i32_to_f32: bad argument");
+    if (n == 0) return BASIC_OK;
+    hipLaunchKernelGGL(i32_to_f32_kernel, dim3(grid_for(n)), dim3(kBlock), 0, as_stream(hip_stream), d_in, n, d_out);
+    BASIC_HIP_TRY(hipGetLastError());
+    return BASIC_OK;
+}
+
+extern "C" int basic_pgm_gauss_encode_group_dev(const float *d_y, const float *d_params, int batch, int channels,
+                                                int hw, const int32_t *d_elems, int64_t n_elems, const float *d_table,
+                                                int table_len, int32_t *d_symbols, int32_t *d_indexes,
+                                                int64_t per_image, int64_t out_base, float *d_ybuf, void *hip_stream)
+{
+    BASIC_REQUIRE(d_y && d_params && d_elems && d_table && d_symbols && d_indexes && d_ybuf && batch >= 1 &&
+                      channels >= 1 && hw >= 1 && n_elems >= 0 && table_len >= 1 && table_len <= 4096,
+                  "pgm_gauss_encode_group: bad argument");
+    if (n_elems == 0) return BASIC_OK;
+    hipLaunchKernelGGL(pgm_gauss_group_kernel<0>, dim3(grid_for(batch * n_elems)), dim3(kBlock),
+                       table_len * sizeof(float), as_stream(hip_stream), d_y, d_params, batch, channels, hw, d_elems,
+                       n_elems, d_table, table_len, d_symbols, d_indexes, per_image, out_base, d_ybuf);
+    BASIC_HIP_TRY(hipGetLastError());
+    return BASIC_OK;
+}
+
+extern "C" int basic_pgm_gauss_index_group_dev(const float *d_params, int batch, int channels, int hw,
+                                               const int32_t *d_elems, int64_t n_elems, const float *d_table,
+                                               int table_len, int32_t *d_indexes, int64_t per_image, int64_t out_base,
+                                               void *hip_stream)
+{
+    BASIC_REQUIRE(d_params && d_elems && d_table && d_indexes && batch >= 1 && channels >= 1 && hw >= 1 &&
+                      n_elems >= 0 && table_len >= 1 && table_len <= 4096,
+                  "pgm_gauss_index_group: bad argument");
+    if (n_elems == 0) return BASIC_OK;
+    hipLaunchKernelGGL(pgm_gauss_group_kernel<1>, dim3(grid_for(batch * n_elems)), dim3(kBlock),
+                       table_len * sizeof(float), as_stream(hip_stream), nullptr, d_params, batch, channels, hw,
+                       d_elems, n_elems, d_table, table_len, nullptr, d_indexes, per_image, out_base, nullptr);
+    BASIC_HIP_TRY(hipGetLastError());
+    return BASIC_OK;
+}
+
+extern "C" int basic_pgm_gauss_scatter_group_dev(const int32_t *d_symbols, const float *d_params, int batch,
+                                                 int channels, int hw, const int32_t *d_elems, int64_t n_elems,
+                                                 int64_t per_image, int64_t in_base, float *d_ybuf, void *hip_stream)
+{
+    BASIC_REQUIRE(d_symbols && d_params && d_elems && d_ybuf && batch >= 1 && channels >= 1 && hw >= 1 && n_elems >= 0,
+                  "pgm_gauss_scatter_group: bad argument");
+    if (n_elems == 0) return BASIC_OK;
+    hipLaunchKernelGGL(pgm_gauss_group_kernel<2>, dim3(grid_for(batch * n_elems)), dim3(kBlock), 0,
+                       as_stream(hip_stream), nullptr, d_params, batch, channels, hw, d_elems, n_elems, nullptr, 0,
+                       const_cast<int32_t *>(d_symbols), nullptr, per_image, in_base, d_ybuf);
+    BASIC_HIP_TRY(hipGetLastError());
+    return BASIC_OK;
+}
+
+extern "C" int basic_mse_per_image_dev(const float *d_a, const float *d_b, int batch, int64_t elems_per_image,
+                                       float *d_mse, void *hip_stream)
+{
+    BASIC_REQUIRE(d_a && d_b && d_mse && batch >= 1 && elems_per_image >= 1, "mse_per_image: bad argument");
+    hipLaunchKernelGGL(mse_per_image_kernel, dim3(batch), dim3(kBlock), 0, as_stream(hip_stream), d_a, d_b,
+                       elems_per_image, d_mse);
+    BASIC_HIP_TRY(hipGetLastError());
+    return BASIC_OK;
+}

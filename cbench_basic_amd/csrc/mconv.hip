@@ -1,0 +1,183 @@
+// Topo-group masked convolution evaluated ONLY at a list of positions (the positions of the
+// topo group being coded), on the fp32 matrix core.
+//
+// Reference: TopoGroupDynamicMaskConv2d.forward, nn/layers/masked_conv.py:102-228
+//     out[b, co, p] = bias[co] + sum_{ci, tap} W[co, ci, tap] * x[b, ci, p + tap]
+//                                 * [ topo_in[g_in(ci), p + tap]  (< or <=)  topo_out[g_out(co), p] ]
+//   with g_in(ci) = ci / (Cin/Gi), g_out(co) = co / (Cout/Go) (contiguous channel groups,
+//   masked_conv.py:170-172,211-212), zero padding excluded from the sum (:125), "<=" when
+//   allow_same_topogroup_conv (:168-169).  The 5x5 context conv and the 1x1 "param merger"
+//   layers (pgm_coder.py:1215-1239,1621-1630; masked_conv.py:262-300) are all this one operator.
+//
+// The reference recomputes the full H x W map for every topo group (pgm_coder.py:922-924,
+// 958-961).  Here a launch touches only the listed positions, and a whole (tap, input group)
+// slab is skipped when its mask is empty for all 32 positions of the wave -- for causal
+// patterns that removes most of the K loop.
+//
+// Mapping: one wavefront = one 32-row tile of ONE output channel group x 32 listed positions.
+// A fragments are coalesced 128-byte rows of the packed weights [tap][ci][co]; B fragments are
+// gathered from x with the mask applied as a select (so masked garbage, even NaN, never enters
+// the sum -- the reference multiplies by 0 instead, which only differs for non-finite data).
+#include "common.h"
+
+#include <cstring>
+#include <new>
+#include <vector>
+
+using namespace basic;
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct MaskedLaunch {
+    const float *x;        // [B][cin][H][W]
+    float *y;              // [B][out_total][H][W], this layer writes channels out_off .. out_off+cout
+    const float *w;        // [ntaps][cin][coutp]
+    const float *bias;     // [coutp]
+    const int32_t *topo_in;   // [gi][H][W]
+    const int32_t *topo_out;  // [go][H][W]
+    const int32_t *pos;    // [n_pos] flat b*H*W + p
+    int64_t n_pos;
+    int batch, cin, cout, coutp, h, w_, gi, go, gs_in, gs_out, tiles_per_group;
+    int out_total, out_off, ntaps, pad, ksize, allow_same, act;
+};
+
+__global__ __launch_bounds__(64) void masked_conv_pos_kernel(const MaskedLaunch g)
+{
+    const int lane = threadIdx.x, col = lane & 31, khalf = lane >> 5;
+    const int tile = blockIdx.y;
+    const int grp_o = tile / g.tiles_per_group, ti = tile - grp_o * g.tiles_per_group;
+    const int row_in_group = ti * 32 + col;                 // A-fragment row of this lane
+    const bool row_ok = row_in_group < g.gs_out;
+    const int co_a = grp_o * g.gs_out + row_in_group;       // output channel of the A row
+
+    const int64_t pj = static_cast<int64_t>(blockIdx.x) * 32 + col;
+    const bool pos_ok = pj < g.n_pos;
+    const int hw = g.h * g.w_;
+    int b = 0, py = 0, px = 0;
+    if (pos_ok) {
+        const int32_t f = g.pos[pj];
+        b = f / hw;
+        const int p = f - b * hw;
+        py = p / g.w_;
+        px = p - py * g.w_;
+    }
+    const int32_t centre = pos_ok ? g.topo_out[grp_o * hw + py * g.w_ + px] : 0;
+    const float *xb = g.x + static_cast<int64_t>(b) * g.cin * hw;
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    for (int t = 0; t < g.ntaps; ++t) {
+        const int dy = t / g.ksize - g.pad, dx = t % g.ksize - g.pad;
+        const int yy = py + dy, xx = px + dx;
+        const bool inside = pos_ok && yy >= 0 && yy < g.h && xx >= 0 && xx < g.w_;
+        const int noff = yy * g.w_ + xx;
+        for (int gin = 0; gin < g.gi; ++gin) {
+            bool open = false;
+            if (inside) {
+                const int32_t tn = g.topo_in[gin * hw + noff];
+                open = g.allow_same ? (tn <= centre) : (tn < centre);
+            }
+            if (__ballot(open) == 0ull) continue;  // wave-uniform skip of an all-masked slab
+            const int c_beg = gin * g.gs_in, c_end = c_beg + g.gs_in;
+            const float *wt = g.w + (static_cast<int64_t>(t) * g.cin) * g.coutp + co_a;
+            for (int c = c_beg; c < c_end; c += 2) {
+                const int ci = c + khalf;
+                const bool ci_ok = ci < c_end;
+                float bfrag = 0.f, afrag = 0.f;
+                if (open && ci_ok) bfrag = xb[static_cast<int64_t>(ci) * hw + noff];
+                if (row_ok && ci_ok) afrag = wt[static_cast<int64_t>(ci) * g.coutp];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(afrag, bfrag, acc, 0, 0, 0);
+            }
+        }
+    }
+
+    if (pos_ok) {
+        float *yb = g.y + (static_cast<int64_t>(b) * g.out_total + g.out_off) * hw + py * g.w_ + px;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rg = ti * 32 + 8 * (r >> 2) + 4 * khalf + (r & 3);
+            if (rg < g.gs_out) {
+                const int co = grp_o * g.gs_out + rg;
+                float v = acc[r] + g.bias[co];
+                if (g.act == BASIC_ACT_LEAKY_RELU) v = v > 0.f ? v : 0.01f * v;
+                else if (g.act == BASIC_ACT_RELU) v = v > 0.f ? v : 0.f;
+                yb[static_cast<int64_t>(co) * hw] = v;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+struct basic_mconv_plan {
+    int cin = 0, cout = 0, coutp = 0, ksize = 1, gi = 1, go = 1, allow_same = 0, act = 0;
+    float *d_w = nullptr, *d_bias = nullptr;
+};
+
+extern "C" void basic_mconv_plan_destroy(basic_mconv_plan *p)
+{
+    if (!p) return;
+    if (p->d_w) (void)hipFree(p->d_w);
+    if (p->d_bias) (void)hipFree(p->d_bias);
+    delete p;
+}
+
+extern "C" int basic_mconv_plan_create(const float *weight, const float *bias, int cin, int cout, int ksize,
+                                       int in_groups, int out_groups, int allow_same_topogroup, int activation,
+                                       basic_mconv_plan **out)
+{
+    BASIC_REQUIRE(weight && out && cin >= 1 && cout >= 1 && (ksize == 1 || ksize == 3 || ksize == 5),
+                  "mconv_plan_create: bad geometry (odd kernel <= 5)");
+    BASIC_REQUIRE(in_groups >= 1 && out_groups >= 1 && cin % in_groups == 0 && cout % out_groups == 0,
+                  "mconv_plan_create: channels must divide into the channel groups");
+    BASIC_REQUIRE(activation == BASIC_ACT_NONE || activation == BASIC_ACT_RELU || activation == BASIC_ACT_LEAKY_RELU,
+                  "mconv_plan_create: bad activation");
+    int rc = require_device();
+    if (rc) return rc;
+    auto *p = new (std::nothrow) basic_mconv_plan();
+    if (!p) { set_error("out of host memory"); return BASIC_ERR_INVALID; }
+    p->cin = cin; p->cout = cout; p->coutp = (cout + 3) / 4 * 4; p->ksize = ksize;
+    p->gi = in_groups; p->go = out_groups; p->allow_same = allow_same_topogroup ? 1 : 0; p->act = activation;
+    const int ntaps = ksize * ksize;
+    std::vector<float> wp(static_cast<size_t>(ntaps) * cin * p->coutp, 0.f), hb(p->coutp, 0.f);
+    for (int o = 0; o < cout; ++o)
+        for (int c = 0; c < cin; ++c)
+            for (int t = 0; t < ntaps; ++t)
+                wp[(static_cast<size_t>(t) * cin + c) * p->coutp + o] = weight[(static_cast<size_t>(o) * cin + c) * ntaps + t];
+    if (bias) std::memcpy(hb.data(), bias, sizeof(float) * cout);
+    hipError_t e = hipMalloc(&p->d_w, wp.size() * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(p->d_w, wp.data(), wp.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc(&p->d_bias, hb.size() * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(p->d_bias, hb.data(), hb.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { basic_mconv_plan_destroy(p); return hip_fail(e, "mconv_plan_create", __FILE__, __LINE__); }
+    *out = p;
+    return BASIC_OK;
+}
+
+extern "C" int basic_mconv_forward_pos_dev(const basic_mconv_plan *p, const float *d_x, const int32_t *d_topo_in,
+                                           const int32_t *d_topo_out, int batch, int h, int w, const int32_t *d_pos,
+                                           int64_t n_pos, float *d_y, int out_channels_total, int out_channel_offset,
+                                           void *hip_stream)
+{
+    BASIC_REQUIRE(p && d_x && d_topo_in && d_topo_out && d_pos && d_y && batch >= 1 && h >= 1 && w >= 1 && n_pos >= 0,
+                  "mconv_forward_pos: bad argument");
+    BASIC_REQUIRE(out_channel_offset >= 0 && out_channel_offset + p->cout <= out_channels_total,
+                  "mconv_forward_pos: output channel window out of range");
+    BASIC_REQUIRE(static_cast<int64_t>(batch) * h * w < (1ll << 31), "mconv_forward_pos: position index overflow");
+    if (n_pos == 0) return BASIC_OK;
+    MaskedLaunch g{};
+    g.x = d_x; g.y = d_y; g.w = p->d_w; g.bias = p->d_bias; g.topo_in = d_topo_in; g.topo_out = d_topo_out;
+    g.pos = d_pos; g.n_pos = n_pos; g.batch = batch; g.cin = p->cin; g.cout = p->cout; g.coutp = p->coutp;
+    g.h = h; g.w_ = w; g.gi = p->gi; g.go = p->go; g.gs_in = p->cin / p->gi; g.gs_out = p->cout / p->go;
+    g.tiles_per_group = (g.gs_out + 31) / 32;
+    g.out_total = out_channels_total; g.out_off = out_channel_offset;
+    g.ntaps = p->ksize * p->ksize; g.pad = p->ksize / 2; g.ksize = p->ksize; g.allow_same = p->allow_same; g.act = p->act;
+    const dim3 grid(static_cast<unsigned>((n_pos + 31) / 32), static_cast<unsigned>(g.tiles_per_group * g.go));
+    hipLaunchKernelGGL(masked_conv_pos_kernel, grid, dim3(64), 0, as_stream(hip_stream), g);
+    BASIC_HIP_TRY(hipGetLastError());
+    return BASIC_OK;
+}

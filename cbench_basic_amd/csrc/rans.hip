@@ -1,0 +1,753 @@
+// rANS (64-bit state, 32-bit words) for gfx950: tables, batched stream kernels and the
+// host-buffer drop-in entry points.
+//
+// Bitstream contract (bit-exact with the reference):
+//   tables   csrc/ans/rans64.cpp:69-182      encoder  csrc/ans/rans64.cpp:203-361
+//   decoder  csrc/ans/rans64.cpp:389-598     raw bits csrc/ans/rans64.cpp:29-65
+//   core     csrc/ans/rans64.h:59-142 (ryg rans64)
+//
+// MI355X mapping: a stream is a strictly serial chain, so parallelism is ACROSS streams:
+// one 64-lane wavefront per stream (one image), hundreds of streams per launch.  Inside a
+// wave the 64 lanes do everything that is NOT serial -- table lookups, exact-division
+// reciprocals, the CDF search (64-ary, one ballot per probe) and coalesced loads/stores --
+// while the serial state update runs on wave-uniform values (scalar ALU).
+#include "common.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <vector>
+
+using namespace basic;
+
+// ---------------------------------------------------------------------------------------
+// Host side: tables
+// ---------------------------------------------------------------------------------------
+struct basic_rans_tables {
+    int rows = 0, stride = 0;
+    int precision = 16, bypass = 1, bypass_precision = 4;
+    std::vector<int32_t> cdfs, sizes, offsets;  // host copies
+    int32_t *d_cdfs = nullptr, *d_sizes = nullptr, *d_offsets = nullptr;
+    int ar_k = 0, ar_rows = 0, ar_order = 0, ar_s1 = 0;
+    std::vector<int32_t> ar;
+    int32_t *d_ar = nullptr;
+};
+
+namespace {
+
+// float32 pmf -> integer cdf summing to 2^precision (reference: rans64.cpp:69-126).
+// All arithmetic is kept in the reference's types: float product, round-half-away, u32 total,
+// u64 rescale, then the "steal one count from the narrowest bin wider than 1" repair.
+int quantize_pmf(const float *pmf, int n, int precision, int32_t *cdf)
+{
+    const uint64_t one = 1ull << precision;
+    cdf[0] = 0;
+    uint32_t total = 0;
+    for (int i = 0; i < n; ++i) {
+        cdf[i + 1] = static_cast<int32_t>(std::round(pmf[i] * static_cast<float>(1 << precision)));
+        total += static_cast<uint32_t>(cdf[i + 1]);
+    }
+    if (total == 0) return BASIC_ERR_INVALID;
+    int32_t run = 0;
+    for (int i = 1; i <= n; ++i) {
+        run += static_cast<int32_t>((one * static_cast<uint64_t>(static_cast<int64_t>(cdf[i]))) / total);
+        cdf[i] = run;
+    }
+    cdf[n] = static_cast<int32_t>(one);
+    for (int i = 0; i < n; ++i) {
+        if (cdf[i] != cdf[i + 1]) continue;
+        uint32_t narrowest = ~0u;
+        int donor = -1;
+        for (int j = 0; j < n; ++j) {
+            const uint32_t width = static_cast<uint32_t>(cdf[j + 1] - cdf[j]);
+            if (width > 1 && width < narrowest) { narrowest = width; donor = j; }
+        }
+        if (donor < 0) return BASIC_ERR_INVALID;
+        if (donor < i) for (int j = donor + 1; j <= i; ++j) cdf[j] -= 1;
+        else           for (int j = i + 1; j <= donor; ++j) cdf[j] += 1;
+    }
+    return BASIC_OK;
+}
+
+int upload_tables(basic_rans_tables *t)
+{
+    int rc = require_device();
+    if (rc) return rc;
+    BASIC_HIP_TRY(hipMalloc(&t->d_cdfs, t->cdfs.size() * sizeof(int32_t)));
+    BASIC_HIP_TRY(hipMalloc(&t->d_sizes, t->sizes.size() * sizeof(int32_t)));
+    BASIC_HIP_TRY(hipMalloc(&t->d_offsets, t->offsets.size() * sizeof(int32_t)));
+    BASIC_HIP_TRY(hipMemcpy(t->d_cdfs, t->cdfs.data(), t->cdfs.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    BASIC_HIP_TRY(hipMemcpy(t->d_sizes, t->sizes.data(), t->sizes.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    BASIC_HIP_TRY(hipMemcpy(t->d_offsets, t->offsets.data(), t->offsets.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    return BASIC_OK;
+}
+
+bool params_ok(int precision, int bypass_precision)
+{
+    return precision >= 1 && precision <= 16 && bypass_precision >= 1 && bypass_precision <= 16;
+}
+
+}  // namespace
+
+extern "C" int basic_pmf_to_quantized_cdf(const float *pmf, int n, int precision, int32_t *cdf_out)
+{
+    BASIC_REQUIRE(pmf && cdf_out && n >= 1 && precision >= 1 && precision <= 30, "pmf_to_quantized_cdf: bad argument");
+    int rc = quantize_pmf(pmf, n, precision, cdf_out);
+    if (rc) set_error("pmf_to_quantized_cdf: degenerate pmf");
+    return rc;
+}
+
+extern "C" int basic_rans_tables_from_freqs(const int32_t *freqs, int rows, int freq_stride, const int32_t *nsym,
+                                            const int32_t *offsets, int freq_precision, int bypass_coding,
+                                            int bypass_precision, basic_rans_tables **out)
+{
+    BASIC_REQUIRE(freqs && nsym && offsets && out && rows >= 1, "init_params: null/empty argument");
+    BASIC_REQUIRE(params_ok(freq_precision, bypass_precision), "init_params: precision out of range");
+    int max_n = 0;
+    for (int r = 0; r < rows; ++r) {
+        BASIC_REQUIRE(nsym[r] >= 1 && nsym[r] <= freq_stride,
+                      "freqs should be 2-dimensional with shape (num_symbols.size(), >num_symbols.max())");
+        max_n = std::max(max_n, nsym[r]);
+    }
+    auto *t = new (std::nothrow) basic_rans_tables();
+    if (!t) { set_error("out of host memory"); return BASIC_ERR_INVALID; }
+    t->rows = rows;
+    t->stride = max_n + 2;
+    t->precision = freq_precision;
+    t->bypass = bypass_coding ? 1 : 0;
+    t->bypass_precision = bypass_precision;
+    t->cdfs.assign(static_cast<size_t>(rows) * t->stride, 0);
+    t->sizes.resize(rows);
+    t->offsets.assign(offsets, offsets + rows);
+    std::vector<float> pmf(max_n + 1);
+    for (int r = 0; r < rows; ++r) {
+        // rans64.cpp:141-151: float accumulation of the counts, tail mass 1 appended.
+        const int n = nsym[r];
+        const int32_t *f = freqs + static_cast<size_t>(r) * freq_stride;
+        float tot = 0.0f;
+        for (int i = 0; i < n; ++i) tot += static_cast<float>(f[i]);
+        tot += 1.0f;
+        for (int i = 0; i < n; ++i) pmf[i] = static_cast<float>(f[i]) / tot;
+        pmf[n] = 1.0f / tot;
+        if (quantize_pmf(pmf.data(), n + 1, freq_precision, &t->cdfs[static_cast<size_t>(r) * t->stride])) {
+            delete t;
+            set_error("init_params: degenerate frequency row");
+            return BASIC_ERR_INVALID;
+        }
+        t->sizes[r] = n + 2;
+    }
+    int rc = upload_tables(t);
+    if (rc) { basic_rans_tables_destroy(t); return rc; }
+    *out = t;
+    return BASIC_OK;
+}
+
+extern "C" int basic_rans_tables_from_cdfs(const int32_t *cdfs, int rows, int cdf_stride, const int32_t *cdf_sizes,
+                                           const int32_t *offsets, int freq_precision, int bypass_coding,
+                                           int bypass_precision, basic_rans_tables **out)
+{
+    BASIC_REQUIRE(cdfs && cdf_sizes && offsets && out && rows >= 1, "init_cdf_params: null/empty argument");
+    BASIC_REQUIRE(params_ok(freq_precision, bypass_precision), "init_cdf_params: precision out of range");
+    int max_len = 0;
+    for (int r = 0; r < rows; ++r) {
+        BASIC_REQUIRE(cdf_sizes[r] >= 2 && cdf_sizes[r] <= cdf_stride,
+                      "cdfs should be 2-dimensional with shape (cdfs_sizes.size(), >cdfs_sizes.max())");
+        max_len = std::max(max_len, cdf_sizes[r]);
+    }
+    auto *t = new (std::nothrow) basic_rans_tables();
+    if (!t) { set_error("out of host memory"); return BASIC_ERR_INVALID; }
+    t->rows = rows;
+    t->stride = max_len;
+    t->precision = freq_precision;
+    t->bypass = bypass_coding ? 1 : 0;
+    t->bypass_precision = bypass_precision;
+    t->cdfs.assign(static_cast<size_t>(rows) * t->stride, 0);
+    for (int r = 0; r < rows; ++r)
+        std::memcpy(&t->cdfs[static_cast<size_t>(r) * t->stride], cdfs + static_cast<size_t>(r) * cdf_stride,
+                    sizeof(int32_t) * cdf_sizes[r]);
+    t->sizes.assign(cdf_sizes, cdf_sizes + rows);
+    t->offsets.assign(offsets, offsets + rows);
+    int rc = upload_tables(t);
+    if (rc) { basic_rans_tables_destroy(t); return rc; }
+    *out = t;
+    return BASIC_OK;
+}
+
+extern "C" int basic_rans_tables_set_ar(basic_rans_tables *t, const int32_t *ar_tab, int k, int rows, int order, int s1)
+{
+    BASIC_REQUIRE(t && ar_tab && k >= 1 && rows >= 1 && s1 >= 1, "init_ar_params: null/empty argument");
+    BASIC_REQUIRE(order == 1 || order == 2, "Too many dimensions!");
+    size_t n = static_cast<size_t>(k) * rows * s1 * (order == 2 ? s1 : 1);
+    t->ar.assign(ar_tab, ar_tab + n);
+    t->ar_k = k; t->ar_rows = rows; t->ar_order = order; t->ar_s1 = s1;
+    if (t->d_ar) { (void)hipFree(t->d_ar); t->d_ar = nullptr; }
+    BASIC_HIP_TRY(hipMalloc(&t->d_ar, n * sizeof(int32_t)));
+    BASIC_HIP_TRY(hipMemcpy(t->d_ar, t->ar.data(), n * sizeof(int32_t), hipMemcpyHostToDevice));
+    return BASIC_OK;
+}
+
+extern "C" int basic_rans_tables_info(const basic_rans_tables *t, int *rows, int *max_cdf_len)
+{
+    BASIC_REQUIRE(t, "ANS not initialized!");
+    if (rows) *rows = t->rows;
+    if (max_cdf_len) *max_cdf_len = *std::max_element(t->sizes.begin(), t->sizes.end());
+    return BASIC_OK;
+}
+
+extern "C" int basic_rans_tables_get_cdfs(const basic_rans_tables *t, int32_t *out, int out_stride)
+{
+    BASIC_REQUIRE(t && out, "ANS not initialized!");
+    for (int r = 0; r < t->rows; ++r) {
+        BASIC_REQUIRE(t->sizes[r] <= out_stride, "get_cdfs: output stride too small");
+        int32_t *dst = out + static_cast<size_t>(r) * out_stride;
+        std::memset(dst, 0, sizeof(int32_t) * out_stride);
+        std::memcpy(dst, &t->cdfs[static_cast<size_t>(r) * t->stride], sizeof(int32_t) * t->sizes[r]);
+    }
+    return BASIC_OK;
+}
+
+extern "C" void basic_rans_tables_destroy(basic_rans_tables *t)
+{
+    if (!t) return;
+    if (t->d_cdfs) (void)hipFree(t->d_cdfs);
+    if (t->d_sizes) (void)hipFree(t->d_sizes);
+    if (t->d_offsets) (void)hipFree(t->d_offsets);
+    if (t->d_ar) (void)hipFree(t->d_ar);
+    delete t;
+}
+
+// ---------------------------------------------------------------------------------------
+// Device side
+// ---------------------------------------------------------------------------------------
+namespace {
+
+constexpr uint64_t kRansL = 1ull << 31;
+
+struct TablesDev {
+    const int32_t *cdfs, *sizes, *offsets;
+    int rows, stride, precision, bypass, bypass_precision;
+};
+
+struct ArDev {
+    const int32_t *tab;  // nullptr = no AR remap
+    int k, order, rows, s1;
+    const int32_t *ar_indexes, *off0, *off1;  // per stream-element arrays (global element ids)
+};
+
+
+__device__ __forceinline__ int32_t clampi(int32_t v, int32_t lo, int32_t hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// AR remap of the table row (ans_interface.hpp:89-104); every index is clamped so that a
+// malformed input can never read outside the tables.
+__device__ __forceinline__ int32_t ar_row(const ArDev &ar, int32_t a, int32_t row, int32_t v0, int32_t v1)
+{
+    a = clampi(a, 0, ar.k - 1);
+    row = clampi(row, 0, ar.rows - 1);
+    v0 = clampi(v0, 0, ar.s1 - 1);
+    if (ar.order == 1) return ar.tab[(static_cast<int64_t>(a) * ar.rows + row) * ar.s1 + v0];
+    v1 = clampi(v1, 0, ar.s1 - 1);
+    return ar.tab[((static_cast<int64_t>(a) * ar.rows + row) * ar.s1 + v0) * ar.s1 + v1];
+}
+
+__device__ __forceinline__ uint32_t bcast_u32(uint32_t v, int lane)
+{
+    return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), lane));
+}
+__device__ __forceinline__ uint64_t bcast_u64(uint64_t v, int lane)
+{
+    return static_cast<uint64_t>(bcast_u32(static_cast<uint32_t>(v), lane)) |
+           (static_cast<uint64_t>(bcast_u32(static_cast<uint32_t>(v >> 32), lane)) << 32);
+}
+__device__ __forceinline__ uint64_t uniform_u64(uint64_t v)
+{
+    uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v));
+    uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v >> 32));
+    return static_cast<uint64_t>(lo) | (static_cast<uint64_t>(hi) << 32);
+}
+
+// ceil(2^(63+shift) / f) for f >= 2 with shift = ceil(log2 f): the 64-bit reciprocal that makes
+// q = mulhi(x, rcp) >> (shift-1) == floor(x / f) for every x < 2^63 (Alverson 1991).  Built from
+// two 64-by-32 divisions, per lane, in the parallel phase.
+__device__ __forceinline__ void exact_reciprocal(uint32_t f, uint64_t &rcp, uint32_t &post_shift)
+{
+    const uint32_t shift = 32u - static_cast<uint32_t>(__clz(static_cast<int>(f - 1u)));
+    const uint64_t hi_num = 1ull << (shift + 31u);  // top 64 bits of 2^(63+shift) split as hi:lo words
+    const uint64_t q_hi = hi_num / f;
+    const uint64_t lo_num = ((hi_num % f) << 32) + (f - 1u);
+    const uint64_t q_lo = lo_num / f;
+    rcp = (q_hi << 32) + q_lo;
+    post_shift = shift - 1u;
+}
+
+struct Emitter {
+    uint32_t *p;   // next free word is p[-1]; wave-uniform
+    uint32_t *lo;  // slot start
+    bool overflow;
+    __device__ __forceinline__ void push(uint32_t w, int lane)
+    {
+        if (p == lo) { overflow = true; return; }
+        --p;
+        if (lane == 0) *p = w;
+    }
+};
+
+// x = C(s, x) with renormalisation (rans64.h:65-84).  All operands are wave-uniform.
+__device__ __forceinline__ void put_symbol(uint64_t &x, Emitter &em, int lane, uint32_t start, uint32_t freq,
+                                           uint64_t rcp, uint32_t post_shift, uint32_t precision)
+{
+    const uint64_t x_max = static_cast<uint64_t>(freq) << (63u - precision);  // ((L>>prec)<<32)*freq
+    if (x >= x_max) { em.push(static_cast<uint32_t>(x), lane); x >>= 32; }
+    uint64_t q;
+    if (freq == 1u) q = x;
+    else q = __umul64hi(x, rcp) >> post_shift;
+    x = x + start + q * ((1u << precision) - freq);  // (q << prec) + (x - q*freq) + start
+}
+
+__device__ __forceinline__ void put_raw(uint64_t &x, Emitter &em, int lane, uint32_t val, uint32_t nbits)
+{ /* rans64.cpp:29-47 */
+    const uint64_t x_max = 1ull << (63u - nbits);  // ((L>>16)<<32) << (16-nbits)
+    if (x >= x_max) { em.push(static_cast<uint32_t>(x), lane); x >>= 32; }
+    x = (x << nbits) | val;
+}
+
+// One wavefront per stream.  Symbols are consumed last-to-first in chunks of 64: the lanes
+// prepare (start, freq, reciprocal, raw bypass payload) for their own symbol, then the chunk is
+// folded into the state serially on broadcast (scalar) values.
+__global__ __launch_bounds__(64) void rans_encode_kernel(TablesDev T, ArDev ar, const int32_t *__restrict__ symbols,
+                                                         const int32_t *__restrict__ indexes,
+                                                         const int64_t *__restrict__ seg, uint32_t *out_words,
+                                                         int64_t slot_words, int32_t *out_nwords)
+{
+    const int stream = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int64_t beg = seg[stream];
+    const int64_t n = seg[stream + 1] - beg;
+    const int32_t *sym = symbols + beg;
+    const int32_t *idx = indexes + beg;
+    uint32_t *slot = out_words + static_cast<int64_t>(stream) * slot_words;
+    Emitter em{slot + slot_words, slot, false};
+    uint64_t x = kRansL;
+    const uint32_t prec = static_cast<uint32_t>(T.precision);
+    const uint32_t bprec = static_cast<uint32_t>(T.bypass_precision);
+    const uint32_t maxbv = (1u << bprec) - 1u;
+
+    for (int64_t hi = n; hi > 0; hi -= 64) {
+        const int64_t i = hi - 64 + lane;  // lane 63 holds the chunk's last symbol
+        uint32_t start = 0, freq = 1, raw = 0, post_shift = 0;
+        uint64_t rcp = 0;
+        bool is_bypass = false;
+        if (i >= 0) {
+            int32_t row = idx[i];
+            if (ar.tab) {
+                const int64_t g = beg + i;
+                const int32_t a = ar.ar_indexes ? ar.ar_indexes[g] : 0;
+                const int32_t d0 = ar.off0[g];
+                const int32_t v0 = (d0 > 0 && d0 <= i) ? sym[i - d0] + 1 : 0;
+                int32_t v1 = 0;
+                if (ar.order == 2) {
+                    const int32_t d1 = ar.off1[g];
+                    v1 = (d1 > 0 && d1 <= i) ? sym[i - d1] + 1 : 0;
+                }
+                row = ar_row(ar, a, row, v0, v1);
+            }
+            row = clampi(row, 0, T.rows - 1);
+            const int32_t *cdf = T.cdfs + static_cast<int64_t>(row) * T.stride;
+            const int32_t max_value = T.sizes[row] - 2;
+            int32_t value = sym[i] - T.offsets[row];
+            if (T.bypass) {
+                if (value < 0) { raw = static_cast<uint32_t>(-2 * value - 1); value = max_value; }
+                else if (value >= max_value) { raw = static_cast<uint32_t>(2 * (value - max_value)); value = max_value; }
+                is_bypass = (value == max_value);
+            }
+            value = clampi(value, 0, max_value);  // without bypass the reference is UB out of range
+            const int32_t c0 = cdf[value], c1 = cdf[value + 1];
+            start = static_cast<uint32_t>(c0) & 0xFFFFu;          // uint16_t casts, rans64.cpp:289-291
+            freq = static_cast<uint32_t>(c1 - c0) & 0xFFFFu;
+            if (freq >= 2u) exact_reciprocal(freq, rcp, post_shift);
+        }
+        const uint64_t bypass_mask = __ballot(is_bypass);
+        const int j_lo = hi >= 64 ? 0 : static_cast<int>(64 - hi);
+        for (int j = 63; j >= j_lo; --j) {
+            if ((bypass_mask >> j) & 1ull) {
+                // decode order: sentinel, count nibbles, payload low-first  =>  written reversed
+                const uint32_t r = bcast_u32(raw, j);
+                int nb = 0;
+                while (nb * bprec < 32u && (r >> (nb * bprec)) != 0u) ++nb;
+                for (int k = nb - 1; k >= 0; --k) put_raw(x, em, lane, (r >> (k * bprec)) & maxbv, bprec);
+                put_raw(x, em, lane, static_cast<uint32_t>(nb) % maxbv, bprec);
+                for (uint32_t k = 0; k < static_cast<uint32_t>(nb) / maxbv; ++k) put_raw(x, em, lane, maxbv, bprec);
+            }
+            put_symbol(x, em, lane, bcast_u32(start, j), bcast_u32(freq, j), bcast_u64(rcp, j),
+                       bcast_u32(post_shift, j), prec);
+        }
+    }
+    em.push(static_cast<uint32_t>(x >> 32), lane);  // flush, rans64.h:87-94
+    em.push(static_cast<uint32_t>(x), lane);
+    if (lane == 0) out_nwords[stream] = em.overflow ? -1 : static_cast<int32_t>((slot + slot_words) - em.p);
+}
+
+// Word reader: 64 words are kept in a VGPR (lane k = word base+k) and handed out by broadcast.
+struct WordReader {
+    const uint32_t *words;
+    int64_t limit;  // words in this stream; reads past it return 0 (truncated stream != fault)
+    int64_t pos;    // next word (uniform)
+    int64_t base;   // first word cached
+    uint32_t cache;
+    __device__ __forceinline__ void fill(int lane)
+    {
+        base = pos & ~63ll;
+        cache = (base + lane < limit) ? words[base + lane] : 0u;
+    }
+    __device__ __forceinline__ uint32_t next(int lane)
+    {
+        if (pos - base >= 64) fill(lane);
+        const uint32_t w = bcast_u32(cache, static_cast<int>(pos - base));
+        ++pos;
+        return w;
+    }
+};
+
+__device__ __forceinline__ uint32_t get_raw(uint64_t &x, WordReader &rd, int lane, uint32_t nbits)
+{ /* rans64.cpp:49-65 */
+    const uint32_t v = static_cast<uint32_t>(x) & ((1u << nbits) - 1u);
+    x >>= nbits;
+    if (x < kRansL) x = (x << 32) | rd.next(lane);
+    return v;
+}
+
+// One wavefront per stream; the CDF search of each symbol is a 64-ary search over the row
+// (one probe per lane, one ballot per level), everything else is scalar.
+template <bool AR>
+__global__ __launch_bounds__(64) void rans_decode_kernel(TablesDev T, ArDev ar, const uint32_t *__restrict__ words_all,
+                                                         const int64_t *__restrict__ word_off,
+                                                         const int32_t *__restrict__ indexes,
+                                                         const int64_t *__restrict__ seg, int32_t *out_symbols,
+                                                         uint64_t *state, int64_t *pos_io)
+{
+    const int stream = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int64_t beg = seg[stream];
+    const int64_t n = seg[stream + 1] - beg;
+    const int32_t *idx = indexes + beg;
+    int32_t *out = out_symbols + beg;
+
+    WordReader rd;
+    rd.words = words_all + word_off[stream];
+    rd.limit = word_off[stream + 1] - word_off[stream];
+    uint64_t x;
+    int64_t p0 = pos_io[stream];
+    if (p0 < 0) {
+        rd.pos = 0;
+        rd.fill(lane);
+        const uint32_t w0 = rd.next(lane), w1 = rd.next(lane);
+        x = static_cast<uint64_t>(w0) | (static_cast<uint64_t>(w1) << 32);
+    } else {
+        rd.pos = p0;
+        rd.fill(lane);
+        x = state[stream];
+    }
+    x = uniform_u64(x);
+    const uint32_t prec = static_cast<uint32_t>(T.precision);
+    const uint32_t mask = (1u << prec) - 1u;
+    const uint32_t bprec = static_cast<uint32_t>(T.bypass_precision);
+    const uint32_t maxbv = (1u << bprec) - 1u;
+
+    for (int64_t c0 = 0; c0 < n; c0 += 64) {
+        const int64_t i = c0 + lane;
+        int32_t row_l = 0, size_l = 2, off_l = 0;
+        if (i < n) {
+            row_l = AR ? idx[i] : clampi(idx[i], 0, T.rows - 1);
+            if (!AR) { size_l = T.sizes[row_l]; off_l = T.offsets[row_l]; }
+        }
+        int32_t result = 0;
+        const int cnt = (n - c0) < 64 ? static_cast<int>(n - c0) : 64;
+        for (int j = 0; j < cnt; ++j) {
+            int32_t row = static_cast<int32_t>(bcast_u32(static_cast<uint32_t>(row_l), j));
+            int32_t size, offset;
+            if (AR) {
+                // remap from already-decoded symbols (ans_interface.hpp:89-104); lane-uniform loads
+                const int64_t e = c0 + j, g = beg + e;
+                const int32_t a = ar.ar_indexes ? ar.ar_indexes[g] : 0;
+                const int32_t d0 = ar.off0[g];
+                const int32_t v0 = (d0 > 0 && d0 <= e) ? __hip_atomic_load(out + (e - d0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 : 0;
+                int32_t v1 = 0;
+                if (ar.order == 2) {
+                    const int32_t d1 = ar.off1[g];
+                    v1 = (d1 > 0 && d1 <= e) ? __hip_atomic_load(out + (e - d1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 : 0;
+                }
+                row = ar_row(ar, a, row, v0, v1);
+                row = __builtin_amdgcn_readfirstlane(clampi(row, 0, T.rows - 1));
+                size = T.sizes[row];
+                offset = T.offsets[row];
+                size = __builtin_amdgcn_readfirstlane(size);
+                offset = __builtin_amdgcn_readfirstlane(offset);
+            } else {
+                size = static_cast<int32_t>(bcast_u32(static_cast<uint32_t>(size_l), j));
+                offset = static_cast<int32_t>(bcast_u32(static_cast<uint32_t>(off_l), j));
+            }
+            const int32_t *cdf = T.cdfs + static_cast<int64_t>(row) * T.stride;
+            const uint32_t cf = static_cast<uint32_t>(x) & mask;
+
+            // find t = first entry with cdf[t] > cf (t >= 1 because cdf[0] = 0); s = t - 1.
+            int32_t lo = 0;           // window start (uniform)
+            int32_t span = size;      // entries still in play, starting at lo
+            while (span > 64) {       // coarse level(s): probe the last entry of each of 64 blocks
+                const int32_t step = (span + 63) >> 6;
+                int32_t pi = lo + (lane + 1) * step - 1;
+                const bool in = pi < lo + span;
+                if (!in) pi = lo + span - 1;
+                const int32_t v = cdf[pi];
+                const uint64_t m = __ballot(static_cast<uint32_t>(v) > cf);
+                const int blk = __builtin_ctzll(m);  // m != 0: the final entry 2^prec > cf
+                const int32_t nlo = lo + blk * step;
+                const int32_t nspan = (nlo + step <= lo + span) ? step : (lo + span - nlo);
+                lo = nlo;
+                span = nspan;
+            }
+            // fine level: lanes cover entries lo-1 .. lo+span-1 (span+1 <= 65 -> lane 0 is entry lo-1
+            // only when lo > 0; entry lo+span-1 by lane span).  Use two registers to stay within 64.
+            const int32_t e0 = lo + lane;  // entry index for register A
+            int32_t va = (lane < span) ? cdf[e0] : 0x7FFFFFFF;
+            const uint64_t m = __ballot(static_cast<uint32_t>(va) > cf && lane < span);
+            const int tl = __builtin_ctzll(m);  // lane of t
+            const uint32_t c_t = bcast_u32(static_cast<uint32_t>(va), tl);
+            uint32_t c_s;
+            if (tl > 0) c_s = bcast_u32(static_cast<uint32_t>(va), tl - 1);
+            else c_s = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(cdf[lo - 1]));
+            const int32_t s = lo + tl - 1;
+            const uint32_t freq = c_t - c_s;
+
+            x = static_cast<uint64_t>(freq) * (x >> prec) + (static_cast<uint32_t>(x) & mask) - c_s;  // rans64.h:128-142
+            if (x < kRansL) x = (x << 32) | rd.next(lane);
+
+            int32_t value = s;
+            if (T.bypass && value == size - 2) {
+                uint32_t v = get_raw(x, rd, lane, bprec);
+                uint32_t nb = v;
+                while (v == maxbv) { v = get_raw(x, rd, lane, bprec); nb += v; }
+                uint32_t raw = 0;
+                for (uint32_t k = 0; k < nb; ++k) {
+                    const uint32_t nib = get_raw(x, rd, lane, bprec);
+                    if (k * bprec < 32u) raw |= nib << (k * bprec);
+                }
+                value = static_cast<int32_t>(raw >> 1);
+                if (raw & 1u) value = -value - 1; else value += size - 2;
+            }
+            value += offset;
+            if (AR) {
+                if (lane == 0) __hip_atomic_store(out + (c0 + j), value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                result = (lane == j) ? value : result;
+            }
+        }
+        if (!AR && i < n) out[i] = result;
+    }
+    if (lane == 0) { state[stream] = x; pos_io[stream] = rd.pos; }
+}
+
+TablesDev dev_view(const basic_rans_tables *t)
+{
+    return TablesDev{t->d_cdfs, t->d_sizes, t->d_offsets, t->rows, t->stride, t->precision, t->bypass, t->bypass_precision};
+}
+
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 4); }
+    template <typename T> T *as() { return static_cast<T *>(p); }
+};
+
+}  // namespace
+
+extern "C" int64_t basic_rans_encode_bound(int64_t n)
+{
+    // worst case per symbol: one 16-bit symbol + <= 13 raw groups of bypass_precision bits, well under
+    // 3 words; plus 2 flush words.
+    return (3 * n + 4) * 4;
+}
+
+extern "C" int basic_rans_encode_batch_dev(const basic_rans_tables *t, const int32_t *d_symbols,
+                                           const int32_t *d_indexes, const int64_t *d_seg, int nstreams,
+                                           uint32_t *d_out_words, int64_t slot_words, int32_t *d_out_nwords,
+                                           void *hip_stream)
+{
+    if (!t) { set_error("ANS not initialized!"); return BASIC_ERR_NOT_INIT; }
+    BASIC_REQUIRE(d_symbols && d_indexes && d_seg && d_out_words && d_out_nwords && nstreams >= 1 && slot_words >= 2,
+                  "rans_encode_batch: bad argument");
+    BASIC_REQUIRE(!t->d_ar, "rans_encode_batch: AR tables are only supported by the host-buffer entry points");
+    ArDev ar{};
+    hipLaunchKernelGGL(rans_encode_kernel, dim3(nstreams), dim3(64), 0, as_stream(hip_stream), dev_view(t), ar,
+                       d_symbols, d_indexes, d_seg, d_out_words, slot_words, d_out_nwords);
+    BASIC_HIP_TRY(hipGetLastError());
+    return BASIC_OK;
+}
+
+extern "C" int basic_rans_decode_batch_dev(const basic_rans_tables *t, const uint32_t *d_words,
+                                           const int64_t *d_word_off, const int32_t *d_indexes, const int64_t *d_seg,
+                                           int nstreams, int32_t *d_out_symbols, uint64_t *d_state, int64_t *d_pos,
+                                           void *hip_stream)
+{
+    if (!t) { set_error("ANS not initialized!"); return BASIC_ERR_NOT_INIT; }
+    BASIC_REQUIRE(d_words && d_word_off && d_indexes && d_seg && d_out_symbols && d_state && d_pos && nstreams >= 1,
+                  "rans_decode_batch: bad argument");
+    BASIC_REQUIRE(!t->d_ar, "rans_decode_batch: AR tables are only supported by the host-buffer entry points");
+    ArDev ar{};
+    hipLaunchKernelGGL(rans_decode_kernel<false>, dim3(nstreams), dim3(64), 0, as_stream(hip_stream), dev_view(t), ar,
+                       d_words, d_word_off, d_indexes, d_seg, d_out_symbols, d_state, d_pos);
+    BASIC_HIP_TRY(hipGetLastError());
+    return BASIC_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// Host-buffer drop-ins (single stream): stage -> kernel -> copy back.
+// ---------------------------------------------------------------------------------------
+namespace {
+
+int stage_ar(const basic_rans_tables *t, int64_t n, const int32_t *ar_indexes, const int32_t *ar_off0,
+             const int32_t *ar_off1, DevBuf &b_ai, DevBuf &b_o0, DevBuf &b_o1, ArDev &ar)
+{
+    ar = ArDev{};
+    if (!t->d_ar) return BASIC_OK;
+    if (!ar_off0 || (t->ar_order == 2 && !ar_off1)) {
+        set_error("ar_offsets is required for ar coding!");
+        return BASIC_ERR_INVALID;
+    }
+    const size_t bytes = static_cast<size_t>(n) * sizeof(int32_t);
+    ar.tab = t->d_ar; ar.k = t->ar_k; ar.order = t->ar_order; ar.rows = t->ar_rows; ar.s1 = t->ar_s1;
+    if (ar_indexes) {
+        BASIC_HIP_TRY(b_ai.alloc(bytes));
+        BASIC_HIP_TRY(hipMemcpy(b_ai.p, ar_indexes, bytes, hipMemcpyHostToDevice));
+        ar.ar_indexes = b_ai.as<int32_t>();
+    }
+    BASIC_HIP_TRY(b_o0.alloc(bytes));
+    BASIC_HIP_TRY(hipMemcpy(b_o0.p, ar_off0, bytes, hipMemcpyHostToDevice));
+    ar.off0 = b_o0.as<int32_t>();
+    if (t->ar_order == 2) {
+        BASIC_HIP_TRY(b_o1.alloc(bytes));
+        BASIC_HIP_TRY(hipMemcpy(b_o1.p, ar_off1, bytes, hipMemcpyHostToDevice));
+        ar.off1 = b_o1.as<int32_t>();
+    }
+    return BASIC_OK;
+}
+
+}  // namespace
+
+extern "C" int basic_rans_encode_host(const basic_rans_tables *t, const int32_t *symbols, const int32_t *indexes,
+                                      int64_t n, const int32_t *ar_indexes, const int32_t *ar_off0,
+                                      const int32_t *ar_off1, uint8_t *out, int64_t out_capacity, int64_t *out_len)
+{
+    if (!t) { set_error("ANS not initialized!"); return BASIC_ERR_NOT_INIT; }
+    BASIC_REQUIRE(n >= 0 && out && out_len && (n == 0 || (symbols && indexes)), "encode_with_indexes: bad argument");
+    const int64_t slot_words = basic_rans_encode_bound(n) / 4;
+    DevBuf b_sym, b_idx, b_seg, b_out, b_nw, b_ai, b_o0, b_o1;
+    const size_t bytes = static_cast<size_t>(n) * sizeof(int32_t);
+    BASIC_HIP_TRY(b_sym.alloc(bytes));
+    BASIC_HIP_TRY(b_idx.alloc(bytes));
+    BASIC_HIP_TRY(b_seg.alloc(2 * sizeof(int64_t)));
+    BASIC_HIP_TRY(b_out.alloc(static_cast<size_t>(slot_words) * 4));
+    BASIC_HIP_TRY(b_nw.alloc(sizeof(int32_t)));
+    if (n) {
+        BASIC_HIP_TRY(hipMemcpy(b_sym.p, symbols, bytes, hipMemcpyHostToDevice));
+        BASIC_HIP_TRY(hipMemcpy(b_idx.p, indexes, bytes, hipMemcpyHostToDevice));
+    }
+    const int64_t seg[2] = {0, n};
+    BASIC_HIP_TRY(hipMemcpy(b_seg.p, seg, sizeof(seg), hipMemcpyHostToDevice));
+    ArDev ar;
+    int rc = stage_ar(t, n, ar_indexes, ar_off0, ar_off1, b_ai, b_o0, b_o1, ar);
+    if (rc) return rc;
+    hipLaunchKernelGGL(rans_encode_kernel, dim3(1), dim3(64), 0, nullptr, dev_view(t), ar, b_sym.as<int32_t>(),
+                       b_idx.as<int32_t>(), b_seg.as<int64_t>(), b_out.as<uint32_t>(), slot_words, b_nw.as<int32_t>());
+    BASIC_HIP_TRY(hipGetLastError());
+    int32_t nwords = 0;
+    BASIC_HIP_TRY(hipMemcpy(&nwords, b_nw.p, sizeof(nwords), hipMemcpyDeviceToHost));
+    if (nwords < 0) { set_error("rans encoder: slot overflow"); return BASIC_ERR_OVERFLOW; }
+    const int64_t nbytes = static_cast<int64_t>(nwords) * 4;
+    *out_len = nbytes;
+    if (nbytes > out_capacity) { set_error("encode_with_indexes: output buffer too small"); return BASIC_ERR_OVERFLOW; }
+    BASIC_HIP_TRY(hipMemcpy(out, b_out.as<uint32_t>() + (slot_words - nwords), nbytes, hipMemcpyDeviceToHost));
+    return BASIC_OK;
+}
+
+struct basic_rans_stream {
+    const basic_rans_tables *t = nullptr;
+    DevBuf words, state, pos, woff;
+    int64_t nwords = 0;
+};
+
+extern "C" int basic_rans_stream_open(const basic_rans_tables *t, const uint8_t *stream, int64_t stream_len,
+                                      basic_rans_stream **out)
+{
+    if (!t) { set_error("ANS not initialized!"); return BASIC_ERR_NOT_INIT; }
+    BASIC_REQUIRE(stream && out && stream_len >= 8 && (stream_len % 4) == 0, "set_stream: stream must hold >= 2 whole 32-bit words");
+    auto *s = new (std::nothrow) basic_rans_stream();
+    if (!s) { set_error("out of host memory"); return BASIC_ERR_INVALID; }
+    s->t = t;
+    s->nwords = stream_len / 4;
+    hipError_t e = s->words.alloc(static_cast<size_t>(stream_len));
+    if (e == hipSuccess) e = hipMemcpy(s->words.p, stream, stream_len, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = s->state.alloc(8);
+    if (e == hipSuccess) e = s->pos.alloc(8);
+    if (e == hipSuccess) e = s->woff.alloc(16);
+    const int64_t minus1 = -1;
+    const int64_t woff[2] = {0, s->nwords};
+    if (e == hipSuccess) e = hipMemcpy(s->pos.p, &minus1, 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(s->woff.p, woff, 16, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { delete s; return hip_fail(e, "rans_stream_open", __FILE__, __LINE__); }
+    *out = s;
+    return BASIC_OK;
+}
+
+namespace {
+int stream_decode(basic_rans_stream *s, const int32_t *indexes, int64_t n, const int32_t *ar_indexes,
+                  const int32_t *ar_off0, const int32_t *ar_off1, int32_t *out_symbols)
+{
+    BASIC_REQUIRE(s && n >= 0 && (n == 0 || (indexes && out_symbols)), "decode: bad argument");
+    if (n == 0) return BASIC_OK;
+    const basic_rans_tables *t = s->t;
+    DevBuf b_idx, b_seg, b_out, b_ai, b_o0, b_o1;
+    const size_t bytes = static_cast<size_t>(n) * sizeof(int32_t);
+    BASIC_HIP_TRY(b_idx.alloc(bytes));
+    BASIC_HIP_TRY(b_out.alloc(bytes));
+    BASIC_HIP_TRY(b_seg.alloc(2 * sizeof(int64_t)));
+    BASIC_HIP_TRY(hipMemcpy(b_idx.p, indexes, bytes, hipMemcpyHostToDevice));
+    const int64_t seg[2] = {0, n};
+    BASIC_HIP_TRY(hipMemcpy(b_seg.p, seg, sizeof(seg), hipMemcpyHostToDevice));
+    ArDev ar;
+    int rc = stage_ar(t, n, ar_indexes, ar_off0, ar_off1, b_ai, b_o0, b_o1, ar);
+    if (rc) return rc;
+    if (ar.tab)
+        hipLaunchKernelGGL(rans_decode_kernel<true>, dim3(1), dim3(64), 0, nullptr, dev_view(t), ar,
+                           s->words.as<uint32_t>(), s->woff.as<int64_t>(), b_idx.as<int32_t>(), b_seg.as<int64_t>(),
+                           b_out.as<int32_t>(), s->state.as<uint64_t>(), s->pos.as<int64_t>());
+    else
+        hipLaunchKernelGGL(rans_decode_kernel<false>, dim3(1), dim3(64), 0, nullptr, dev_view(t), ar,
+                           s->words.as<uint32_t>(), s->woff.as<int64_t>(), b_idx.as<int32_t>(), b_seg.as<int64_t>(),
+                           b_out.as<int32_t>(), s->state.as<uint64_t>(), s->pos.as<int64_t>());
+    BASIC_HIP_TRY(hipGetLastError());
+    BASIC_HIP_TRY(hipMemcpy(out_symbols, b_out.p, bytes, hipMemcpyDeviceToHost));
+    return BASIC_OK;
+}
+}  // namespace
+
+extern "C" int basic_rans_stream_decode(basic_rans_stream *s, const int32_t *indexes, int64_t n, int32_t *out_symbols)
+{
+    // decode_stream ignores AR parameters in the reference (rans64.cpp:529,537)
+    if (!s) { set_error("set_stream was not called"); return BASIC_ERR_NOT_INIT; }
+    BASIC_REQUIRE(!s->t->d_ar, "decode_stream does not support AR tables (reference: rans64.cpp:529)");
+    return stream_decode(s, indexes, n, nullptr, nullptr, nullptr, out_symbols);
+}
+
+extern "C" void basic_rans_stream_close(basic_rans_stream *s) { delete s; }
+
+extern "C" int basic_rans_decode_host(const basic_rans_tables *t, const uint8_t *stream, int64_t stream_len,
+                                      const int32_t *indexes, int64_t n, const int32_t *ar_indexes,
+                                      const int32_t *ar_off0, const int32_t *ar_off1, int32_t *out_symbols)
+{
+    basic_rans_stream *s = nullptr;
+    int rc = basic_rans_stream_open(t, stream, stream_len, &s);
+    if (rc) return rc;
+    rc = stream_decode(s, indexes, n, ar_indexes, ar_off0, ar_off1, out_symbols);
+    basic_rans_stream_close(s);
+    return rc;
+}

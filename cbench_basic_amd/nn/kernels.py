@@ -1,0 +1,222 @@
+"""Thin torch-tensor front-ends of the C-ABI compute entry points (include/basic_hip.h).
+
+PyTorch is used here for device memory and streams only; every operation below is a
+hand-written HIP kernel.  All functions require CUDA(HIP) tensors and raise otherwise --
+there is no CPU implementation behind them.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from .. import _lib
+
+ACT_NONE, ACT_RELU, ACT_LEAKY_RELU, ACT_GDN, ACT_IGDN = 0, 1, 2, 3, 4
+
+
+def _dev(t, dtype=None):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise _lib.BasicHipError("cbench_basic_amd kernels need tensors on the MI355X (got a CPU tensor); "
+                                 "there is no CPU fallback")
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f"expected {dtype}, got {t.dtype}")
+    return t.contiguous()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _f32(a):
+    return np.ascontiguousarray(a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else a, dtype=np.float32)
+
+
+class ConvPlan:
+    """Packed weights + fused epilogue of one conv / deconv layer (basic_conv_plan_*)."""
+
+    def __init__(self, weight, bias, stride, padding, output_padding=0, transposed=False, act=ACT_NONE,
+                 gamma=None, beta=None, cin_active=None, cout_active=None):
+        w = _f32(weight)
+        self.transposed = bool(transposed)
+        cin, cout = (w.shape[0], w.shape[1]) if transposed else (w.shape[1], w.shape[0])
+        self.cin = cin if cin_active is None else int(cin_active)
+        self.cout = cout if cout_active is None else int(cout_active)
+        b = _f32(bias) if bias is not None else None
+        g = _f32(gamma) if gamma is not None else None
+        be = _f32(beta) if beta is not None else None
+        if g is not None and g.shape[0] != cout:
+            # effective gamma/beta given for the active slice only: embed in a [cout][cout] frame
+            gf = np.zeros((cout, cout), np.float32); gf[: g.shape[0], : g.shape[1]] = g
+            bf = np.ones((cout,), np.float32); bf[: be.shape[0]] = be
+            g, be = gf, bf
+        h = ctypes.c_void_p()
+        _lib.check(_lib.lib().basic_conv_plan_create(
+            w.ctypes.data, b.ctypes.data if b is not None else None, cin, cout, w.shape[2], int(stride), int(padding),
+            int(output_padding), int(self.transposed), int(act), g.ctypes.data if g is not None else None,
+            be.ctypes.data if be is not None else None, self.cin, self.cout, ctypes.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                _lib.lib().basic_conv_plan_destroy(h)
+            except Exception:
+                pass
+
+    def out_hw(self, h, w):
+        oh, ow = ctypes.c_int(), ctypes.c_int()
+        _lib.check(_lib.lib().basic_conv_plan_out_hw(self._h, int(h), int(w), ctypes.byref(oh), ctypes.byref(ow)))
+        return oh.value, ow.value
+
+    def flops(self, batch, h, w):
+        return int(_lib.lib().basic_conv_plan_flops(self._h, int(batch), int(h), int(w)))
+
+    def __call__(self, x, out=None):
+        x = _dev(x, torch.float32)
+        B, C, H, W = x.shape
+        if C != self.cin:
+            raise ValueError(f"conv plan expects {self.cin} input channels, got {C}")
+        oh, ow = self.out_hw(H, W)
+        if out is None:
+            out = torch.empty((B, self.cout, oh, ow), device=x.device, dtype=torch.float32)
+        _lib.check(_lib.lib().basic_conv_forward_dev(self._h, x.data_ptr(), B, H, W, out.data_ptr(), _stream()))
+        return out
+
+
+class MaskedConvPlan:
+    """basic_mconv_plan_*: topo-group masked conv evaluated at a position list."""
+
+    def __init__(self, weight, bias, in_groups, out_groups, allow_same, act=ACT_NONE):
+        w = _f32(weight)
+        b = _f32(bias) if bias is not None else None
+        self.cout, self.cin, self.k = w.shape[0], w.shape[1], w.shape[2]
+        h = ctypes.c_void_p()
+        _lib.check(_lib.lib().basic_mconv_plan_create(w.ctypes.data, b.ctypes.data if b is not None else None, self.cin,
+                                                      self.cout, self.k, int(in_groups), int(out_groups), int(bool(allow_same)),
+                                                      int(act), ctypes.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                _lib.lib().basic_mconv_plan_destroy(h)
+            except Exception:
+                pass
+
+    def __call__(self, x, topo_in, topo_out, pos, out, out_offset=0):
+        x = _dev(x, torch.float32)
+        B, C, H, W = x.shape
+        topo_in, topo_out, pos = _dev(topo_in, torch.int32), _dev(topo_out, torch.int32), _dev(pos, torch.int32)
+        out = _dev(out, torch.float32)
+        _lib.check(_lib.lib().basic_mconv_forward_pos_dev(self._h, x.data_ptr(), topo_in.data_ptr(), topo_out.data_ptr(), B, H, W,
+                                                          pos.data_ptr(), pos.numel(), out.data_ptr(), out.shape[1], int(out_offset),
+                                                          _stream()))
+        return out
+
+
+class RansTables:
+    """Device-resident CDF tables (basic_rans_tables_*) for the batched stream coder."""
+
+    def __init__(self, freqs=None, nsym=None, offsets=None, cdfs=None, cdf_sizes=None, precision=16, bypass=True,
+                 bypass_precision=4):
+        h = ctypes.c_void_p()
+        off = np.ascontiguousarray(offsets, dtype=np.int32)
+        if cdfs is not None:
+            c = np.ascontiguousarray(cdfs, dtype=np.int32)
+            s = np.ascontiguousarray(cdf_sizes, dtype=np.int32)
+            _lib.check(_lib.lib().basic_rans_tables_from_cdfs(c.ctypes.data, c.shape[0], c.shape[1], s.ctypes.data, off.ctypes.data,
+                                                              precision, int(bypass), bypass_precision, ctypes.byref(h)))
+        else:
+            f = np.ascontiguousarray(freqs, dtype=np.int32)
+            n = np.ascontiguousarray(nsym, dtype=np.int32)
+            _lib.check(_lib.lib().basic_rans_tables_from_freqs(f.ctypes.data, f.shape[0], f.shape[1], n.ctypes.data, off.ctypes.data,
+                                                               precision, int(bypass), bypass_precision, ctypes.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                _lib.lib().basic_rans_tables_destroy(h)
+            except Exception:
+                pass
+
+    def get_cdfs(self):
+        rows, mx = ctypes.c_int(), ctypes.c_int()
+        _lib.check(_lib.lib().basic_rans_tables_info(self._h, ctypes.byref(rows), ctypes.byref(mx)))
+        out = np.zeros((rows.value, mx.value), dtype=np.int32)
+        _lib.check(_lib.lib().basic_rans_tables_get_cdfs(self._h, out.ctypes.data, mx.value))
+        return out
+
+    def encode_batch(self, symbols, indexes, seg, slot_words=None):
+        """symbols/indexes int32 [total]; seg int64 [nstreams+1] -> (words [nstreams, slot], nwords [nstreams])."""
+        symbols, indexes, seg = _dev(symbols, torch.int32), _dev(indexes, torch.int32), _dev(seg, torch.int64)
+        ns = seg.numel() - 1
+        if slot_words is None:
+            raise ValueError("slot_words is required")
+        words = torch.empty((ns, slot_words), device=symbols.device, dtype=torch.int32)
+        nwords = torch.empty((ns,), device=symbols.device, dtype=torch.int32)
+        _lib.check(_lib.lib().basic_rans_encode_batch_dev(self._h, symbols.data_ptr(), indexes.data_ptr(), seg.data_ptr(), ns,
+                                                          words.data_ptr(), slot_words, nwords.data_ptr(), _stream()))
+        return words, nwords
+
+    def decode_batch(self, words, word_off, indexes, seg, out=None, state=None, pos=None):
+        words, word_off = _dev(words, torch.int32), _dev(word_off, torch.int64)
+        indexes, seg = _dev(indexes, torch.int32), _dev(seg, torch.int64)
+        ns = seg.numel() - 1
+        if out is None:
+            out = torch.empty_like(indexes)
+        if state is None:
+            state = torch.zeros((ns,), device=words.device, dtype=torch.int64)
+            pos = torch.full((ns,), -1, device=words.device, dtype=torch.int64)
+        _lib.check(_lib.lib().basic_rans_decode_batch_dev(self._h, words.data_ptr(), word_off.data_ptr(), indexes.data_ptr(),
+                                                          seg.data_ptr(), ns, out.data_ptr(), state.data_ptr(), pos.data_ptr(), _stream()))
+        return out, state, pos
+
+
+def gc_quantize_index(y, scales, table, bound=0.11, want_yhat=True):
+    y, scales, table = _dev(y, torch.float32), _dev(scales, torch.float32), _dev(table, torch.float32)
+    sym = torch.empty(y.shape, device=y.device, dtype=torch.int32)
+    idx = torch.empty(y.shape, device=y.device, dtype=torch.int32)
+    yhat = torch.empty_like(y) if want_yhat else None
+    _lib.check(_lib.lib().basic_gc_quantize_index_dev(y.data_ptr(), scales.data_ptr(), y.numel(), table.data_ptr(), table.numel(),
+                                                      float(bound), sym.data_ptr(), idx.data_ptr(),
+                                                      yhat.data_ptr() if yhat is not None else None, _stream()))
+    return sym, idx, yhat
+
+
+def eb_quantize_index(z, medians):
+    z, medians = _dev(z, torch.float32), _dev(medians, torch.float32)
+    B, C = z.shape[0], z.shape[1]
+    hw = z.numel() // (B * C)
+    sym = torch.empty(z.shape, device=z.device, dtype=torch.int32)
+    idx = torch.empty(z.shape, device=z.device, dtype=torch.int32)
+    zhat = torch.empty_like(z)
+    _lib.check(_lib.lib().basic_eb_quantize_index_dev(z.data_ptr(), medians.data_ptr(), B, C, hw, sym.data_ptr(), idx.data_ptr(),
+                                                      zhat.data_ptr(), _stream()))
+    return sym, idx, zhat
+
+
+def eb_dequantize(sym, medians):
+    sym, medians = _dev(sym, torch.int32), _dev(medians, torch.float32)
+    B, C = sym.shape[0], sym.shape[1]
+    hw = sym.numel() // (B * C)
+    zhat = torch.empty(sym.shape, device=sym.device, dtype=torch.float32)
+    _lib.check(_lib.lib().basic_eb_dequantize_dev(sym.data_ptr(), medians.data_ptr(), B, C, hw, zhat.data_ptr(), _stream()))
+    return zhat
+
+
+def i32_to_f32(sym):
+    sym = _dev(sym, torch.int32)
+    out = torch.empty(sym.shape, device=sym.device, dtype=torch.float32)
+    _lib.check(_lib.lib().basic_i32_to_f32_dev(sym.data_ptr(), sym.numel(), out.data_ptr(), _stream()))
+    return out
+
+
+def mse_per_image(a, b):
+    a, b = _dev(a, torch.float32), _dev(b, torch.float32)
+    out = torch.empty((a.shape[0],), device=a.device, dtype=torch.float32)
+    _lib.check(_lib.lib().basic_mse_per_image_dev(a.data_ptr(), b.data_ptr(), a.shape[0], a.numel() // a.shape[0], out.data_ptr(), _stream()))
+    return out

@@ -1,0 +1,212 @@
+/*
+ * basic_hip.h -- C ABI of libbasic_hip.so, the MI355X (gfx950) native replacement for the
+ * native layer of worldlife123/cbench_BaSIC on the encode/decode hot path.
+ *
+ * Every entry point is `extern "C"`, takes plain pointers / sizes, returns an int status and
+ * never throws.  Pointers named d_* are DEVICE pointers (HBM); everything else is host
+ * memory.  `hip_stream` is a hipStream_t passed as void* (NULL = default stream).
+ * Citations (file:line) are relative to the reference checkout /root/reference.
+ */
+#ifndef BASIC_HIP_H
+#define BASIC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes (the Python shim maps them to the reference's exceptions) ---------- */
+#define BASIC_OK 0
+#define BASIC_ERR_INVALID (-1)   /* py::value_error in the reference (bad shape/argument)      */
+#define BASIC_ERR_NOT_INIT (-2)  /* "ANS not initialized!"  csrc/ans/rans64.cpp:209,395,506   */
+#define BASIC_ERR_HIP (-3)       /* HIP runtime failure; text in basic_last_error()            */
+#define BASIC_ERR_OVERFLOW (-4)  /* caller buffer too small (reference: UB, rans64.cpp:240)    */
+#define BASIC_ERR_NO_DEVICE (-5) /* no gfx950 device visible: the library never falls back     */
+
+const char *basic_last_error(void);
+/* Number of visible HIP devices; BASIC_ERR_NO_DEVICE if none. */
+int basic_device_count(int *count);
+int basic_set_device(int ordinal);
+int basic_stream_synchronize(void *hip_stream);
+
+/* ======================================================================================
+ * 1. rANS tables  -- replaces Rans64Base::init_params / init_cdf_params / get_cdfs
+ *    (csrc/ans/rans64.cpp:69-182, rans64.hpp:38-49) and pmf_to_quantized_cdf
+ *    (csrc/ans/rans64.cpp:69-126 == csrc/rans/rans_interface.cpp:450-519).
+ *    Tables are built on the host in IEEE float32 with the reference's operation order and
+ *    uploaded once; the object owns both copies.
+ * ==================================================================================== */
+typedef struct basic_rans_tables basic_rans_tables;
+
+int basic_pmf_to_quantized_cdf(const float *pmf, int n, int precision, int32_t *cdf_out /* n+1 */);
+
+/* freqs: int32 [rows][freq_stride]; nsym/offsets: int32 [rows]. */
+int basic_rans_tables_from_freqs(const int32_t *freqs, int rows, int freq_stride, const int32_t *nsym,
+                                 const int32_t *offsets, int freq_precision, int bypass_coding,
+                                 int bypass_precision, basic_rans_tables **out);
+/* cdfs: int32 [rows][cdf_stride]; cdf_sizes/offsets: int32 [rows]. */
+int basic_rans_tables_from_cdfs(const int32_t *cdfs, int rows, int cdf_stride, const int32_t *cdf_sizes,
+                                const int32_t *offsets, int freq_precision, int bypass_coding,
+                                int bypass_precision, basic_rans_tables **out);
+/* AR index-remap tables, ANSBase::init_ar_params (csrc/ans/ans_interface.cpp:75-137):
+ * ar_tab int32 [k][rows][s1] (order 1) or [k][rows][s1][s1] (order 2). */
+int basic_rans_tables_set_ar(basic_rans_tables *t, const int32_t *ar_tab, int k, int rows, int order, int s1);
+int basic_rans_tables_info(const basic_rans_tables *t, int *rows, int *max_cdf_len);
+/* get_cdfs(): out int32 [rows][out_stride], padding written as 0. */
+int basic_rans_tables_get_cdfs(const basic_rans_tables *t, int32_t *out, int out_stride);
+void basic_rans_tables_destroy(basic_rans_tables *t);
+
+/* ======================================================================================
+ * 2. Host-buffer coder -- the drop-in for the pybind11 methods
+ *      Rans64Encoder::encode_with_indexes   csrc/ans/rans64.cpp:203-361
+ *      Rans64Decoder::decode_with_indexes   csrc/ans/rans64.cpp:389-499
+ *      Rans64Decoder::set_stream/decode_stream  rans64.hpp:104-111, rans64.cpp:501-598
+ *      BufferedRansEncoder/RansDecoder      csrc/rans/rans_interface.cpp:109-424
+ *    Arrays are staged to HBM, coded by the HIP kernel, and the result copied back.
+ *    ar_indexes may be NULL (treated as 0); ar_off0/ar_off1 are the per-element back
+ *    distances (rows of the reference's ar_offsets array); pass NULL when no AR table is set.
+ * ==================================================================================== */
+int basic_rans_encode_host(const basic_rans_tables *t, const int32_t *symbols, const int32_t *indexes,
+                           int64_t n, const int32_t *ar_indexes, const int32_t *ar_off0,
+                           const int32_t *ar_off1, uint8_t *out, int64_t out_capacity, int64_t *out_len);
+/* Upper bound of the encoded size in bytes for n symbols (always sufficient). */
+int64_t basic_rans_encode_bound(int64_t n);
+int basic_rans_decode_host(const basic_rans_tables *t, const uint8_t *stream, int64_t stream_len,
+                           const int32_t *indexes, int64_t n, const int32_t *ar_indexes,
+                           const int32_t *ar_off0, const int32_t *ar_off1, int32_t *out_symbols);
+
+typedef struct basic_rans_stream basic_rans_stream;
+int basic_rans_stream_open(const basic_rans_tables *t, const uint8_t *stream, int64_t stream_len,
+                           basic_rans_stream **out);
+int basic_rans_stream_decode(basic_rans_stream *s, const int32_t *indexes, int64_t n, int32_t *out_symbols);
+void basic_rans_stream_close(basic_rans_stream *s);
+
+/* ======================================================================================
+ * 3. Batched device-pointer coder (the hot path: one independent stream per image).
+ *    d_seg[nstreams+1] (int64) gives each stream's symbol range inside d_symbols/d_indexes.
+ *    Encoder: stream i is written right-aligned into its slot
+ *       d_out_words[i*slot_words .. (i+1)*slot_words), its length in d_out_nwords[i]
+ *       (-1 = slot overflow).  Bytes = little-endian u32 words, exactly the reference's
+ *       py::bytes (rans64.cpp:352-354).
+ *    Decoder: stream i is the words d_words[d_word_off[i] .. d_word_off[i+1]) (d_word_off has
+ *       nstreams+1 entries; reads past a stream's end return 0 instead of faulting);
+ *       d_state/d_pos (per stream) carry the coder between calls (decode_stream semantics);
+ *       set d_pos[i] = -1 to initialise from the stream head.
+ * ==================================================================================== */
+int basic_rans_encode_batch_dev(const basic_rans_tables *t, const int32_t *d_symbols,
+                                const int32_t *d_indexes, const int64_t *d_seg, int nstreams,
+                                uint32_t *d_out_words, int64_t slot_words, int32_t *d_out_nwords,
+                                void *hip_stream);
+int basic_rans_decode_batch_dev(const basic_rans_tables *t, const uint32_t *d_words,
+                                const int64_t *d_word_off, const int32_t *d_indexes, const int64_t *d_seg,
+                                int nstreams, int32_t *d_out_symbols, uint64_t *d_state, int64_t *d_pos,
+                                void *hip_stream);
+
+/* ======================================================================================
+ * 4. Entropy-parameter kernels (coalesced elementwise, fused quantise + table index).
+ * ==================================================================================== */
+/* CompressAI GaussianConditional path (compressai_coder.py:377-393; upstream build_indexes
+ * quoted at pgm_coder.py:814-818): idx = (T-1) - #{j<T-1 : max(scale,bound) <= table[j]},
+ * sym = round_half_even(y).  d_table: float32 [T] on device.  d_yhat (optional) = float(sym). */
+int basic_gc_quantize_index_dev(const float *d_y, const float *d_scales, int64_t n, const float *d_table,
+                                int table_len, float scale_bound, int32_t *d_symbols, int32_t *d_indexes,
+                                float *d_yhat, void *hip_stream);
+/* EntropyBottleneck path (compressai_coder.py:230-245): sym = round(z - median[c]),
+ * idx = c, zhat = sym + median[c].  Layout [B][C][HW]. */
+int basic_eb_quantize_index_dev(const float *d_z, const float *d_medians, int batch, int channels, int hw,
+                                int32_t *d_symbols, int32_t *d_indexes, float *d_zhat, void *hip_stream);
+int basic_eb_dequantize_dev(const int32_t *d_symbols, const float *d_medians, int batch, int channels,
+                            int hw, float *d_zhat, void *hip_stream);
+/* int32 symbols -> float32 (GaussianConditional.decompress/dequantize without means). */
+int basic_i32_to_f32_dev(const int32_t *d_in, int64_t n, float *d_out, void *hip_stream);
+
+/* Gaussian PGM coder (pgm_coder.py:735-821, torch_ans.py:279-282) evaluated on the element
+ * list of ONE topo group.  Every image of the batch is an independent stream and shares the
+ * list d_elems (int32 per-image element ids c*HW+p in coding order = ascending flat index,
+ * pgm_coder.py:898-900).  params are "split_interleave" (channel 2c = mean, 2c+1 = scale)
+ * in a [B][2C][HW] tensor; y / ybuf are [B][C][HW].  For element k of image b:
+ *    idx = argmin_j |scale - table[j]| (first minimum),  mu = mean,
+ *    sym = round_half_even(y - mu),  ybuf = sym + mu          (pgm_coder.py:927-941)
+ * Outputs are dense per image: d_symbols/d_indexes[b*per_image + out_base + k]. */
+int basic_pgm_gauss_encode_group_dev(const float *d_y, const float *d_params, int batch, int channels, int hw,
+                                     const int32_t *d_elems, int64_t n_elems, const float *d_table,
+                                     int table_len, int32_t *d_symbols, int32_t *d_indexes, int64_t per_image,
+                                     int64_t out_base, float *d_ybuf, void *hip_stream);
+/* Decoder half: indexes only (before rANS, pgm_coder.py:962-966) ... */
+int basic_pgm_gauss_index_group_dev(const float *d_params, int batch, int channels, int hw,
+                                    const int32_t *d_elems, int64_t n_elems, const float *d_table,
+                                    int table_len, int32_t *d_indexes, int64_t per_image, int64_t out_base,
+                                    void *hip_stream);
+/* ... and reconstruction (after rANS, pgm_coder.py:973-978): ybuf = sym + mu. */
+int basic_pgm_gauss_scatter_group_dev(const int32_t *d_symbols, const float *d_params, int batch, int channels,
+                                      int hw, const int32_t *d_elems, int64_t n_elems, int64_t per_image,
+                                      int64_t in_base, float *d_ybuf, void *hip_stream);
+
+/* ======================================================================================
+ * 5. Transforms: implicit-GEMM convolution on fp32 MFMA (v_mfma_f32_32x32x2_f32) with fused
+ *    bias + activation / (I)GDN epilogue.  Replaces the ATen calls behind
+ *    nn/models/google.py:25-101, nn/layers/slimmable_layers.py:157-183,258-282.
+ * ==================================================================================== */
+typedef struct basic_conv_plan basic_conv_plan;
+
+#define BASIC_ACT_NONE 0
+#define BASIC_ACT_RELU 1
+#define BASIC_ACT_LEAKY_RELU 2 /* slope 0.01 (torch default) */
+#define BASIC_ACT_GDN 3        /* y = x * rsqrt(beta + gamma . x^2)   */
+#define BASIC_ACT_IGDN 4       /* y = x * sqrt (beta + gamma . x^2)   */
+
+/* Create a plan from host weights in PyTorch layout.
+ *   transposed == 0: weight [cout][cin][k][k]  (nn.Conv2d),   out = floor((in+2p-k)/s)+1
+ *   transposed == 1: weight [cin][cout][k][k]  (nn.ConvTranspose2d), out = (in-1)*s-2p+k+output_padding
+ * bias may be NULL.  For GDN/IGDN, gamma [cout][cout] and beta [cout] are the EFFECTIVE
+ * (already re-parametrised, non-negative) values.  cin_active/cout_active <= cin/cout select
+ * the slimmable sub-network (weight slicing W[:co,:ci], slimmable_layers.py:142-170). */
+int basic_conv_plan_create(const float *weight, const float *bias, int cin, int cout, int ksize, int stride,
+                           int padding, int output_padding, int transposed, int activation,
+                           const float *gamma, const float *beta, int cin_active, int cout_active,
+                           basic_conv_plan **out);
+int basic_conv_plan_out_hw(const basic_conv_plan *p, int in_h, int in_w, int *out_h, int *out_w);
+/* d_in: float32 [batch][cin_active][in_h][in_w]; d_out: float32 [batch][cout_active][out_h][out_w]. */
+int basic_conv_forward_dev(const basic_conv_plan *p, const float *d_in, int batch, int in_h, int in_w,
+                           float *d_out, void *hip_stream);
+void basic_conv_plan_destroy(basic_conv_plan *p);
+/* 2*MACs of one forward (conv + GDN), for roofline accounting. */
+int64_t basic_conv_plan_flops(const basic_conv_plan *p, int batch, int in_h, int in_w);
+
+/* ======================================================================================
+ * 6. Topo-group masked convolution (TopoGroupDynamicMaskConv2d.forward,
+ *    nn/layers/masked_conv.py:102-228) evaluated ONLY at a list of positions -- the positions
+ *    of the topo group being coded -- instead of the full map the reference recomputes for
+ *    every group (pgm_coder.py:922-924,958-961).  One operator serves the 5x5 context conv
+ *    and the 1x1 "param merger" layers (pgm_coder.py:1215-1239, masked_conv.py:262-300):
+ *      y[b,co,p] = bias[co] + sum_{ci,tap} W[co,ci,tap] * x[b,ci,p+tap]
+ *                    * [ topo_in[g_in(ci), p+tap]  (< | <=)  topo_out[g_out(co), p] ]
+ * ==================================================================================== */
+typedef struct basic_mconv_plan basic_mconv_plan;
+/* weight [cout][cin][k][k] (k in {1,3,5}, padding k/2), bias [cout] or NULL.
+ * in_groups/out_groups: contiguous channel groups of x / y; allow_same_topogroup selects <=. */
+int basic_mconv_plan_create(const float *weight, const float *bias, int cin, int cout, int ksize,
+                            int in_groups, int out_groups, int allow_same_topogroup, int activation,
+                            basic_mconv_plan **out);
+/* d_x [B][cin][H][W]; d_topo_in int32 [in_groups][H][W]; d_topo_out int32 [out_groups][H][W];
+ * d_pos int32 [n_pos] flat ids b*H*W + y*W + x.  Writes channels
+ * [out_channel_offset, out_channel_offset+cout) of d_y [B][out_channels_total][H][W] at the
+ * listed positions only. */
+int basic_mconv_forward_pos_dev(const basic_mconv_plan *p, const float *d_x, const int32_t *d_topo_in,
+                                const int32_t *d_topo_out, int batch, int h, int w, const int32_t *d_pos,
+                                int64_t n_pos, float *d_y, int out_channels_total, int out_channel_offset,
+                                void *hip_stream);
+void basic_mconv_plan_destroy(basic_mconv_plan *p);
+
+/* ======================================================================================
+ * 7. Distortion metric: per-image PSNR pieces (benchmark/metrics/pytorch_distortion.py:12-15):
+ *    d_mse[b] = mean((a-b)^2) over C*H*W in float32 accumulate-by-tree.
+ * ==================================================================================== */
+int basic_mse_per_image_dev(const float *d_a, const float *d_b, int batch, int64_t elems_per_image,
+                            float *d_mse, void *hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BASIC_HIP_H */

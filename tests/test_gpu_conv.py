@@ -1,0 +1,163 @@
+"""GPU parity: MFMA implicit-GEMM conv / deconv / GDN kernels vs a plain PyTorch fp32 CPU
+reference of the same op (tolerance 1e-4 relative to the output scale, BASELINE.json north_star)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+def _close(got, ref):
+    scale = max(1.0, float(ref.abs().max()))
+    err = float((got.cpu() - ref).abs().max())
+    assert err <= TOL * scale, f"max abs err {err} vs scale {scale}"
+
+
+def _gdn_ref(x, gamma, beta, inverse):
+    C = x.shape[1]
+    norm = F.conv2d(x * x, gamma.reshape(C, C, 1, 1), beta)
+    return x * (torch.sqrt(norm) if inverse else torch.rsqrt(norm))
+
+
+CASES = [
+    # cin, cout, k, s, p, op, transposed, act, B, H, W
+    (3, 128, 5, 2, 2, 0, False, "gdn", 2, 64, 64),
+    (128, 128, 5, 2, 2, 0, False, "gdn", 1, 32, 48),
+    (128, 192, 5, 2, 2, 0, False, "none", 2, 16, 16),
+    (192, 128, 3, 1, 1, 0, False, "relu", 3, 16, 16),
+    (128, 128, 5, 2, 2, 0, False, "leaky", 5, 8, 8),
+    (128, 128, 5, 2, 2, 0, False, "none", 9, 4, 4),
+    (192, 128, 5, 2, 2, 1, True, "igdn", 2, 16, 16),
+    (128, 128, 5, 2, 2, 1, True, "igdn", 1, 24, 40),
+    (128, 3, 5, 2, 2, 1, True, "none", 2, 32, 32),
+    (128, 128, 5, 2, 2, 1, True, "relu", 3, 4, 4),
+    (128, 192, 5, 2, 2, 1, True, "leaky", 2, 8, 8),
+    (288, 384, 3, 1, 1, 0, False, "none", 2, 16, 16),
+    (5, 7, 3, 1, 1, 0, False, "none", 1, 5, 7),       # ragged everything
+    (48, 48, 5, 2, 2, 0, False, "gdn", 1, 18, 22),     # slimmable width, odd sizes
+    (72, 96, 5, 2, 2, 1, True, "igdn", 1, 7, 9),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[str(c) for c in CASES])
+def test_conv_matches_torch(case):
+    from cbench_basic_amd.nn import kernels as K
+    cin, cout, k, s, p, op, tr, act, B, H, W = case
+    if cout > 192:
+        pytest.skip("cout > 192 unsupported by plan")
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    x = torch.randn(B, cin, H, W, generator=g)
+    wshape = (cin, cout, k, k) if tr else (cout, cin, k, k)
+    w = torch.randn(wshape, generator=g) * (1.0 / (cin * k * k) ** 0.5)
+    b = torch.randn(cout, generator=g) * 0.1
+    gamma = beta = None
+    if act in ("gdn", "igdn"):
+        gamma = torch.rand(cout, cout, generator=g) * 0.02 + 0.1 * torch.eye(cout)
+        beta = torch.rand(cout, generator=g) + 0.5
+    ref = F.conv_transpose2d(x, w, b, stride=s, padding=p, output_padding=op) if tr else F.conv2d(x, w, b, stride=s, padding=p)
+    if act == "relu":
+        ref = F.relu(ref)
+    elif act == "leaky":
+        ref = F.leaky_relu(ref)
+    elif act in ("gdn", "igdn"):
+        ref = _gdn_ref(ref, gamma, beta, act == "igdn")
+    code = dict(none=K.ACT_NONE, relu=K.ACT_RELU, leaky=K.ACT_LEAKY_RELU, gdn=K.ACT_GDN, igdn=K.ACT_IGDN)[act]
+    plan = K.ConvPlan(w, b, s, p, op, tr, code, gamma, beta)
+    got = plan(x.cuda())
+    torch.cuda.synchronize()
+    assert got.shape == ref.shape
+    _close(got, ref)
+
+
+def test_slimmable_weight_slicing():
+    """DynamicConv2d semantics (slimmable_layers.py:142-170): W[:co,:ci], b[:co]."""
+    from cbench_basic_amd.nn import kernels as K
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 72, 12, 12, generator=g)
+    w = torch.randn(192, 192, 5, 5, generator=g) * 0.02
+    b = torch.randn(192, generator=g) * 0.1
+    ref = F.conv2d(x, w[:96, :72], b[:96], stride=2, padding=2)
+    plan = K.ConvPlan(w, b, 2, 2, cin_active=72, cout_active=96)
+    _close(plan(x.cuda()), ref)
+
+
+def _masked_conv_ref(x, w, b, topo_in, topo_out, allow_same):
+    """Restates TopoGroupDynamicMaskConv2d.forward (masked_conv.py:102-228) with explicit loops over groups."""
+    B, Cin, H, W = x.shape
+    Cout, _, k, _ = w.shape
+    Gi, Go = topo_in.shape[0], topo_out.shape[0]
+    pad = k // 2
+    xu = F.unfold(x, k, padding=pad).reshape(B, Cin, k * k, H * W)
+    big = 10 ** 6
+    tu = F.unfold(topo_in.float().unsqueeze(0) - big, k, padding=pad).reshape(Gi, k * k, H * W) + big  # padded -> huge
+    out = torch.zeros(B, Cout, H * W)
+    gs_i, gs_o = Cin // Gi, Cout // Go
+    for go in range(Go):
+        c = topo_out[go].reshape(1, 1, H * W).float()
+        m = (tu <= c) if allow_same else (tu < c)  # [Gi, kk, HW]
+        m = m & (tu < big / 2)
+        mm = m.unsqueeze(1).repeat(1, gs_i, 1, 1).reshape(1, Cin, k * k, H * W).float()
+        wg = w[go * gs_o:(go + 1) * gs_o].reshape(gs_o, Cin * k * k)
+        out[:, go * gs_o:(go + 1) * gs_o] = torch.matmul(wg, (xu * mm).reshape(B, Cin * k * k, H * W))
+    return (out + b.reshape(1, Cout, 1)).reshape(B, Cout, H, W)
+
+
+@pytest.mark.parametrize("cfg", [(192, 384, 5, 1, 1, False), (192, 384, 5, 4, 4, False), (768, 640, 1, 2, 1, True),
+                                 (768, 1536, 1, 24, 24, True), (96, 192, 5, 12, 12, False), (40, 24, 3, 2, 2, True)])
+def test_masked_conv_positions(cfg):
+    from cbench_basic_amd.nn import kernels as K
+    cin, cout, k, gi, go, same = cfg
+    g = torch.Generator().manual_seed(cin * 7 + cout)
+    B, H, W = 2, 6, 7
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) * (1.0 / (cin * k * k) ** 0.5)
+    b = torch.randn(cout, generator=g) * 0.1
+    topo_in = torch.randint(-1, 5, (gi, H, W), generator=g)
+    topo_out = torch.randint(0, 5, (go, H, W), generator=g)
+    ref = _masked_conv_ref(x, w, b, topo_in, topo_out, same)
+    plan = K.MaskedConvPlan(w, b, gi, go, same)
+    sel = torch.randperm(B * H * W, generator=g)[: B * H * W - 9].sort().values.int()
+    out = torch.full((B, cout + 8, H, W), -7.0).cuda()
+    plan(x.cuda(), topo_in.int().cuda(), topo_out.int().cuda(), sel.cuda(), out, out_offset=8)
+    torch.cuda.synchronize()
+    out = out.cpu()
+    mask = torch.zeros(B * H * W, dtype=torch.bool)
+    mask[sel.long()] = True
+    mask = mask.reshape(B, 1, H, W)
+    assert torch.all(out[:, :8] == -7.0)
+    got = out[:, 8:]
+    assert torch.all(got[(~mask).expand_as(got)] == -7.0), "positions outside the list were touched"
+    err = ((got - ref).abs() * mask).max()
+    assert err <= TOL * max(1.0, float(ref.abs().max())), float(err)
+
+
+def test_entropy_param_kernels():
+    from cbench_basic_amd.nn import kernels as K
+    g = torch.Generator().manual_seed(0)
+    table = torch.exp(torch.linspace(np.log(0.11), np.log(256), 64))
+    y = torch.randn(2, 192, 16, 16, generator=g) * 5
+    y.view(-1)[:8] = torch.tensor([0.5, 1.5, 2.5, -0.5, -1.5, 3.5, -2.5, 0.49999997])
+    s = torch.rand(2, 192, 16, 16, generator=g) * 30
+    s.view(-1)[:70] = torch.cat([table, torch.tensor([0.0, 0.05, 0.11, 300.0, 256.0, 1e-9])])
+    sym, idx, yhat = K.gc_quantize_index(y.cuda(), s.cuda(), table.cuda())
+    sb = torch.max(s, torch.tensor(0.11))
+    ref_idx = torch.full(s.shape, 63, dtype=torch.int32)
+    for t in table[:-1]:
+        ref_idx -= (sb <= t).int()
+    assert torch.equal(idx.cpu(), ref_idx)
+    assert torch.equal(sym.cpu(), torch.round(y).int())
+    assert torch.equal(yhat.cpu(), torch.round(y))
+    z = torch.randn(3, 128, 4, 4, generator=g) * 3
+    med = torch.randn(128, generator=g)
+    sym, idx, zhat = K.eb_quantize_index(z.cuda(), med.cuda())
+    m4 = med.reshape(1, -1, 1, 1)
+    assert torch.equal(sym.cpu(), torch.round(z - m4).int())
+    assert torch.equal(zhat.cpu(), torch.round(z - m4) + m4)
+    assert torch.equal(idx.cpu(), torch.arange(128).reshape(1, -1, 1, 1).expand(3, 128, 4, 4).int())
+    assert torch.equal(K.eb_dequantize(sym, med.cuda()).cpu(), zhat.cpu())
+    a, b = torch.rand(4, 3, 32, 32, generator=g), torch.rand(4, 3, 32, 32, generator=g)
+    mse = K.mse_per_image(a.cuda(), b.cuda()).cpu()
+    assert torch.allclose(mse, ((a - b) ** 2).reshape(4, -1).mean(1), rtol=1e-5)
