@@ -40,6 +40,7 @@ _SIGNATURES = {
     "basic_rans_stream_decode": (_I, [_P, _P, _L, _P]),
     "basic_rans_stream_close": (None, [_P]),
     "basic_rans_encode_batch_dev": (_I, [_P, _P, _P, _P, _I, _P, _L, _P, _P]),
+    "basic_rans_compact_streams_dev": (_I, [_P, _L, _P, _P, _I, _P, _P]),
     "basic_rans_decode_batch_dev": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _P, _P]),
     "basic_gc_quantize_index_dev": (_I, [_P, _P, _L, _P, _I, _F, _P, _P, _P, _P]),
     "basic_eb_quantize_index_dev": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P]),

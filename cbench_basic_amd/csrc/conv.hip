@@ -38,6 +38,7 @@ constexpr int kCK = 4;        // input channels per LDS stage (2 MFMA k-pairs)
 constexpr int kMaxTaps = 25;  // 5x5
 constexpr int kThreads = 256;
 constexpr int kTilePos = 128;  // output positions per workgroup
+constexpr int kMaxCoutPerLaunch = 192;  // 6 accumulator tiles per wave
 
 struct TapLaunch {
     const float *in;
@@ -47,6 +48,7 @@ struct TapLaunch {
     const float *gammaT;  // [coutp(k)][coutp(i)] effective gamma transposed, zero padded
     const float *beta;    // [coutp]
     int batch, cin, cin_pad, cout, coutp;
+    int out_ctotal, co_base;  // this launch writes channels co_base .. co_base+cout of out_ctotal
     int in_h, in_w, out_h, out_w;
     int mh, mw;  // m-grid of this launch
     int s_in, s_out, oy0, ox0;
@@ -208,7 +210,7 @@ __global__ __launch_bounds__(kThreads) void conv_tap_mfma_kernel(const TapLaunch
     if (my < g.mh && mx < g.mw && b < g.batch) {
         const int oy = my * g.s_out + g.oy0, ox = mx * g.s_out + g.ox0;
         const int64_t plane = static_cast<int64_t>(g.out_h) * g.out_w;
-        float *o = g.out + static_cast<int64_t>(b) * g.cout * plane + static_cast<int64_t>(oy) * g.out_w + ox;
+        float *o = g.out + (static_cast<int64_t>(b) * g.out_ctotal + g.co_base) * plane + static_cast<int64_t>(oy) * g.out_w + ox;
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -226,22 +228,30 @@ struct Phase {
     float *d_wpack = nullptr;
 };
 
+struct Chunk {  // <= 192 output channels handled by one launch family
+    int co0 = 0, cout = 0, coutp = 0, mt = 0;
+    std::vector<Phase> phases;
+    float *d_bias = nullptr;
+};
+
 }  // namespace
 
 struct basic_conv_plan {
     int cin = 0, cout = 0, ksize = 0, stride = 1, padding = 0, output_padding = 0, transposed = 0, act = 0;
-    int cin_pad = 0, coutp = 0, mt = 0;
+    int cin_pad = 0;
     int s_in = 1, s_out = 1;
-    std::vector<Phase> phases;
-    float *d_bias = nullptr, *d_gammaT = nullptr, *d_beta = nullptr;
+    std::vector<Chunk> chunks;
+    float *d_gammaT = nullptr, *d_beta = nullptr;
 };
 
 extern "C" void basic_conv_plan_destroy(basic_conv_plan *p)
 {
     if (!p) return;
-    for (auto &ph : p->phases)
-        if (ph.d_wpack) (void)hipFree(ph.d_wpack);
-    if (p->d_bias) (void)hipFree(p->d_bias);
+    for (auto &ch : p->chunks) {
+        for (auto &ph : ch.phases)
+            if (ph.d_wpack) (void)hipFree(ph.d_wpack);
+        if (ch.d_bias) (void)hipFree(ch.d_bias);
+    }
     if (p->d_gammaT) (void)hipFree(p->d_gammaT);
     if (p->d_beta) (void)hipFree(p->d_beta);
     delete p;
@@ -266,8 +276,8 @@ extern "C" int basic_conv_plan_create(const float *weight, const float *bias, in
     BASIC_REQUIRE(weight && out && cin >= 1 && cout >= 1 && ksize >= 1 && ksize <= 5 && stride >= 1 && stride <= 2 &&
                       padding >= 0 && padding <= ksize,
                   "conv_plan_create: unsupported geometry (k<=5, stride<=2)");
-    BASIC_REQUIRE(cin_active >= 1 && cin_active <= cin && cout_active >= 1 && cout_active <= cout && cout_active <= 192,
-                  "conv_plan_create: active channel slice out of range (cout <= 192)");
+    BASIC_REQUIRE(cin_active >= 1 && cin_active <= cin && cout_active >= 1 && cout_active <= cout,
+                  "conv_plan_create: active channel slice out of range");
     BASIC_REQUIRE(activation >= BASIC_ACT_NONE && activation <= BASIC_ACT_IGDN, "conv_plan_create: bad activation");
     const bool gdn = activation == BASIC_ACT_GDN || activation == BASIC_ACT_IGDN;
     BASIC_REQUIRE(!gdn || (gamma && beta), "conv_plan_create: GDN needs gamma and beta");
@@ -280,73 +290,82 @@ extern "C" int basic_conv_plan_create(const float *weight, const float *bias, in
     p->cin = ci_n; p->cout = co_n; p->ksize = ksize; p->stride = stride; p->padding = padding;
     p->output_padding = output_padding; p->transposed = transposed ? 1 : 0; p->act = activation;
     p->cin_pad = (ci_n + kCK - 1) / kCK * kCK;
-    p->mt = (co_n + 31) / 32;
-    p->coutp = p->mt * 32;
     p->s_in = transposed ? 1 : stride;
     p->s_out = transposed ? stride : 1;
 
-    // ---- tap lists
     const int nph = transposed ? stride : 1;
-    for (int py = 0; py < nph; ++py)
-        for (int px = 0; px < nph; ++px) {
-            Phase ph;
-            ph.oy0 = py; ph.ox0 = px;
-            std::vector<int> kys, kxs, dys, dxs;
-            for (int k = 0; k < ksize; ++k) {
-                if (!transposed) { kys.push_back(k); dys.push_back(k - padding); }
-                else if ((py + padding - k) % stride == 0) { kys.push_back(k); dys.push_back((py + padding - k) / stride); }
-            }
-            for (int k = 0; k < ksize; ++k) {
-                if (!transposed) { kxs.push_back(k); dxs.push_back(k - padding); }
-                else if ((px + padding - k) % stride == 0) { kxs.push_back(k); dxs.push_back((px + padding - k) / stride); }
-            }
-            if (kys.empty() || kxs.empty()) {  // phase receives only the bias
-                ph.ntaps = 0;
-                p->phases.push_back(ph);
-                continue;
-            }
-            int dymin = dys[0], dymax = dys[0], dxmin = dxs[0], dxmax = dxs[0];
-            for (int v : dys) { dymin = v < dymin ? v : dymin; dymax = v > dymax ? v : dymax; }
-            for (int v : dxs) { dxmin = v < dxmin ? v : dxmin; dxmax = v > dxmax ? v : dxmax; }
-            ph.dymin = dymin; ph.dxmin = dxmin; ph.span_y = dymax - dymin + 1; ph.span_x = dxmax - dxmin + 1;
-            std::vector<std::pair<int, int>> taps;  // (ky, kx)
-            for (size_t a = 0; a < kys.size(); ++a)
-                for (size_t b = 0; b < kxs.size(); ++b) {
-                    ph.dy[ph.ntaps] = static_cast<signed char>(dys[a] - dymin);
-                    ph.dx[ph.ntaps] = static_cast<signed char>(dxs[b] - dxmin);
-                    taps.emplace_back(kys[a], kxs[b]);
-                    ++ph.ntaps;
+    const int n_chunks = (co_n + kMaxCoutPerLaunch - 1) / kMaxCoutPerLaunch;
+    const int per_chunk = ((co_n + n_chunks - 1) / n_chunks + 31) / 32 * 32;  // balanced, whole M-tiles
+    for (int co0 = 0; co0 < co_n; co0 += per_chunk) {
+        Chunk ch;
+        ch.co0 = co0;
+        ch.cout = (co_n - co0 < per_chunk) ? co_n - co0 : per_chunk;
+        ch.mt = (ch.cout + 31) / 32;
+        ch.coutp = ch.mt * 32;
+        for (int py = 0; py < nph; ++py)
+            for (int px = 0; px < nph; ++px) {
+                Phase ph;
+                ph.oy0 = py; ph.ox0 = px;
+                std::vector<int> kys, kxs, dys, dxs;
+                for (int k = 0; k < ksize; ++k) {
+                    if (!transposed) { kys.push_back(k); dys.push_back(k - padding); }
+                    else if ((py + padding - k) % stride == 0) { kys.push_back(k); dys.push_back((py + padding - k) / stride); }
                 }
-            // ---- pack weights: [cin_pad/CK][ntaps][CK][coutp]
-            std::vector<float> wp(static_cast<size_t>(p->cin_pad) * ph.ntaps * p->coutp, 0.f);
-            for (int c = 0; c < ci_n; ++c)
-                for (int t = 0; t < ph.ntaps; ++t)
-                    for (int o = 0; o < co_n; ++o) {
-                        const int ky = taps[t].first, kx = taps[t].second;
-                        const float w = transposed
-                            ? weight[((static_cast<size_t>(c) * cout + o) * ksize + ky) * ksize + kx]
-                            : weight[((static_cast<size_t>(o) * cin + c) * ksize + ky) * ksize + kx];
-                        wp[((static_cast<size_t>(c / kCK) * ph.ntaps + t) * kCK + (c % kCK)) * p->coutp + o] = w;
+                for (int k = 0; k < ksize; ++k) {
+                    if (!transposed) { kxs.push_back(k); dxs.push_back(k - padding); }
+                    else if ((px + padding - k) % stride == 0) { kxs.push_back(k); dxs.push_back((px + padding - k) / stride); }
+                }
+                if (kys.empty() || kxs.empty()) {  // phase receives only the bias
+                    ph.ntaps = 0;
+                    ch.phases.push_back(ph);
+                    continue;
+                }
+                int dymin = dys[0], dymax = dys[0], dxmin = dxs[0], dxmax = dxs[0];
+                for (int v : dys) { dymin = v < dymin ? v : dymin; dymax = v > dymax ? v : dymax; }
+                for (int v : dxs) { dxmin = v < dxmin ? v : dxmin; dxmax = v > dxmax ? v : dxmax; }
+                ph.dymin = dymin; ph.dxmin = dxmin; ph.span_y = dymax - dymin + 1; ph.span_x = dxmax - dxmin + 1;
+                std::vector<std::pair<int, int>> taps;  // (ky, kx)
+                for (size_t a = 0; a < kys.size(); ++a)
+                    for (size_t b = 0; b < kxs.size(); ++b) {
+                        ph.dy[ph.ntaps] = static_cast<signed char>(dys[a] - dymin);
+                        ph.dx[ph.ntaps] = static_cast<signed char>(dxs[b] - dxmin);
+                        taps.emplace_back(kys[a], kxs[b]);
+                        ++ph.ntaps;
                     }
-            rc = upload(wp, &ph.d_wpack);
-            p->phases.push_back(ph);
-            if (rc) { basic_conv_plan_destroy(p); return rc; }
-        }
-
-    std::vector<float> hb(p->coutp, 0.f);
-    if (bias) std::memcpy(hb.data(), bias, sizeof(float) * co_n);
-    rc = upload(hb, &p->d_bias);
-    if (!rc && gdn) {
+                // ---- pack weights: [cin_pad/CK][ntaps][CK][coutp]
+                std::vector<float> wp(static_cast<size_t>(p->cin_pad) * ph.ntaps * ch.coutp, 0.f);
+                for (int c = 0; c < ci_n; ++c)
+                    for (int t = 0; t < ph.ntaps; ++t)
+                        for (int o = 0; o < ch.cout; ++o) {
+                            const int ky = taps[t].first, kx = taps[t].second, og = co0 + o;
+                            const float w = transposed
+                                ? weight[((static_cast<size_t>(c) * cout + og) * ksize + ky) * ksize + kx]
+                                : weight[((static_cast<size_t>(og) * cin + c) * ksize + ky) * ksize + kx];
+                            wp[((static_cast<size_t>(c / kCK) * ph.ntaps + t) * kCK + (c % kCK)) * ch.coutp + o] = w;
+                        }
+                rc = upload(wp, &ph.d_wpack);
+                ch.phases.push_back(ph);
+                if (rc) { p->chunks.push_back(ch); basic_conv_plan_destroy(p); return rc; }
+            }
+        std::vector<float> hb(ch.coutp, 0.f);
+        if (bias) std::memcpy(hb.data(), bias + co0, sizeof(float) * ch.cout);
+        rc = upload(hb, &ch.d_bias);
+        p->chunks.push_back(ch);
+        if (rc) { basic_conv_plan_destroy(p); return rc; }
+    }
+    if (gdn) {
+        if (p->chunks.size() != 1) { basic_conv_plan_destroy(p); set_error("conv_plan_create: GDN needs cout <= 192"); return BASIC_ERR_INVALID; }
+        const int coutp = p->chunks[0].coutp;
         // gamma [cout][cout] effective -> gammaT[k][i] = gamma[i][k], zero padded; beta padded with 1
-        std::vector<float> gt(static_cast<size_t>(p->coutp) * p->coutp, 0.f), bt(p->coutp, 1.f);
+        std::vector<float> gt(static_cast<size_t>(coutp) * coutp, 0.f), bt(coutp, 1.f);
         for (int i = 0; i < co_n; ++i) {
             bt[i] = beta[i];
-            for (int k = 0; k < co_n; ++k) gt[static_cast<size_t>(k) * p->coutp + i] = gamma[static_cast<size_t>(i) * cout + k];
+            for (int k = 0; k < co_n; ++k) gt[static_cast<size_t>(k) * coutp + i] = gamma[static_cast<size_t>(i) * cout + k];
         }
         rc = upload(gt, &p->d_gammaT);
         if (!rc) rc = upload(bt, &p->d_beta);
+        if (rc) { basic_conv_plan_destroy(p); return rc; }
     }
-    if (rc) { basic_conv_plan_destroy(p); return rc; }
     *out = p;
     return BASIC_OK;
 }
@@ -408,10 +427,11 @@ extern "C" int basic_conv_forward_dev(const basic_conv_plan *p, const float *d_i
     int oh = 0, ow = 0;
     int rc = basic_conv_plan_out_hw(p, in_h, in_w, &oh, &ow);
     if (rc) return rc;
-    for (const Phase &ph : p->phases) {
+    for (const Chunk &ch : p->chunks)
+    for (const Phase &ph : ch.phases) {
         TapLaunch g{};
-        g.in = d_in; g.out = d_out; g.wpack = ph.d_wpack; g.bias = p->d_bias; g.gammaT = p->d_gammaT; g.beta = p->d_beta;
-        g.batch = batch; g.cin = p->cin; g.cin_pad = ph.ntaps ? p->cin_pad : 0; g.cout = p->cout; g.coutp = p->coutp;
+        g.in = d_in; g.out = d_out; g.wpack = ph.d_wpack; g.bias = ch.d_bias; g.gammaT = p->d_gammaT; g.beta = p->d_beta;
+        g.batch = batch; g.cin = p->cin; g.cin_pad = ph.ntaps ? p->cin_pad : 0; g.cout = ch.cout; g.coutp = ch.coutp; g.out_ctotal = p->cout; g.co_base = ch.co0;
         g.in_h = in_h; g.in_w = in_w; g.out_h = oh; g.out_w = ow;
         g.s_in = p->s_in; g.s_out = p->s_out; g.oy0 = ph.oy0; g.ox0 = ph.ox0;
         g.mh = (oh - ph.oy0 + p->s_out - 1) / p->s_out;
@@ -438,7 +458,7 @@ extern "C" int basic_conv_forward_dev(const basic_conv_plan *p, const float *d_i
         BASIC_REQUIRE(static_cast<int64_t>(tb) * p->cin * in_h * in_w < (1ll << 29), "conv_forward: input tile too large");
         BASIC_REQUIRE(lds_bytes <= 160 * 1024, "conv_forward: LDS budget exceeded");
         hipStream_t st = as_stream(hip_stream);
-        switch (p->mt) {
+        switch (ch.mt) {
             case 1: rc = launch_mt<1>(g, blocks, lds_bytes, st); break;
             case 2: rc = launch_mt<2>(g, blocks, lds_bytes, st); break;
             case 3: rc = launch_mt<3>(g, blocks, lds_bytes, st); break;

@@ -546,6 +546,19 @@ __global__ __launch_bounds__(64) void rans_decode_kernel(TablesDev T, ArDev ar, 
     if (lane == 0) { state[stream] = x; pos_io[stream] = rd.pos; }
 }
 
+// Gather the right-aligned streams of an encode batch into one contiguous buffer.
+__global__ void compact_streams_kernel(const uint32_t *__restrict__ slots, int64_t slot_words,
+                                       const int32_t *__restrict__ nwords, const int64_t *__restrict__ out_off,
+                                       uint32_t *__restrict__ out)
+{
+    const int s = blockIdx.x;
+    const int n = nwords[s];
+    if (n <= 0) return;
+    const uint32_t *src = slots + static_cast<int64_t>(s + 1) * slot_words - n;
+    uint32_t *dst = out + out_off[s];
+    for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < n; i += gridDim.y * blockDim.x) dst[i] = src[i];
+}
+
 TablesDev dev_view(const basic_rans_tables *t)
 {
     return TablesDev{t->d_cdfs, t->d_sizes, t->d_offsets, t->rows, t->stride, t->precision, t->bypass, t->bypass_precision};
@@ -595,6 +608,17 @@ extern "C" int basic_rans_decode_batch_dev(const basic_rans_tables *t, const uin
     ArDev ar{};
     hipLaunchKernelGGL(rans_decode_kernel<false>, dim3(nstreams), dim3(64), 0, as_stream(hip_stream), dev_view(t), ar,
                        d_words, d_word_off, d_indexes, d_seg, d_out_symbols, d_state, d_pos);
+    BASIC_HIP_TRY(hipGetLastError());
+    return BASIC_OK;
+}
+
+extern "C" int basic_rans_compact_streams_dev(const uint32_t *d_slots, int64_t slot_words, const int32_t *d_nwords,
+                                              const int64_t *d_out_off, int nstreams, uint32_t *d_out, void *hip_stream)
+{
+    BASIC_REQUIRE(d_slots && d_nwords && d_out_off && d_out && nstreams >= 1 && slot_words >= 2,
+                  "rans_compact_streams: bad argument");
+    hipLaunchKernelGGL(compact_streams_kernel, dim3(nstreams, 8), dim3(256), 0, as_stream(hip_stream), d_slots, slot_words,
+                       d_nwords, d_out_off, d_out);
     BASIC_HIP_TRY(hipGetLastError());
     return BASIC_OK;
 }

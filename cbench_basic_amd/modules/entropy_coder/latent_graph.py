@@ -1,0 +1,318 @@
+"""Latent-graph entropy model driver -- API of LatentGraphicalANSEntropyCoder
+(cbench/modules/entropy_coder/latent_graph.py:306) restricted to the encode / decode /
+update_state hot path:
+
+    encode:  node generators -> inference edges (x->y->z: g_a, h_a) -> generative pass
+             (z then y): per node  forward (quantise)  +  encode (bytes),  generative edges
+             (z->y: h_s)                                     latent_graph.py:1232-1264, :721, :760
+    decode:  split bytes -> generative pass z -> y -> x (h_s, g_s)      latent_graph.py:1266-1295
+    stream:  merge_bytes([bytes_z, bytes_y], num_segments=2)            utils/bytes_ops.py:19-33
+
+Graph traversal is tiny host logic; every tensor operation it triggers is a HIP kernel.
+Training-only machinery (losses, MC sampling, FLOPs regularisers, sandwich rule) is out of
+scope; the greedy complexity search itself (post_training_process) is a "next" row of
+SURVEY 8f -- its RESULT (per-level node parameters) can be installed with
+``set_complexity_level_params``.
+"""
+import copy
+from typing import Any, Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from ...base import HotPathModule
+from ...codecs.base import (VariableComplexityCodecInterface, VariableRateCodecInterface,
+                            VariableTaskCodecInterface)
+from ...utils.bytes_ops import merge_bytes, split_merged_bytes
+
+
+class LossyDummyEntropyCoder(HotPathModule):
+    """latent_graph.py:68-144: the input node of a lossy codec carries no bits; decoding
+    returns the prior (= g_s output)."""
+
+    def __init__(self, *args, lambda_rd=1.0, distortion_type="mse", **kwargs):
+        super().__init__()
+        self.lambda_rd = lambda_rd
+        self.distortion_type = distortion_type
+
+    def forward(self, data, *args, prior=None, **kwargs):
+        return prior
+
+    def encode(self, data, *args, prior=None, **kwargs) -> bytes:
+        return b""
+
+    def decode(self, byte_string: bytes, *args, prior=None, **kwargs):
+        return prior
+
+    def update_state(self, *args, **kwargs):
+        pass
+
+
+class LatentGraphicalANSEntropyCoder(HotPathModule, VariableRateCodecInterface, VariableComplexityCodecInterface,
+                                     VariableTaskCodecInterface):
+    DEFAULT_EDGE_SPLIT_SYMBOL = "_"
+    DEFAULT_PRIOR_KEY_NAME = "prior"
+    DEFAULT_UNCONDITIONAL_NODE_NAME = "u"
+    DEFAULT_INPUT_NODE_NAME = "x"
+    DEFAULT_RATE_LEVEL_NODE_NAME = "vrlevel"
+    DEFAULT_COMPLEX_LEVEL_NODE_NAME = "sclevel"
+    DEFAULT_TASK_INDEX_NODE_NAME = "taskidx"
+
+    def __init__(self, *args,
+                 use_lossy_compression=True,
+                 lossy_compression_lambda_rd=1.0,
+                 lossy_compression_distortion_type="mse",
+                 node_generator_dict: Dict[str, nn.Module] = None,
+                 node_generator_input_mapping: Optional[Dict[str, Dict[str, str]]] = None,
+                 dynamic_node_generator_dict: Dict[str, nn.Module] = None,
+                 latent_node_entropy_coder_dict: Dict[str, nn.Module] = None,
+                 latent_inference_dict: Dict[str, nn.Module] = None,
+                 latent_generative_dict: Dict[str, nn.Module] = None,
+                 latent_inference_input_mapping: Optional[Dict[str, Dict[str, str]]] = None,
+                 latent_generative_input_mapping: Optional[Dict[str, Dict[str, str]]] = None,
+                 latent_node_inference_topo_order: Optional[List[str]] = None,
+                 latent_node_generative_topo_order: Optional[List[str]] = None,
+                 complexity_level_greedy_search=False,
+                 complexity_level_greedy_search_num_levels: Optional[int] = None,
+                 complexity_level_controller_nodes=(),
+                 task_names: Optional[List[str]] = None,
+                 **kwargs):
+        super().__init__()
+        node_generator_dict = dict(node_generator_dict or {})
+        dynamic_node_generator_dict = dict(dynamic_node_generator_dict or {})
+        latent_node_entropy_coder_dict = dict(latent_node_entropy_coder_dict or {})
+        self.use_lossy_compression = use_lossy_compression
+        if use_lossy_compression and self.DEFAULT_INPUT_NODE_NAME not in latent_node_entropy_coder_dict:
+            latent_node_entropy_coder_dict[self.DEFAULT_INPUT_NODE_NAME] = LossyDummyEntropyCoder(
+                lambda_rd=lossy_compression_lambda_rd, distortion_type=lossy_compression_distortion_type)
+
+        self.node_generators = nn.ModuleDict(node_generator_dict)
+        self.node_generator_input_mapping = dict(node_generator_input_mapping or {})
+        self.dynamic_node_generators = nn.ModuleDict(dynamic_node_generator_dict)
+        self.latent_node_entropy_coders = nn.ModuleDict(latent_node_entropy_coder_dict)
+        self.latent_inference_modules = nn.ModuleDict(dict(latent_inference_dict or {}))
+        self.latent_generative_modules = nn.ModuleDict(dict(latent_generative_dict or {}))
+        self.latent_inference_input_mapping = dict(latent_inference_input_mapping or {})
+        self.latent_generative_input_mapping = dict(latent_generative_input_mapping or {})
+        self.latent_node_inference_topo_order = list(latent_node_inference_topo_order)
+        self.latent_node_generative_topo_order = list(latent_node_generative_topo_order)
+        self.complexity_level_greedy_search = complexity_level_greedy_search
+        self.complexity_level_controller_nodes = list(complexity_level_controller_nodes)
+        self.task_names = task_names
+
+        # edges grouped by destination / source node (latent_graph.py:546-558)
+        sym = self.DEFAULT_EDGE_SPLIT_SYMBOL
+        self._inference_edges_into = {n: [] for n in self.latent_node_inference_topo_order}
+        for edge in self.latent_inference_modules:
+            self._inference_edges_into[edge.split(sym)[1]].append(edge)
+        self._generative_edges_from = {n: [] for n in self.latent_node_generative_topo_order}
+        for edge in self.latent_generative_modules:
+            self._generative_edges_from[edge.split(sym)[0]].append(edge)
+
+        # variable rate / complexity / task bookkeeping (latent_graph.py:566-648)
+        def _levels(name):
+            if name in self.dynamic_node_generators:
+                g = self.dynamic_node_generators[name]
+                return g.max_sample - g.min_sample + 1
+            return 0
+        self._num_rate_levels = _levels(self.DEFAULT_RATE_LEVEL_NODE_NAME)
+        self._num_tasks = _levels(self.DEFAULT_TASK_INDEX_NODE_NAME)
+        self._num_complex_levels = _levels(self.DEFAULT_COMPLEX_LEVEL_NODE_NAME)
+        if complexity_level_greedy_search and complexity_level_greedy_search_num_levels is not None:
+            self._num_complex_levels = complexity_level_greedy_search_num_levels
+        self._current_rate_level = -1
+        self._current_task_idx = -1
+        self._current_complex_level = -1
+        self._complexity_param_all_levels = None  # list of {node name: value}, one per level
+        if self._num_tasks > 0 and self.task_names is None:
+            self.task_names = list(range(self._num_tasks))
+
+    # ---- default nodes (latent_graph.py:650-683)
+    def _get_default_node_dict(self, force_add_default_dynamic_nodes=False, **kwargs):
+        out = {self.DEFAULT_UNCONDITIONAL_NODE_NAME: None, **kwargs}
+        if self.training:
+            return out
+        if self._num_rate_levels > 0 and self.DEFAULT_RATE_LEVEL_NODE_NAME not in out:
+            if self._current_rate_level >= 0:
+                out[self.DEFAULT_RATE_LEVEL_NODE_NAME] = self._current_rate_level
+            elif force_add_default_dynamic_nodes:
+                out[self.DEFAULT_RATE_LEVEL_NODE_NAME] = 0
+        if self._num_tasks > 0 and self.DEFAULT_TASK_INDEX_NODE_NAME not in out:
+            if self._current_task_idx >= 0:
+                out[self.DEFAULT_TASK_INDEX_NODE_NAME] = self._current_task_idx
+            elif force_add_default_dynamic_nodes:
+                out[self.DEFAULT_TASK_INDEX_NODE_NAME] = 0
+        if self._num_complex_levels > 0 and self.DEFAULT_COMPLEX_LEVEL_NODE_NAME not in out:
+            if self.complexity_level_greedy_search and self._complexity_param_all_levels is not None:
+                out.update(**self._complexity_param_all_levels[self._current_complex_level])  # :673-675
+            elif self._current_complex_level >= 0:
+                out[self.DEFAULT_COMPLEX_LEVEL_NODE_NAME] = self._current_complex_level
+            elif force_add_default_dynamic_nodes:
+                out[self.DEFAULT_COMPLEX_LEVEL_NODE_NAME] = 0
+        return out
+
+    # ---- shared encoder/decoder constants (latent_graph.py:686-719)
+    def _node_generate_process(self, **kwargs):
+        out = dict(**kwargs)
+        sym = self.DEFAULT_EDGE_SPLIT_SYMBOL
+        for name, module in self.node_generators.items():
+            inputs = {ik: out[nk] for nk, ik in self.node_generator_input_mapping.get(name, {}).items()}
+            if sym in name:
+                inode, onode = name.split(sym)
+                if onode in out:
+                    continue
+                if name in out:
+                    out[onode] = out.pop(name)
+                    continue
+                out[onode] = module(out[inode], **inputs)
+            elif name not in out:
+                out[name] = module(**inputs)
+        return out
+
+    # ---- inference pass (latent_graph.py:721-758)
+    def _inference_process(self, input_dict):
+        out = dict(**input_dict)
+        sym = self.DEFAULT_EDGE_SPLIT_SYMBOL
+        for node in self.latent_node_inference_topo_order:
+            kw = {ik: out[nk] for nk, ik in self.latent_inference_input_mapping.get(node, {}).items()}
+            for edge in self._inference_edges_into[node]:
+                kw.update({ik: out[ek] for ek, ik in self.latent_inference_input_mapping.get(edge, {}).items()})
+                inode, onode = edge.split(sym)
+                with self.profiler.start_time_profile(f"latent_inference_modules_{edge}"):
+                    val = self.latent_inference_modules[edge](out[inode], **kw)
+                if onode in out:
+                    raise NotImplementedError("multi-edge aggregation is not on the hot path")
+                out[onode] = val
+        return out
+
+    # ---- generative pass (latent_graph.py:760-868)
+    def _generative_process(self, input_dict, prior_dict=None, do_encode=False, **kwargs):
+        data = dict(**input_dict)
+        kw_all = dict(**input_dict, **kwargs)
+        prior_dict = dict(prior_dict or {})
+        sym = self.DEFAULT_EDGE_SPLIT_SYMBOL
+        nodes = list(self.latent_node_generative_topo_order)
+        if do_encode and self.use_lossy_compression:
+            nodes.remove(self.DEFAULT_INPUT_NODE_NAME)
+        for node in nodes:
+            prior_dict.setdefault(node, dict())
+            node_data = data.get(node)
+            if node in self.latent_node_entropy_coders:
+                coder = self.latent_node_entropy_coders[node]
+                pk = dict()
+                priors = prior_dict[node]
+                if node in self.latent_generative_input_mapping:
+                    for nk, ik in self.latent_generative_input_mapping[node].items():
+                        if len(priors) == 1:
+                            pk.update(prior=list(priors.values())[0])
+                        if nk in priors:
+                            pk[ik] = priors[nk]
+                        elif nk in kw_all:
+                            pk[ik] = kw_all[nk]
+                        else:
+                            raise ValueError(f"latent_generative_input_mapping incorrect! node {node}, mapping {nk} : {ik}")
+                else:
+                    assert len(priors) <= 1
+                    if len(priors) == 1:
+                        pk.update(prior=list(priors.values())[0])
+                with self.profiler.start_time_profile(f"latent_node_entropy_coders_{node}"):
+                    if isinstance(node_data, bytes):
+                        node_data = coder.decode(node_data, **pk)
+                        data[node] = node_data
+                    else:
+                        raw = node_data
+                        node_data = coder(raw, **pk)            # forward: quantised latent (:836)
+                        data[node] = coder.encode(raw, **pk) if do_encode else node_data  # (:838)
+                    kw_all[node] = node_data
+            for edge in self._generative_edges_from[node]:
+                ek = {ik: kw_all[k] for k, ik in self.latent_generative_input_mapping.get(edge, {}).items()}
+                inode, onode = edge.split(sym)
+                if do_encode and self.use_lossy_compression and onode == self.DEFAULT_INPUT_NODE_NAME:
+                    continue  # g_s is not needed to encode (:855-856)
+                with self.profiler.start_time_profile(f"latent_generative_modules_{edge}"):
+                    val = self.latent_generative_modules[edge](node_data, **ek)
+                kw_all[edge] = val
+                prior_dict.setdefault(onode, dict())[inode] = val
+        return data, prior_dict
+
+    def _coded_nodes(self):
+        nodes = list(self.latent_node_generative_topo_order)
+        if self.use_lossy_compression:
+            nodes.remove(self.DEFAULT_INPUT_NODE_NAME)
+        return nodes
+
+    def encode(self, data, *args, prior=None, **kwargs):
+        with torch.no_grad():
+            if data.device != self.device:
+                data = data.to(device=self.device)
+            node_dict = self._node_generate_process(**self._get_default_node_dict(force_add_default_dynamic_nodes=True, **kwargs))
+            input_dict = {self.DEFAULT_INPUT_NODE_NAME: data, **node_dict}
+            prior_dict = dict() if prior is None else {self.DEFAULT_INPUT_NODE_NAME: dict(prior=prior)}
+            with self.profiler.start_time_profile("encode_inference"):
+                latent_dict = self._inference_process(input_dict)
+            with self.profiler.start_time_profile("encode_generative"):
+                data_dict, _ = self._generative_process(latent_dict, prior_dict=prior_dict, do_encode=True)
+            nodes = self._coded_nodes()
+            return merge_bytes([data_dict[n] for n in nodes], num_segments=len(nodes))
+
+    def decode(self, data, *args, prior=None, **kwargs):
+        with torch.no_grad():
+            node_dict = self._node_generate_process(**self._get_default_node_dict(force_add_default_dynamic_nodes=True, **kwargs))
+            nodes = self._coded_nodes()
+            input_dict = dict(zip(nodes, split_merged_bytes(data, num_segments=len(nodes))))
+            prior_dict = dict() if prior is None else {self.DEFAULT_INPUT_NODE_NAME: dict(prior=prior)}
+            if self.use_lossy_compression:
+                input_dict[self.DEFAULT_INPUT_NODE_NAME] = b""
+            with self.profiler.start_time_profile("decode_generative"):
+                data_dict, _ = self._generative_process(input_dict, prior_dict=prior_dict, **node_dict)
+            return data_dict[self.DEFAULT_INPUT_NODE_NAME]
+
+    def forward(self, data, *args, **kwargs):
+        """Eval-mode forward: quantised reconstruction without entropy coding (latent_graph.py:870-1230
+        minus the training losses)."""
+        with torch.no_grad():
+            node_dict = self._node_generate_process(**self._get_default_node_dict(force_add_default_dynamic_nodes=True, **kwargs))
+            latent = self._inference_process({self.DEFAULT_INPUT_NODE_NAME: data.to(self.device), **node_dict})
+            data_dict, prior_dict = self._generative_process(latent)
+            return data_dict[self.DEFAULT_INPUT_NODE_NAME]
+
+    def update_state(self, *args, **kwargs) -> None:  # latent_graph.py:1297-1301
+        for coder in self.latent_node_entropy_coders.values():
+            coder.update_state(*args, **kwargs)
+
+    # ---- VariableRate / Complexity / Task (latent_graph.py:1660-1691)
+    def set_rate_level(self, level, *args, **kwargs) -> None:
+        assert 0 <= level < max(1, self._num_rate_levels)
+        self._current_rate_level = level
+
+    @property
+    def num_rate_levels(self):
+        return max(1, self._num_rate_levels)
+
+    def set_complex_level(self, level, *args, **kwargs) -> None:
+        assert 0 <= level < max(1, self._num_complex_levels)
+        self._current_complex_level = level
+
+    @property
+    def num_complex_levels(self):
+        return max(1, self._num_complex_levels)
+
+    def set_complexity_level_params(self, params_per_level: List[Dict[str, Any]]):
+        """Install the outcome of the greedy search (latent_graph.py:1615-1619): one dict of
+        controller-node values (e.g. slim one-hots pgmxy/pgmyz/pgmzy/pgmyx) per level."""
+        self._complexity_param_all_levels = list(params_per_level)
+        self._num_complex_levels = len(params_per_level)
+        self.complexity_level_greedy_search = True
+
+    def get_current_complex_metrics(self, *args, **kwargs):
+        return dict()
+
+    def set_task(self, task, *args, **kwargs) -> bool:
+        if self._num_tasks == 0:
+            return False
+        self._current_task_idx = self.task_names.index(task) if task in self.task_names else int(task)
+        return True
+
+    @property
+    def num_tasks(self):
+        return max(1, self._num_tasks)

@@ -1,0 +1,286 @@
+"""z / y latent coders of the plain hyperprior graph -- API of
+cbench/modules/prior_model/prior_coder/compressai_coder.py:87-397 (CompressAIEntropyBottleneckPriorCoder,
+CompressAISlimmableEntropyBottleneckPriorCoder, CompressAIGaussianConditionalCoder).
+
+The reference delegates the arithmetic to CompressAI 1.2.3 (``EntropyBottleneck``,
+``GaussianConditional``, ``compressai.ans``), which is NOT vendored in the reference tree
+(requirements.txt:15).  Its published algorithm is restated here:
+  * table construction (``update()``) runs once, on the host, in float32 with the upstream
+    operation order, and the integer CDFs are uploaded to HBM;
+  * the per-image work -- quantise, table index, rANS -- is hand-written HIP
+    (csrc/entropy.hip, csrc/rans.hip), one rANS stream per image, bypass always on,
+    16-bit precision (csrc/rans/rans_interface.cpp:50-53 is the in-tree fork of compressai.ans).
+Framing is the reference's ``write_body``/``read_body`` (compressai_coder.py:63-84), big-endian.
+"""
+import math
+import struct
+from typing import List
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ....base import HotPathModule
+from ....nn import kernels as K
+from .... import ans as _ans
+
+SCALES_MIN, SCALES_MAX, SCALES_LEVELS = 0.11, 256, 64
+
+
+def get_scale_table(min=SCALES_MIN, max=SCALES_MAX, levels=SCALES_LEVELS):
+    """compressai_coder.py:28-30."""
+    return torch.exp(torch.linspace(math.log(min), math.log(max), levels))
+
+
+def write_body(shape, out_strings: List[List[bytes]], segments=1) -> bytes:
+    """compressai_coder.py:75-84: >III (H, W, n) then per string >I length(s) and payload(s)."""
+    parts = [struct.pack(">3I", shape[0], shape[1], len(out_strings))]
+    for s in out_strings:
+        assert len(s) == segments
+        parts.append(struct.pack(">%dI" % segments, *[len(seg) for seg in s]))
+        parts.extend(s)
+    return b"".join(parts)
+
+
+def read_body(data: bytes, segments=1):
+    """compressai_coder.py:63-72."""
+    h, w, n = struct.unpack(">3I", data[:12])
+    cur, out = 12, []
+    for _ in range(n):
+        lens = struct.unpack(">%dI" % segments, data[cur:cur + 4 * segments])
+        cur += 4 * segments
+        batch = []
+        for L in lens:
+            batch.append(data[cur:cur + L])
+            cur += L
+        out.append(batch)
+    return out, (h, w)
+
+
+def _pmf_to_cdf(pmf, tail_mass, pmf_length, max_length, precision=16):
+    """EntropyModel._pmf_to_cdf (upstream): per row quantise [pmf[:len], tail] to a 2^16 CDF."""
+    cdf = np.zeros((len(pmf_length), max_length + 2), dtype=np.int32)
+    for i in range(len(pmf_length)):
+        prob = np.concatenate([pmf[i, : pmf_length[i]], tail_mass[i]]).astype(np.float32)
+        q = _ans.pmf_to_quantized_cdf(prob.tolist(), precision)
+        cdf[i, : len(q)] = q
+    return cdf
+
+
+class EntropyBottleneck(nn.Module):
+    """Parameter holder + table builder of the factorised prior (Balle et al. 2018), with
+    CompressAI 1.2.3's parameter names (matrices.N / biases.N / factors.N / quantiles)."""
+
+    def __init__(self, channels, tail_mass=1e-9, init_scale=10, filters=(3, 3, 3, 3)):
+        super().__init__()
+        self.channels = int(channels)
+        self.filters = tuple(int(f) for f in filters)
+        self.init_scale = float(init_scale)
+        self.tail_mass = float(tail_mass)
+        f = (1,) + self.filters + (1,)
+        scale = self.init_scale ** (1 / (len(self.filters) + 1))
+        self.matrices, self.biases, self.factors = nn.ParameterList(), nn.ParameterList(), nn.ParameterList()
+        for i in range(len(self.filters) + 1):
+            init = np.log(np.expm1(1 / scale / f[i + 1]))
+            self.matrices.append(nn.Parameter(torch.full((channels, f[i + 1], f[i]), float(init))))
+            self.biases.append(nn.Parameter(torch.empty(channels, f[i + 1], 1).uniform_(-0.5, 0.5)))
+            if i < len(self.filters):
+                self.factors.append(nn.Parameter(torch.zeros(channels, f[i + 1], 1)))
+        self.quantiles = nn.Parameter(torch.tensor([-self.init_scale, 0.0, self.init_scale]).repeat(channels, 1, 1))
+        target = np.log(2 / self.tail_mass - 1)
+        self.register_buffer("target", torch.Tensor([-target, 0, target]))
+
+    def _logits_cumulative(self, inputs):
+        logits = inputs
+        for i in range(len(self.filters) + 1):
+            logits = torch.matmul(F.softplus(self.matrices[i].detach().float().cpu()), logits)
+            logits = logits + self.biases[i].detach().float().cpu()
+            if i < len(self.filters):
+                logits = logits + torch.tanh(self.factors[i].detach().float().cpu()) * torch.tanh(logits)
+        return logits
+
+    def medians(self):
+        return self.quantiles.detach()[:, 0, 1].float()
+
+    def build_tables(self):
+        """EntropyBottleneck.update() (upstream): returns (cdf int32 [C, L], cdf_length, offset)."""
+        with torch.no_grad():
+            q = self.quantiles.detach().float().cpu()
+            medians = q[:, 0, 1]
+            minima = torch.clamp(torch.ceil(medians - q[:, 0, 0]).int(), min=0)
+            maxima = torch.clamp(torch.ceil(q[:, 0, 2] - medians).int(), min=0)
+            offset = -minima
+            pmf_start = medians - minima
+            pmf_length = maxima + minima + 1
+            max_length = int(pmf_length.max().item())
+            samples = torch.arange(max_length)[None, :] + pmf_start[:, None, None]
+            lower = self._logits_cumulative(samples - 0.5)
+            upper = self._logits_cumulative(samples + 0.5)
+            sign = -torch.sign(lower + upper)
+            pmf = torch.abs(torch.sigmoid(sign * upper) - torch.sigmoid(sign * lower))[:, 0, :]
+            tail = torch.sigmoid(lower[:, 0, :1]) + torch.sigmoid(-upper[:, 0, -1:])
+        cdf = _pmf_to_cdf(pmf.numpy(), tail.numpy(), pmf_length.numpy(), max_length)
+        return cdf, (pmf_length + 2).numpy().astype(np.int32), offset.numpy().astype(np.int32)
+
+
+class CompressAIEntropyBottleneckPriorCoder(HotPathModule):
+    """compressai_coder.py:87-248."""
+
+    def __init__(self, entropy_bottleneck_channels=256, eps=1e-7, use_inner_aux_opt=False, use_bit_rate_loss=True,
+                 freeze_params=False, training_output_straight_through=False, **kwargs):
+        super().__init__()
+        self.entropy_bottleneck = EntropyBottleneck(entropy_bottleneck_channels)
+        self.eps = eps
+        self._tables = None
+        self._medians_dev = None
+
+    def _ready(self):
+        if self._tables is None:
+            raise RuntimeError("Not Initialized! Should call self.update_state() before coding!")
+        if self._medians_dev is None or self._medians_dev.device != self.device:
+            self._medians_dev = self.entropy_bottleneck.medians().to(self.device).contiguous()
+
+    def update_state(self, *args, **kwargs) -> None:  # :247-248 -> EntropyBottleneck.update()
+        cdf, lengths, offsets = self.entropy_bottleneck.build_tables()
+        self._tables = K.RansTables(cdfs=cdf, cdf_sizes=lengths, offsets=offsets, precision=16, bypass=True, bypass_precision=4)
+        self._cdf_host = (cdf, lengths, offsets)
+        self._medians_dev = None
+
+    def forward(self, input, *args, channel_gains=None, channel_gains_inv=None, **kwargs):
+        """Eval-mode forward (:203-228): dequantised latent round(z - median) + median."""
+        self._ready()
+        if channel_gains is not None:
+            input = input * channel_gains.reshape(1, -1, 1, 1)
+        _, _, zhat = K.eb_quantize_index(input, self._medians_dev)
+        if channel_gains_inv is not None:
+            zhat = zhat * channel_gains_inv.reshape(1, -1, 1, 1)
+        return zhat
+
+    def encode(self, input, *args, channel_gains=None, channel_gains_inv=None, **kwargs) -> bytes:  # :230-236
+        self._ready()
+        if channel_gains is not None:
+            input = input * channel_gains.reshape(1, -1, 1, 1)
+        sym, idx, _ = K.eb_quantize_index(input, self._medians_dev)
+        n = sym[0].numel()
+        strings = self._tables.encode_batch_to_bytes(sym.reshape(-1), idx.reshape(-1), n)
+        return write_body(input.shape[-2:], [[s] for s in strings])
+
+    def decode(self, byte_string, *args, channel_gains=None, channel_gains_inv=None, **kwargs):  # :238-245
+        self._ready()
+        strings, shape = read_body(byte_string)
+        B, C = len(strings), self.entropy_bottleneck.channels
+        idx = torch.arange(C, device=self.device, dtype=torch.int32).reshape(1, C, 1, 1).expand(B, C, *shape).contiguous()
+        sym = self._tables.decode_batch_from_bytes([s[0] for s in strings], idx.reshape(-1), C * shape[0] * shape[1])
+        zhat = K.eb_dequantize(sym.reshape(B, C, *shape), self._medians_dev)
+        if channel_gains_inv is not None:
+            zhat = zhat * channel_gains_inv.reshape(1, -1, 1, 1)
+        return zhat
+
+
+class CompressAISlimmableEntropyBottleneckPriorCoder(HotPathModule):
+    """compressai_coder.py:251-338: one EntropyBottleneck per slimmable width."""
+
+    def __init__(self, entropy_bottleneck_channels_list=[256], **kwargs):
+        super().__init__()
+        self.entropy_bottleneck_channels_list = list(entropy_bottleneck_channels_list)
+        self.entropy_bottlenecks = nn.ModuleList(
+            [CompressAIEntropyBottleneckPriorCoder(c, **kwargs) for c in self.entropy_bottleneck_channels_list])
+
+    def _pick(self, channels, slim_level):
+        return self.entropy_bottlenecks[self.entropy_bottleneck_channels_list.index(channels) if slim_level is None else slim_level]
+
+    def forward(self, input, *args, slim_level=None, **kwargs):
+        return self._pick(input.shape[1], slim_level)(input, *args, **kwargs)
+
+    def encode(self, input, *args, slim_level=None, **kwargs) -> bytes:
+        return self._pick(input.shape[1], slim_level).encode(input, *args, **kwargs)
+
+    def decode(self, byte_string, *args, slim_level=None, **kwargs):
+        if slim_level is None:
+            # the reference dereferences an undefined tensor here (compressai_coder.py:333); require the level
+            raise ValueError("slim_level is required to decode a slimmable entropy bottleneck stream")
+        return self.entropy_bottlenecks[slim_level].decode(byte_string, *args, **kwargs)
+
+    def update_state(self, *args, **kwargs) -> None:
+        for eb in self.entropy_bottlenecks:
+            eb.update_state(*args, **kwargs)
+
+
+def gaussian_conditional_tables(scale_table: torch.Tensor, tail_mass=1e-9):
+    """GaussianConditional.update() (upstream; an in-tree restatement sits commented out at
+    pgm_coder.py:2095-2135).  Returns (cdf int32 [T, L], cdf_length, offset)."""
+    from scipy.stats import norm
+    st = scale_table.float().cpu()
+    multiplier = -norm.ppf(tail_mass / 2)
+    pmf_center = torch.ceil(st * multiplier).int()
+    pmf_length = 2 * pmf_center + 1
+    max_length = int(torch.max(pmf_length).item())
+    samples = torch.abs(torch.arange(max_length).int() - pmf_center[:, None]).float()
+    scale = st.unsqueeze(1).float()
+
+    def phi(v):
+        return 0.5 * torch.erfc(-(2 ** -0.5) * v)
+
+    upper = phi((0.5 - samples) / scale)
+    lower = phi((-0.5 - samples) / scale)
+    pmf = upper - lower
+    tail = 2 * lower[:, :1]
+    cdf = _pmf_to_cdf(pmf.numpy(), tail.numpy(), pmf_length.numpy(), max_length)
+    return cdf, (pmf_length + 2).numpy().astype(np.int32), (-pmf_center).numpy().astype(np.int32)
+
+
+class CompressAIGaussianConditionalCoder(HotPathModule):
+    """compressai_coder.py:341-397: zero-mean Gaussian with hyperprior scales."""
+
+    def __init__(self, use_bit_rate_loss=True, training_output_straight_through=False, scale_bound=0.11, **kwargs):
+        super().__init__()
+        self.scale_bound = float(scale_bound)
+        self._tables = None
+        self._scale_table_dev = None
+
+    def update_state(self, *args, **kwargs) -> None:  # :395-397
+        self.scale_table = get_scale_table()
+        cdf, lengths, offsets = gaussian_conditional_tables(self.scale_table)
+        self._tables = K.RansTables(cdfs=cdf, cdf_sizes=lengths, offsets=offsets, precision=16, bypass=True, bypass_precision=4)
+        self._cdf_host = (cdf, lengths, offsets)
+        self._scale_table_dev = None
+
+    def _ready(self):
+        if self._tables is None:
+            raise RuntimeError("Not Initialized! Should call self.update_state() before coding!")
+        if self._scale_table_dev is None or self._scale_table_dev.device != self.device:
+            self._scale_table_dev = self.scale_table.to(self.device).contiguous()
+
+    @staticmethod
+    def _crop(prior, h, w):
+        return prior[..., :h, :w].contiguous()
+
+    def forward(self, y, *args, prior=None, channel_gains=None, channel_gains_inv=None, **kwargs):
+        self._ready()
+        if channel_gains is not None:
+            y = y * channel_gains.reshape(1, -1, 1, 1)
+        _, _, yhat = K.gc_quantize_index(y, self._crop(prior, *y.shape[-2:]), self._scale_table_dev, self.scale_bound)
+        if channel_gains_inv is not None:
+            yhat = yhat * channel_gains_inv.reshape(1, -1, 1, 1)
+        return yhat
+
+    def encode(self, y, *args, prior=None, channel_gains=None, channel_gains_inv=None, **kwargs):  # :377-385
+        self._ready()
+        if channel_gains is not None:
+            y = y * channel_gains.reshape(1, -1, 1, 1)
+        sym, idx, _ = K.gc_quantize_index(y, self._crop(prior, *y.shape[-2:]), self._scale_table_dev, self.scale_bound,
+                                          want_yhat=False)
+        strings = self._tables.encode_batch_to_bytes(sym.reshape(-1), idx.reshape(-1), sym[0].numel())
+        return write_body(y.shape[-2:], [[s] for s in strings])
+
+    def decode(self, byte_string, *args, prior=None, channel_gains=None, channel_gains_inv=None, **kwargs):  # :387-393
+        self._ready()
+        strings, shape = read_body(byte_string)
+        scales = self._crop(prior, *shape)
+        _, idx, _ = K.gc_quantize_index(scales, scales, self._scale_table_dev, self.scale_bound, want_yhat=False)
+        sym = self._tables.decode_batch_from_bytes([s[0] for s in strings], idx.reshape(-1), idx[0].numel())
+        yhat = K.i32_to_f32(sym.reshape(idx.shape))
+        if channel_gains_inv is not None:
+            yhat = yhat * channel_gains_inv.reshape(1, -1, 1, 1)
+        return yhat

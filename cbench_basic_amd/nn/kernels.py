@@ -162,6 +162,42 @@ class RansTables:
                                                           words.data_ptr(), slot_words, nwords.data_ptr(), _stream()))
         return words, nwords
 
+    def encode_batch_to_bytes(self, symbols, indexes, n_per_stream):
+        """Equal-length streams (one per image): returns a list of ``bytes`` (reference py::bytes)."""
+        symbols, indexes = _dev(symbols, torch.int32), _dev(indexes, torch.int32)
+        ns = symbols.numel() // n_per_stream
+        seg = torch.arange(ns + 1, device=symbols.device, dtype=torch.int64) * n_per_stream
+        slot = n_per_stream + 2  # the reference's own buffer size (rans64.cpp:240)
+        words, nwords = self.encode_batch(symbols, indexes, seg, slot)
+        nw = nwords.cpu().numpy()
+        if (nw < 0).any():  # bypass-heavy data: retry with the guaranteed bound
+            slot = 3 * n_per_stream + 4
+            words, nwords = self.encode_batch(symbols, indexes, seg, slot)
+            nw = nwords.cpu().numpy()
+        off = np.concatenate([[0], np.cumsum(nw)]).astype(np.int64)
+        d_off = torch.from_numpy(off).to(symbols.device)
+        packed = torch.empty((int(off[-1]),), device=symbols.device, dtype=torch.int32)
+        _lib.check(_lib.lib().basic_rans_compact_streams_dev(words.data_ptr(), slot, nwords.data_ptr(), d_off.data_ptr(), ns,
+                                                             packed.data_ptr(), _stream()))
+        host = packed.cpu().numpy()
+        return [host[off[i]:off[i + 1]].tobytes() for i in range(ns)]
+
+    def decode_batch_from_bytes(self, strings, indexes, n_per_stream):
+        """Inverse of encode_batch_to_bytes: int32 symbols shaped like ``indexes`` (device)."""
+        indexes = _dev(indexes, torch.int32)
+        ns = len(strings)
+        for s in strings:
+            if len(s) < 8 or len(s) % 4:
+                raise ValueError("rANS stream must hold >= 2 whole 32-bit words")
+        lens = np.array([len(s) // 4 for s in strings], dtype=np.int64)
+        woff = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        host = np.frombuffer(b"".join(strings), dtype=np.int32)
+        d_words = torch.from_numpy(host.copy()).to(indexes.device)
+        d_woff = torch.from_numpy(woff).to(indexes.device)
+        seg = torch.arange(ns + 1, device=indexes.device, dtype=torch.int64) * n_per_stream
+        out, _, _ = self.decode_batch(d_words, d_woff, indexes, seg)
+        return out
+
     def decode_batch(self, words, word_off, indexes, seg, out=None, state=None, pos=None):
         words, word_off = _dev(words, torch.int32), _dev(word_off, torch.int64)
         indexes, seg = _dev(indexes, torch.int32), _dev(seg, torch.int64)

@@ -98,6 +98,10 @@ int basic_rans_encode_batch_dev(const basic_rans_tables *t, const int32_t *d_sym
                                 const int32_t *d_indexes, const int64_t *d_seg, int nstreams,
                                 uint32_t *d_out_words, int64_t slot_words, int32_t *d_out_nwords,
                                 void *hip_stream);
+/* Packs the right-aligned encoder slots into one contiguous buffer: stream i (d_nwords[i] words)
+ * goes to d_out + d_out_off[i]; streams with d_nwords[i] <= 0 are skipped. */
+int basic_rans_compact_streams_dev(const uint32_t *d_slots, int64_t slot_words, const int32_t *d_nwords,
+                                   const int64_t *d_out_off, int nstreams, uint32_t *d_out, void *hip_stream);
 int basic_rans_decode_batch_dev(const basic_rans_tables *t, const uint32_t *d_words,
                                 const int64_t *d_word_off, const int32_t *d_indexes, const int64_t *d_seg,
                                 int nstreams, int32_t *d_out_symbols, uint64_t *d_state, int64_t *d_pos,
