@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""Headline benchmark: encode+decode throughput (Mpix/s) of the hyperprior codec on synthetic
+3x256x256 batches, one process per GPU, images sharded per rank (no data-path collective), one
+RCCL all-reduce of the metric sums at the end (the analogue of reduce_across_processes,
+cbench/utils/logging_utils.py:458-465).
+
+A "step" = codec.compress(batch) followed by codec.decompress(bytes) for one batch of
+--batch images resident in HBM (bytes cross PCIe in both directions inside the step, exactly as
+the reference's timed region does, basic_benchmark.py:200-231).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     -- conv MFMA kernel family: algorithmic FLOPs / measured kernel time vs 157.3 TF fp32
+  cpu_baseline -- the CPU oracle (PyTorch-CPU fp32 convs + C rANS restatement) on a bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md "Peak FP32 (matrix)"
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=256, help="images per GPU per step (weak scaling)")
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--cpu-images", type=int, default=64, help="bounded CPU-baseline sample (images)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def conv_flops_per_image(codec, size):
+    """Algorithmic FLOPs (2*MAC, conv + GDN) of encode (g_a, h_a, h_s) + decode (h_s, g_s) per image."""
+    ec = codec.entropy_coder
+    g_a, h_a = ec.latent_inference_modules["x_y"], ec.latent_inference_modules["y_z"]
+    h_s, g_s = ec.latent_generative_modules["z_y"], ec.latent_generative_modules["y_x"]
+    s16, s64 = size // 16, size // 64
+    enc = g_a.flops(1, size, size) + h_a.flops(1, s16, s16) + h_s.flops(1, s64, s64)
+    dec = h_s.flops(1, s64, s64) + g_s.flops(1, s16, s16)
+    return enc, dec
+
+
+def measure_conv_kernels(codec, x, reps=3):
+    """HIP-event time of the transform launches alone (same stream as the launches), returning
+    (seconds per pass over the batch, launches per pass)."""
+    ec = codec.entropy_coder
+    g_a, h_a = ec.latent_inference_modules["x_y"], ec.latent_inference_modules["y_z"]
+    h_s, g_s = ec.latent_generative_modules["z_y"], ec.latent_generative_modules["y_x"]
+
+    def one_pass():
+        y = g_a(x)
+        z = h_a(y)
+        s = h_s(z)
+        s2 = h_s(z)
+        xh = g_s(y)
+        return xh
+
+    one_pass()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        one_pass()
+    e1.record()
+    torch.cuda.synchronize()
+    launches = 0
+    for m in (g_a, h_a, h_s, h_s, g_s):
+        for p in m.plans():
+            launches += (1 if p.cout <= 4 else 4) if p.transposed else 1
+    return e0.elapsed_time(e1) / 1e3 / reps, launches
+
+
+def cpu_baseline(codec_cpu_state, n_images, size):
+    from oracle.codec_oracle import HyperpriorOracle
+    # the GPU box gives one GPU a 16-core CPU share; more threads than that only oversubscribes
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))
+    torch.set_num_threads(cores)
+    oracle = HyperpriorOracle(codec_cpu_state)
+    torch.manual_seed(0)
+    oracle.decompress(oracle.compress(torch.rand(1, 3, size, size)))  # warm-up
+    t0, done = time.time(), 0
+    for i in range(n_images):  # bounded sample: stop after ~20 s of CPU work
+        torch.manual_seed(i)
+        x = torch.rand(1, 3, size, size)
+        oracle.decompress(oracle.compress(x))
+        done += 1
+        if time.time() - t0 > 20.0:
+            break
+    dt = time.time() - t0
+    return dict(value=done * size * size / dt / 1e6, unit="Mpix/s", cores=cores, kind="port",
+                sample=f"{done} images 3x{size}x{size}, batch 1 (seeds 0..{done - 1}), PyTorch-CPU fp32 transforms + "
+                       f"C rANS oracle, {dt:.1f} s wall")
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl")  # RCCL over xGMI
+    dev = torch.device("cuda", local_rank)
+
+    from cbench_basic_amd.presets import hyperprior_codec, seed_synthetic_weights
+    codec = seed_synthetic_weights(hyperprior_codec(), seed=0).eval()
+    cpu_state = {k: v.clone() for k, v in codec.entropy_coder.state_dict().items()}
+    codec = codec.to(dev)
+    codec.update_state()
+
+    # per-rank shard of the synthetic set: image i = torch.manual_seed(i); torch.rand(3,S,S)
+    # (configs/datasets/images/random_image_generator.py:12-15); rank r owns ids r*batch .. (r+1)*batch-1
+    g = torch.Generator().manual_seed(1234 + rank)
+    x = torch.rand(args.batch, 3, args.size, args.size, generator=g).to(dev)
+
+    def step():
+        data = codec.compress(x)
+        xhat = codec.decompress(data)
+        return data, xhat
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.time()
+    nbytes = 0
+    for _ in range(args.steps):
+        data, xhat = step()
+        nbytes += len(data)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.time() - t0
+
+    from cbench_basic_amd.nn import kernels as K
+    mse = K.mse_per_image(xhat, x)
+    psnr_sum = float((-10 * torch.log10(mse.double())).sum())
+    stats = torch.tensor([dt, float(args.batch * args.steps), float(nbytes), psnr_sum, float(args.batch)], device=dev,
+                         dtype=torch.float64)
+    if dist is not None:
+        tmax = stats[:1].clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+        stats[0] = tmax[0]
+    dt_max, n_img, n_bytes, psnr_tot, n_psnr = [float(v) for v in stats.cpu()]
+
+    if rank == 0:
+        pix = n_img * args.size * args.size
+        enc_f, dec_f = conv_flops_per_image(codec, args.size)
+        conv_s, launches = measure_conv_kernels(codec, x)
+        flops_pass = (enc_f + dec_f) * args.batch
+        achieved = flops_pass / conv_s / 1e12
+        out = dict(
+            metric="encode+decode Mpix/s", value=pix / dt_max / 1e6, unit="Mpix/s", n_gpus=world, steps=args.steps,
+            warmup=args.warmup, ms_per_step=dt_max / args.steps * 1e3, higher_is_better=True, scaling="weak",
+            vs_baseline=None, dtype="f32", data="synthetic",
+            config=dict(workload=f"hyperprior codec N=128 M=192 (lossy_graph_scalable_exp_hp), synthetic 3x{args.size}x{args.size}, "
+                                 f"{args.batch} images per GPU per step, compress+decompress incl. bytes D2H/H2D",
+                        images_per_gpu=args.batch, bpp=n_bytes * 8 / pix, psnr_db=psnr_tot / n_psnr,
+                        parallelism=f"image-sharded x{world}, RCCL all-reduce of metric sums only"),
+            roofline=dict(bound="mfma", achieved=achieved, peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
+                          frac=achieved / PEAK_FP32_MFMA_TFLOPS, traffic=None,
+                          kernel="conv_tap_mfma_kernel<MT> (all transform launches of one encode+decode pass)",
+                          flops_per_launch=flops_pass / launches, launches_per_pass=launches,
+                          avg_launch_ms=conv_s / launches * 1e3, pass_ms=conv_s * 1e3),
+        )
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cpu_state, args.cpu_images, args.size)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -24,6 +24,7 @@
 //     so LDS bandwidth is irrelevant here; the kernel is MFMA-issue bound by design.
 #include "common.h"
 
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -33,11 +34,15 @@ using namespace basic;
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kCK = 4;        // input channels per LDS stage (2 MFMA k-pairs)
+constexpr int kCKConv = 4;    // input channels per LDS stage for many-tap layers (5x5 conv: 25 taps)
+constexpr int kCKFew = 8;     // ... and for few-tap launches (3x3 conv, sub-pixel phases of the 5x5 deconv: <= 9 taps)
+constexpr int kFewTaps = 9;
 constexpr int kMaxTaps = 25;  // 5x5
 constexpr int kThreads = 256;
 constexpr int kTilePos = 128;  // output positions per workgroup
+constexpr int kPSlots = 12;             // patch elements per thread (patch <= 3072 floats)
 constexpr int kMaxCoutPerLaunch = 192;  // 6 accumulator tiles per wave
 
 struct TapLaunch {
@@ -56,6 +61,7 @@ struct TapLaunch {
     int tb_log, th_log, tw_log;  // tile = 2^tb images x 2^th x 2^tw positions (product 128)
     int ph, pw, pwp;             // LDS patch rows / cols / padded cols
     int act;
+    int debug;  // ablation switches for profiling only (BASIC_CONV_DEBUG): 1 = skip staging, 2 = skip MFMA loop
     int tiles_y, tiles_x;
     signed char dy[kMaxTaps], dx[kMaxTaps];  // relative to (dymin, dxmin)
 };
@@ -67,8 +73,8 @@ __device__ __forceinline__ float apply_act(float v, int act)
     return v;
 }
 
-template <int MT>
-__global__ __launch_bounds__(kThreads) void conv_tap_mfma_kernel(const TapLaunch g)
+template <int MT, int kCK>
+__global__ __launch_bounds__(kThreads, (MT <= 4 ? 2 : 1)) void conv_tap_mfma_kernel(const TapLaunch g)
 {
     extern __shared__ float lds[];
     const int wl_floats = g.ntaps * kCK * g.coutp;
@@ -91,7 +97,9 @@ __global__ __launch_bounds__(kThreads) void conv_tap_mfma_kernel(const TapLaunch
     const int q = wave * 32 + col;
     const int tx = q & (TW - 1);
     const int ty = (q >> g.tw_log) & (TH - 1);
-    const int tb = q >> (g.tw_log + g.th_log);
+    const int tb_raw = q >> (g.tw_log + g.th_log);
+    const bool lane_live = tb_raw < TB;         // tiles of tiny maps may hold fewer than 128 positions
+    const int tb = lane_live ? tb_raw : 0;
 
     const int chan_stride = g.ph * g.pwp;
     const int lane_b_base = ((tb * kCK + khalf) * g.ph + ty * g.s_in) * g.pwp + tx * g.s_in;
@@ -109,53 +117,100 @@ __global__ __launch_bounds__(kThreads) void conv_tap_mfma_kernel(const TapLaunch
     const int64_t in_img = static_cast<int64_t>(g.cin) * in_plane;
     const float *in_b0 = g.in + static_cast<int64_t>(b0) * in_img;
 
-    // Gather table, built once per workgroup: for every patch element its global offset (relative to
-    // image b0, channel 0 of the stage) packed with the in-stage channel, or -1 for zero fill.
-    int *gtab = reinterpret_cast<int *>(patch + patch_elems);
-    for (int i = tid; i < patch_elems; i += kThreads) {
-        int r = i;
-        const int px = r % g.pwp; r /= g.pwp;
-        const int py = r % g.ph; r /= g.ph;
-        const int ci = r % kCK;
-        const int pb = r / kCK;
-        const int gy = gy0 + py, gx = gx0 + px;
+    // Per-thread gather descriptors, computed once: patch element i = tid + 256*s reads the global
+    // offset ge[s] >> 2 (relative to image b0, first channel of the stage) of in-stage channel
+    // ge[s] & 3, or is zero-filled when ge[s] < 0.  They live in registers so that each stage's
+    // global loads are independent and can be issued back to back, one stage AHEAD of the MFMAs.
+    int *tapoff = reinterpret_cast<int *>(patch + patch_elems);  // [ntaps] LDS offsets of the taps
+    if (tid < g.ntaps) tapoff[tid] = g.dy[tid] * g.pwp + g.dx[tid];
+    int ge[kPSlots];
+#pragma unroll
+    for (int sl = 0; sl < kPSlots; ++sl) {
+        int r = tid + sl * kThreads;
         int e = -1;
-        if (px < g.pw && gy >= 0 && gy < g.in_h && gx >= 0 && gx < g.in_w && b0 + pb < g.batch)
-            e = ((pb * static_cast<int>(in_img) + gy * g.in_w + gx) << 2) | ci;
-        gtab[i] = e;
+        if (r < patch_elems) {
+            const int px = r % g.pwp; r /= g.pwp;
+            const int py = r % g.ph; r /= g.ph;
+            const int ci = r % kCK;
+            const int pb = r / kCK;
+            const int gy = gy0 + py, gx = gx0 + px;
+            if (px < g.pw && gy >= 0 && gy < g.in_h && gx >= 0 && gx < g.in_w && b0 + pb < g.batch)
+                e = ((pb * static_cast<int>(in_img) + gy * g.in_w + gx) << 4) | ci;
+        }
+        ge[sl] = e;
     }
 
+    constexpr int kStageTaps = (kCK == kCKConv) ? kMaxTaps : kFewTaps;
+    constexpr int kWSlots = (kStageTaps * kCK * 32 * MT / 4 + kThreads - 1) / kThreads;
+    f32x4 wreg[kWSlots];
+    float preg[kPSlots];
+    const int wl_vec = wl_floats / 4;
+
+#define BASIC_FETCH_STAGE(C0)                                                                                   \
+    do {                                                                                                       \
+        const f32x4 *src_ = reinterpret_cast<const f32x4 *>(g.wpack + static_cast<int64_t>((C0) / kCK) * wl_floats); \
+        _Pragma("unroll") for (int sl = 0; sl < kWSlots; ++sl) {                                               \
+            const int i_ = tid + sl * kThreads;                                                                \
+            if (i_ < wl_vec) wreg[sl] = src_[i_];                                                              \
+        }                                                                                                      \
+        const float *in_c0_ = in_b0 + static_cast<int64_t>(C0) * in_plane;                                     \
+        _Pragma("unroll") for (int sl = 0; sl < kPSlots; ++sl) {                                               \
+            const int e_ = ge[sl];                                                                             \
+            float v_ = 0.f;                                                                                    \
+            if (e_ >= 0 && (C0) + (e_ & (kCK - 1)) < g.cin) v_ = in_c0_[(e_ >> 4) + (e_ & (kCK - 1)) * in_plane];              \
+            preg[sl] = v_;                                                                                     \
+        }                                                                                                      \
+    } while (0)
+#define BASIC_COMMIT_STAGE()                                                                                   \
+    do {                                                                                                       \
+        f32x4 *dst_ = reinterpret_cast<f32x4 *>(wl);                                                           \
+        _Pragma("unroll") for (int sl = 0; sl < kWSlots; ++sl) {                                               \
+            const int i_ = tid + sl * kThreads;                                                                \
+            if (i_ < wl_vec) dst_[i_] = wreg[sl];                                                              \
+        }                                                                                                      \
+        _Pragma("unroll") for (int sl = 0; sl < kPSlots; ++sl) {                                               \
+            const int i_ = tid + sl * kThreads;                                                                \
+            if (i_ < patch_elems) patch[i_] = preg[sl];                                                        \
+        }                                                                                                      \
+    } while (0)
+
+    if (g.cin_pad > 0 && !(g.debug & 1)) BASIC_FETCH_STAGE(0);
     for (int c0 = 0; c0 < g.cin_pad; c0 += kCK) {
+        __syncthreads();  // every wave is done reading the previous stage
+        if (!(g.debug & 1)) BASIC_COMMIT_STAGE();
         __syncthreads();
-        // ---- stage the weight slab (contiguous, 16 B per lane)
-        {
-            const float4 *src = reinterpret_cast<const float4 *>(g.wpack + static_cast<int64_t>(c0 / kCK) * wl_floats);
-            float4 *dst = reinterpret_cast<float4 *>(wl);
-            for (int i = tid; i < wl_floats / 4; i += kThreads) dst[i] = src[i];
-        }
-        // ---- stage the input patch (zero fill outside the image / channel range)
-        {
-            const float *in_c0 = in_b0 + static_cast<int64_t>(c0) * in_plane;
-            for (int i = tid; i < patch_elems; i += kThreads) {
-                const int e = gtab[i];
-                float v = 0.f;
-                if (e >= 0 && c0 + (e & 3) < g.cin) v = in_c0[(e >> 2) + (e & 3) * in_plane];
-                patch[i] = v;
-            }
-        }
-        __syncthreads();
-        // ---- MFMA over taps x channel pairs
-        for (int t = 0; t < g.ntaps; ++t) {
-            const int tap_off = g.dy[t] * g.pwp + g.dx[t];
-            const float *wt = wl + t * kCK * g.coutp + lane_a_base;
+        if (c0 + kCK < g.cin_pad && !(g.debug & 1)) BASIC_FETCH_STAGE(c0 + kCK);  // in flight during the MFMAs below
+        // ---- MFMA over (tap, channel pair) steps.  The fragment reads of the next step are issued
+        // before the MFMAs of the current one, on two alternating register sets (no copies, so the
+        // compiler's counted lgkmcnt waits keep the next step's reads in flight while the matrix
+        // core works); sched_barriers pin that order against the machine scheduler.
+        if (!(g.debug & 2)) {
+            constexpr int kPairs = kCK / 2;  // even: the two register sets alternate statically
+            float fa[2][MT], fb[2];
+            int toff = tapoff[0];
+            fb[0] = patch[lane_b_base + toff];
 #pragma unroll
-            for (int cp = 0; cp < kCK / 2; ++cp) {
-                const float bfrag = patch[lane_b_base + tap_off + cp * 2 * chan_stride];
+            for (int m = 0; m < MT; ++m) fa[0][m] = wl[lane_a_base + m * 32];
+            for (int t = 0; t < g.ntaps; ++t) {
+                const int tn = (t + 1 < g.ntaps) ? t + 1 : t;
+                const int toff_n = tapoff[tn];
 #pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    const float afrag = wt[cp * 2 * g.coutp + m * 32];
-                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(afrag, bfrag, acc[m], 0, 0, 0);
+                for (int cp = 0; cp < kPairs; ++cp) {
+                    const int cur = cp & 1, nxt = cur ^ 1;
+                    // next step: (t, cp+1) or (t+1, 0); at the very end a harmless re-read
+                    const bool wrap = (cp + 1 == kPairs);
+                    const int nt = wrap ? tn : t, ncp = wrap ? 0 : cp + 1;
+                    fb[nxt] = patch[lane_b_base + (wrap ? toff_n : toff) + ncp * 2 * chan_stride];
+                    const float *wn = wl + (nt * kCK + ncp * 2) * g.coutp + lane_a_base;
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) fa[nxt][m] = wn[m * 32];
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+                        acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][m], fb[cur], acc[m], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
+                toff = toff_n;
             }
         }
     }
@@ -207,7 +262,7 @@ __global__ __launch_bounds__(kThreads) void conv_tap_mfma_kernel(const TapLaunch
 
     // ---- store
     const int my = my0 + ty, mx = mx0 + tx, b = b0 + tb;
-    if (my < g.mh && mx < g.mw && b < g.batch) {
+    if (lane_live && my < g.mh && mx < g.mw && b < g.batch) {
         const int oy = my * g.s_out + g.oy0, ox = mx * g.s_out + g.ox0;
         const int64_t plane = static_cast<int64_t>(g.out_h) * g.out_w;
         float *o = g.out + (static_cast<int64_t>(b) * g.out_ctotal + g.co_base) * plane + static_cast<int64_t>(oy) * g.out_w + ox;
@@ -221,9 +276,102 @@ __global__ __launch_bounds__(kThreads) void conv_tap_mfma_kernel(const TapLaunch
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Last synthesis layer (ConvTranspose2d 5x5, stride 2, pad 2, output_padding 1, Cout <= 4):
+// three output channels would waste 29/32 of every MFMA tile, and on gfx950 the fp32 matrix rate
+// equals the fp32 vector rate anyway, so this layer runs on the VALU.  One lane owns one INPUT
+// position and produces its 2x2 output pixels x Cout: per input channel 9 LDS reads (the 3x3
+// neighbourhood) feed all 25 taps x Cout FMAs, with the weights as wave-uniform scalar operands.
+// ---------------------------------------------------------------------------------------------
+constexpr int kSmTile = 16;               // 16 x 16 input positions per workgroup
+constexpr int kSmCK = 16;                 // input channels per LDS stage
+constexpr int kSmPatch = kSmTile + 2;     // +-1 halo
+
+struct SmallLaunch {
+    const float *in;      // [B][cin][H][W]
+    float *out;           // [B][cout][2H][2W]
+    const float *wsm;     // [cin][25][4]   W[ci][co][ky][kx] -> [ci][ky*5+kx][co], zero padded to 4
+    const float *bias;    // [4]
+    int batch, cin, cout, in_h, in_w, tiles_y, tiles_x, act;
+};
+
+template <int COUT>
+__global__ __launch_bounds__(256) void deconv5s2_small_cout_kernel(const SmallLaunch g)
+{
+    __shared__ float patch[kSmCK][kSmPatch][kSmPatch + 1];
+    const int tid = threadIdx.x;
+    int bid = blockIdx.x;
+    const int tx_i = bid % g.tiles_x; bid /= g.tiles_x;
+    const int ty_i = bid % g.tiles_y; bid /= g.tiles_y;
+    const int b = bid;
+    const int lx = tid & (kSmTile - 1), ly = tid >> 4;
+    const int my = ty_i * kSmTile + ly, mx = tx_i * kSmTile + lx;
+    const int64_t plane = static_cast<int64_t>(g.in_h) * g.in_w;
+    const float *inb = g.in + static_cast<int64_t>(b) * g.cin * plane;
+
+    float acc[2][2][COUT];
+#pragma unroll
+    for (int py = 0; py < 2; ++py)
+#pragma unroll
+        for (int px = 0; px < 2; ++px)
+#pragma unroll
+            for (int co = 0; co < COUT; ++co) acc[py][px][co] = 0.f;
+
+    for (int c0 = 0; c0 < g.cin; c0 += kSmCK) {
+        __syncthreads();
+        for (int i = tid; i < kSmCK * kSmPatch * kSmPatch; i += 256) {
+            const int px = i % kSmPatch, r = i / kSmPatch;
+            const int py = r % kSmPatch, ci = r / kSmPatch;
+            const int gy = ty_i * kSmTile - 1 + py, gx = tx_i * kSmTile - 1 + px, c = c0 + ci;
+            float v = 0.f;
+            if (gy >= 0 && gy < g.in_h && gx >= 0 && gx < g.in_w && c < g.cin) v = inb[c * plane + gy * g.in_w + gx];
+            patch[ci][py][px] = v;
+        }
+        __syncthreads();
+        const int cmax = (g.cin - c0 < kSmCK) ? g.cin - c0 : kSmCK;
+        for (int ci = 0; ci < cmax; ++ci) {
+            float v[3][3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) v[a][c] = patch[ci][ly + a][lx + c];
+            const float *w = g.wsm + static_cast<int64_t>(c0 + ci) * 100;  // wave-uniform -> scalar loads
+#pragma unroll
+            for (int ky = 0; ky < 5; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 5; ++kx) {
+                    // output row 2*my + py receives input row my + dy through ky = py + 2 - 2*dy
+                    const int py = ky & 1, px = kx & 1;
+                    const int dy = (py + 2 - ky) / 2, dx = (px + 2 - kx) / 2;  // in {-1, 0, 1}
+                    const float x = v[dy + 1][dx + 1];
+#pragma unroll
+                    for (int co = 0; co < COUT; ++co)
+                        acc[py][px][co] = fmaf(x, w[(ky * 5 + kx) * 4 + co], acc[py][px][co]);
+                }
+        }
+    }
+    if (my < g.in_h && mx < g.in_w) {
+        const int oh = 2 * g.in_h, ow = 2 * g.in_w;
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) {
+            if (co >= g.cout) break;
+            const float bv = g.bias[co];
+            float *o = g.out + (static_cast<int64_t>(b) * g.cout + co) * oh * ow + static_cast<int64_t>(2 * my) * ow + 2 * mx;
+#pragma unroll
+            for (int py = 0; py < 2; ++py) {
+                float2 r;
+                r.x = apply_act(acc[py][0][co] + bv, g.act);
+                r.y = apply_act(acc[py][1][co] + bv, g.act);
+                *reinterpret_cast<float2 *>(o + py * ow) = r;
+            }
+        }
+    }
+}
+
 struct Phase {
     int ntaps = 0, dymin = 0, dxmin = 0, span_y = 1, span_x = 1;
     int oy0 = 0, ox0 = 0;
+    int ck = kCKConv, cin_pad = 0;  // channels per LDS stage of this launch, cin rounded up to it
     signed char dy[kMaxTaps], dx[kMaxTaps];
     float *d_wpack = nullptr;
 };
@@ -238,10 +386,10 @@ struct Chunk {  // <= 192 output channels handled by one launch family
 
 struct basic_conv_plan {
     int cin = 0, cout = 0, ksize = 0, stride = 1, padding = 0, output_padding = 0, transposed = 0, act = 0;
-    int cin_pad = 0;
     int s_in = 1, s_out = 1;
     std::vector<Chunk> chunks;
     float *d_gammaT = nullptr, *d_beta = nullptr;
+    float *d_wsm = nullptr, *d_bias4 = nullptr;  // VALU path of the Cout <= 4 synthesis output layer
 };
 
 extern "C" void basic_conv_plan_destroy(basic_conv_plan *p)
@@ -252,6 +400,8 @@ extern "C" void basic_conv_plan_destroy(basic_conv_plan *p)
             if (ph.d_wpack) (void)hipFree(ph.d_wpack);
         if (ch.d_bias) (void)hipFree(ch.d_bias);
     }
+    if (p->d_wsm) (void)hipFree(p->d_wsm);
+    if (p->d_bias4) (void)hipFree(p->d_bias4);
     if (p->d_gammaT) (void)hipFree(p->d_gammaT);
     if (p->d_beta) (void)hipFree(p->d_beta);
     delete p;
@@ -289,9 +439,22 @@ extern "C" int basic_conv_plan_create(const float *weight, const float *bias, in
     const int ci_n = cin_active, co_n = cout_active;
     p->cin = ci_n; p->cout = co_n; p->ksize = ksize; p->stride = stride; p->padding = padding;
     p->output_padding = output_padding; p->transposed = transposed ? 1 : 0; p->act = activation;
-    p->cin_pad = (ci_n + kCK - 1) / kCK * kCK;
     p->s_in = transposed ? 1 : stride;
     p->s_out = transposed ? stride : 1;
+
+    if (transposed && ksize == 5 && stride == 2 && padding == 2 && output_padding == 1 && co_n <= 4 && !gdn) {
+        std::vector<float> ws(static_cast<size_t>(ci_n) * 100, 0.f), b4(4, 0.f);
+        for (int c = 0; c < ci_n; ++c)
+            for (int o = 0; o < co_n; ++o)
+                for (int t = 0; t < 25; ++t)
+                    ws[(static_cast<size_t>(c) * 25 + t) * 4 + o] = weight[(static_cast<size_t>(c) * cout + o) * 25 + t];
+        if (bias) std::memcpy(b4.data(), bias, sizeof(float) * co_n);
+        rc = upload(ws, &p->d_wsm);
+        if (!rc) rc = upload(b4, &p->d_bias4);
+        if (rc) { basic_conv_plan_destroy(p); return rc; }
+        *out = p;
+        return BASIC_OK;
+    }
 
     const int nph = transposed ? stride : 1;
     const int n_chunks = (co_n + kMaxCoutPerLaunch - 1) / kMaxCoutPerLaunch;
@@ -333,7 +496,10 @@ extern "C" int basic_conv_plan_create(const float *weight, const float *bias, in
                         ++ph.ntaps;
                     }
                 // ---- pack weights: [cin_pad/CK][ntaps][CK][coutp]
-                std::vector<float> wp(static_cast<size_t>(p->cin_pad) * ph.ntaps * ch.coutp, 0.f);
+                const int kCK = ph.ntaps <= kFewTaps ? kCKFew : kCKConv;
+                ph.ck = kCK;
+                ph.cin_pad = (ci_n + kCK - 1) / kCK * kCK;
+                std::vector<float> wp(static_cast<size_t>(ph.cin_pad) * ph.ntaps * ch.coutp, 0.f);
                 for (int c = 0; c < ci_n; ++c)
                     for (int t = 0; t < ph.ntaps; ++t)
                         for (int o = 0; o < ch.cout; ++o) {
@@ -401,18 +567,24 @@ extern "C" int64_t basic_conv_plan_flops(const basic_conv_plan *p, int batch, in
 
 namespace {
 
-template <int MT>
-int launch_mt(const TapLaunch &g, int blocks, size_t lds_bytes, hipStream_t st)
+template <int MT, int CK>
+int launch_one(const TapLaunch &g, int blocks, size_t lds_bytes, hipStream_t st)
 {
     static bool attr_set = false;
     if (!attr_set) {
-        BASIC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_tap_mfma_kernel<MT>),
+        BASIC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_tap_mfma_kernel<MT, CK>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL(conv_tap_mfma_kernel<MT>, dim3(blocks), dim3(kThreads), lds_bytes, st, g);
+    hipLaunchKernelGGL((conv_tap_mfma_kernel<MT, CK>), dim3(blocks), dim3(kThreads), lds_bytes, st, g);
     BASIC_HIP_TRY(hipGetLastError());
     return BASIC_OK;
+}
+
+template <int MT>
+int launch_mt(const TapLaunch &g, int ck, int blocks, size_t lds_bytes, hipStream_t st)
+{
+    return ck == kCKFew ? launch_one<MT, kCKFew>(g, blocks, lds_bytes, st) : launch_one<MT, kCKConv>(g, blocks, lds_bytes, st);
 }
 
 int ilog2(int v) { int l = 0; while ((1 << (l + 1)) <= v) ++l; return l; }
@@ -427,11 +599,25 @@ extern "C" int basic_conv_forward_dev(const basic_conv_plan *p, const float *d_i
     int oh = 0, ow = 0;
     int rc = basic_conv_plan_out_hw(p, in_h, in_w, &oh, &ow);
     if (rc) return rc;
+    if (p->d_wsm) {
+        SmallLaunch g{};
+        g.in = d_in; g.out = d_out; g.wsm = p->d_wsm; g.bias = p->d_bias4;
+        g.batch = batch; g.cin = p->cin; g.cout = p->cout; g.in_h = in_h; g.in_w = in_w; g.act = p->act;
+        g.tiles_y = (in_h + kSmTile - 1) / kSmTile;
+        g.tiles_x = (in_w + kSmTile - 1) / kSmTile;
+        const int blocks = batch * g.tiles_y * g.tiles_x;
+        if (p->cout <= 3)
+            hipLaunchKernelGGL(deconv5s2_small_cout_kernel<3>, dim3(blocks), dim3(256), 0, as_stream(hip_stream), g);
+        else
+            hipLaunchKernelGGL(deconv5s2_small_cout_kernel<4>, dim3(blocks), dim3(256), 0, as_stream(hip_stream), g);
+        BASIC_HIP_TRY(hipGetLastError());
+        return BASIC_OK;
+    }
     for (const Chunk &ch : p->chunks)
     for (const Phase &ph : ch.phases) {
         TapLaunch g{};
         g.in = d_in; g.out = d_out; g.wpack = ph.d_wpack; g.bias = ch.d_bias; g.gammaT = p->d_gammaT; g.beta = p->d_beta;
-        g.batch = batch; g.cin = p->cin; g.cin_pad = ph.ntaps ? p->cin_pad : 0; g.cout = ch.cout; g.coutp = ch.coutp; g.out_ctotal = p->cout; g.co_base = ch.co0;
+        g.batch = batch; g.cin = p->cin; g.cin_pad = ph.ntaps ? ph.cin_pad : 0; g.cout = ch.cout; g.coutp = ch.coutp; g.out_ctotal = p->cout; g.co_base = ch.co0;
         g.in_h = in_h; g.in_w = in_w; g.out_h = oh; g.out_w = ow;
         g.s_in = p->s_in; g.s_out = p->s_out; g.oy0 = ph.oy0; g.ox0 = ph.ox0;
         g.mh = (oh - ph.oy0 + p->s_out - 1) / p->s_out;
@@ -441,30 +627,34 @@ extern "C" int basic_conv_forward_dev(const basic_conv_plan *p, const float *d_i
         std::memcpy(g.dy, ph.dy, sizeof(g.dy));
         std::memcpy(g.dx, ph.dx, sizeof(g.dx));
         g.act = p->act;
+        const int kCK = ph.ck;
+        { const char *e = getenv("BASIC_CONV_DEBUG"); g.debug = e ? atoi(e) : 0; }
         // tile shape: 128 positions = TB images x TH x TW, powers of two, preferring wide rows
         int tw = pow2_ceil(g.mw); if (tw > 16) tw = 16;
         int th = pow2_ceil(g.mh); if (th > kTilePos / tw) th = kTilePos / tw;
         int tb = kTilePos / (tw * th);
-        g.tw_log = ilog2(tw); g.th_log = ilog2(th); g.tb_log = ilog2(tb);
         g.ph = (th - 1) * g.s_in + ph.span_y;
         g.pw = (tw - 1) * g.s_in + ph.span_x;
         g.pwp = g.pw | 1;  // odd row pitch
+        while (tb > 1 && tb * kCK * g.ph * g.pwp > kPSlots * kThreads) tb >>= 1;  // patch must fit the staging registers
+        g.tw_log = ilog2(tw); g.th_log = ilog2(th); g.tb_log = ilog2(tb);
         g.tiles_y = (g.mh + th - 1) / th;
         g.tiles_x = (g.mw + tw - 1) / tw;
         const int blocks = ((batch + tb - 1) / tb) * g.tiles_y * g.tiles_x;
         const int wl_floats = g.ntaps * kCK * g.coutp, gam_floats = 32 * g.coutp;
         const size_t lds_bytes = sizeof(float) * (static_cast<size_t>(wl_floats > gam_floats ? wl_floats : gam_floats) +
-                                                 2 * static_cast<size_t>(tb) * kCK * g.ph * g.pwp);
+                                                 static_cast<size_t>(tb) * kCK * g.ph * g.pwp + kMaxTaps);
+        BASIC_REQUIRE(tb * kCK * g.ph * g.pwp <= kPSlots * kThreads, "conv_forward: input patch exceeds the staging registers");
         BASIC_REQUIRE(static_cast<int64_t>(tb) * p->cin * in_h * in_w < (1ll << 29), "conv_forward: input tile too large");
         BASIC_REQUIRE(lds_bytes <= 160 * 1024, "conv_forward: LDS budget exceeded");
         hipStream_t st = as_stream(hip_stream);
         switch (ch.mt) {
-            case 1: rc = launch_mt<1>(g, blocks, lds_bytes, st); break;
-            case 2: rc = launch_mt<2>(g, blocks, lds_bytes, st); break;
-            case 3: rc = launch_mt<3>(g, blocks, lds_bytes, st); break;
-            case 4: rc = launch_mt<4>(g, blocks, lds_bytes, st); break;
-            case 5: rc = launch_mt<5>(g, blocks, lds_bytes, st); break;
-            case 6: rc = launch_mt<6>(g, blocks, lds_bytes, st); break;
+            case 1: rc = launch_mt<1>(g, kCK, blocks, lds_bytes, st); break;
+            case 2: rc = launch_mt<2>(g, kCK, blocks, lds_bytes, st); break;
+            case 3: rc = launch_mt<3>(g, kCK, blocks, lds_bytes, st); break;
+            case 4: rc = launch_mt<4>(g, kCK, blocks, lds_bytes, st); break;
+            case 5: rc = launch_mt<5>(g, kCK, blocks, lds_bytes, st); break;
+            case 6: rc = launch_mt<6>(g, kCK, blocks, lds_bytes, st); break;
             default: set_error("conv_forward: cout > 192 unsupported"); rc = BASIC_ERR_INVALID;
         }
         if (rc) return rc;

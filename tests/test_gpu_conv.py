@@ -39,6 +39,9 @@ CASES = [
     (5, 7, 3, 1, 1, 0, False, "none", 1, 5, 7),       # ragged everything
     (48, 48, 5, 2, 2, 0, False, "gdn", 1, 18, 22),     # slimmable width, odd sizes
     (72, 96, 5, 2, 2, 1, True, "igdn", 1, 7, 9),
+    (20, 3, 5, 2, 2, 1, True, "none", 2, 9, 13),       # VALU small-Cout path, ragged tile
+    (37, 4, 5, 2, 2, 1, True, "relu", 1, 33, 17),
+    (128, 1, 5, 2, 2, 1, True, "leaky", 1, 16, 16),
 ]
 
 
