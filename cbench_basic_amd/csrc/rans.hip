@@ -32,6 +32,12 @@ struct basic_rans_tables {
     int ar_k = 0, ar_rows = 0, ar_order = 0, ar_s1 = 0;
     std::vector<int32_t> ar;
     int32_t *d_ar = nullptr;
+    // Packed copy for the LDS-resident decoder: rows back to back as uint16 (the final entry 2^precision
+    // does not fit 16 bits when precision == 16; it is implied by its position), row r at base[r].
+    std::vector<uint16_t> cdf16;
+    std::vector<int32_t> base;
+    uint16_t *d_cdf16 = nullptr;
+    int32_t *d_base = nullptr;
 };
 
 namespace {
@@ -80,6 +86,17 @@ int upload_tables(basic_rans_tables *t)
     BASIC_HIP_TRY(hipMemcpy(t->d_cdfs, t->cdfs.data(), t->cdfs.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     BASIC_HIP_TRY(hipMemcpy(t->d_sizes, t->sizes.data(), t->sizes.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     BASIC_HIP_TRY(hipMemcpy(t->d_offsets, t->offsets.data(), t->offsets.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    t->base.resize(t->rows);
+    t->cdf16.clear();
+    for (int r = 0; r < t->rows; ++r) {
+        t->base[r] = static_cast<int32_t>(t->cdf16.size());
+        for (int j = 0; j < t->sizes[r]; ++j) t->cdf16.push_back(static_cast<uint16_t>(t->cdfs[static_cast<size_t>(r) * t->stride + j]));
+    }
+    if (t->cdf16.size() & 1) t->cdf16.push_back(0);  // whole 32-bit words for the LDS copy
+    BASIC_HIP_TRY(hipMalloc(&t->d_cdf16, t->cdf16.size() * sizeof(uint16_t)));
+    BASIC_HIP_TRY(hipMalloc(&t->d_base, t->base.size() * sizeof(int32_t)));
+    BASIC_HIP_TRY(hipMemcpy(t->d_cdf16, t->cdf16.data(), t->cdf16.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    BASIC_HIP_TRY(hipMemcpy(t->d_base, t->base.data(), t->base.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     return BASIC_OK;
 }
 
@@ -214,6 +231,8 @@ extern "C" void basic_rans_tables_destroy(basic_rans_tables *t)
     if (t->d_sizes) (void)hipFree(t->d_sizes);
     if (t->d_offsets) (void)hipFree(t->d_offsets);
     if (t->d_ar) (void)hipFree(t->d_ar);
+    if (t->d_cdf16) (void)hipFree(t->d_cdf16);
+    if (t->d_base) (void)hipFree(t->d_base);
     delete t;
 }
 
@@ -227,6 +246,9 @@ constexpr uint64_t kRansL = 1ull << 31;
 struct TablesDev {
     const int32_t *cdfs, *sizes, *offsets;
     int rows, stride, precision, bypass, bypass_precision;
+    const uint16_t *cdf16;  // packed rows (see basic_rans_tables)
+    const int32_t *base;
+    int total16;            // entries in cdf16 (even)
 };
 
 struct ArDev {
@@ -418,19 +440,26 @@ __device__ __forceinline__ uint32_t get_raw(uint64_t &x, WordReader &rd, int lan
 
 // One wavefront per stream; the CDF search of each symbol is a 64-ary search over the row
 // (one probe per lane, one ballot per level), everything else is scalar.
-template <bool AR>
+template <bool AR, bool LDS>
 __global__ __launch_bounds__(64) void rans_decode_kernel(TablesDev T, ArDev ar, const uint32_t *__restrict__ words_all,
                                                          const int64_t *__restrict__ word_off,
                                                          const int32_t *__restrict__ indexes,
                                                          const int64_t *__restrict__ seg, int32_t *out_symbols,
                                                          uint64_t *state, int64_t *pos_io)
 {
+    extern __shared__ uint32_t lds_words[];
+    const uint16_t *lds16 = reinterpret_cast<const uint16_t *>(lds_words);
     const int stream = blockIdx.x;
     const int lane = threadIdx.x;
     const int64_t beg = seg[stream];
     const int64_t n = seg[stream + 1] - beg;
     const int32_t *idx = indexes + beg;
     int32_t *out = out_symbols + beg;
+    if (LDS) {  // whole table set resident in LDS: the serial search never leaves the CU
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(T.cdf16);
+        for (int i = lane; i < T.total16 / 2; i += 64) lds_words[i] = src[i];
+        __syncthreads();
+    }
 
     WordReader rd;
     rd.words = words_all + word_off[stream];
@@ -455,10 +484,10 @@ __global__ __launch_bounds__(64) void rans_decode_kernel(TablesDev T, ArDev ar, 
 
     for (int64_t c0 = 0; c0 < n; c0 += 64) {
         const int64_t i = c0 + lane;
-        int32_t row_l = 0, size_l = 2, off_l = 0;
+        int32_t row_l = 0, size_l = 2, off_l = 0, base_l = 0;
         if (i < n) {
             row_l = AR ? idx[i] : clampi(idx[i], 0, T.rows - 1);
-            if (!AR) { size_l = T.sizes[row_l]; off_l = T.offsets[row_l]; }
+            if (!AR) { size_l = T.sizes[row_l]; off_l = T.offsets[row_l]; if (LDS) base_l = T.base[row_l]; }
         }
         int32_t result = 0;
         const int cnt = (n - c0) < 64 ? static_cast<int>(n - c0) : 64;
@@ -487,6 +516,13 @@ __global__ __launch_bounds__(64) void rans_decode_kernel(TablesDev T, ArDev ar, 
                 offset = static_cast<int32_t>(bcast_u32(static_cast<uint32_t>(off_l), j));
             }
             const int32_t *cdf = T.cdfs + static_cast<int64_t>(row) * T.stride;
+            int32_t rbase = 0;
+            if (LDS) rbase = AR ? __builtin_amdgcn_readfirstlane(T.base[row]) : static_cast<int32_t>(bcast_u32(static_cast<uint32_t>(base_l), j));
+            // entry e of the current row (the last entry, 2^precision, is implied in the packed copy)
+            auto entry = [&](int32_t e) -> int32_t {
+                if (!LDS) return cdf[e];
+                return (e == size - 1) ? (1 << prec) : static_cast<int32_t>(lds16[rbase + e]);
+            };
             const uint32_t cf = static_cast<uint32_t>(x) & mask;
 
             // find t = first entry with cdf[t] > cf (t >= 1 because cdf[0] = 0); s = t - 1.
@@ -497,7 +533,7 @@ __global__ __launch_bounds__(64) void rans_decode_kernel(TablesDev T, ArDev ar, 
                 int32_t pi = lo + (lane + 1) * step - 1;
                 const bool in = pi < lo + span;
                 if (!in) pi = lo + span - 1;
-                const int32_t v = cdf[pi];
+                const int32_t v = entry(pi);
                 const uint64_t m = __ballot(static_cast<uint32_t>(v) > cf);
                 const int blk = __builtin_ctzll(m);  // m != 0: the final entry 2^prec > cf
                 const int32_t nlo = lo + blk * step;
@@ -508,13 +544,13 @@ __global__ __launch_bounds__(64) void rans_decode_kernel(TablesDev T, ArDev ar, 
             // fine level: lanes cover entries lo-1 .. lo+span-1 (span+1 <= 65 -> lane 0 is entry lo-1
             // only when lo > 0; entry lo+span-1 by lane span).  Use two registers to stay within 64.
             const int32_t e0 = lo + lane;  // entry index for register A
-            int32_t va = (lane < span) ? cdf[e0] : 0x7FFFFFFF;
+            int32_t va = (lane < span) ? entry(e0) : 0x7FFFFFFF;
             const uint64_t m = __ballot(static_cast<uint32_t>(va) > cf && lane < span);
             const int tl = __builtin_ctzll(m);  // lane of t
             const uint32_t c_t = bcast_u32(static_cast<uint32_t>(va), tl);
             uint32_t c_s;
             if (tl > 0) c_s = bcast_u32(static_cast<uint32_t>(va), tl - 1);
-            else c_s = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(cdf[lo - 1]));
+            else c_s = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(entry(lo - 1)));
             const int32_t s = lo + tl - 1;
             const uint32_t freq = c_t - c_s;
 
@@ -561,7 +597,8 @@ __global__ void compact_streams_kernel(const uint32_t *__restrict__ slots, int64
 
 TablesDev dev_view(const basic_rans_tables *t)
 {
-    return TablesDev{t->d_cdfs, t->d_sizes, t->d_offsets, t->rows, t->stride, t->precision, t->bypass, t->bypass_precision};
+    return TablesDev{t->d_cdfs, t->d_sizes, t->d_offsets, t->rows, t->stride, t->precision, t->bypass, t->bypass_precision,
+                     t->d_cdf16, t->d_base, static_cast<int>(t->cdf16.size())};
 }
 
 struct DevBuf {
@@ -570,6 +607,45 @@ struct DevBuf {
     hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 4); }
     template <typename T> T *as() { return static_cast<T *>(p); }
 };
+
+}  // namespace
+
+namespace {
+
+constexpr size_t kLdsTableBudget = 144 * 1024;  // of the 160 KiB per CU
+
+template <bool AR, bool LDS>
+int launch_decode_v(const basic_rans_tables *t, const ArDev &ar, int nstreams, hipStream_t st, const uint32_t *d_words,
+                    const int64_t *d_word_off, const int32_t *d_indexes, const int64_t *d_seg, int32_t *d_out,
+                    uint64_t *d_state, int64_t *d_pos)
+{
+    const size_t lds = LDS ? t->cdf16.size() * sizeof(uint16_t) : 0;
+    if (LDS) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            BASIC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(rans_decode_kernel<AR, LDS>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_set = true;
+        }
+    }
+    hipLaunchKernelGGL((rans_decode_kernel<AR, LDS>), dim3(nstreams), dim3(64), lds, st, dev_view(t), ar, d_words, d_word_off,
+                       d_indexes, d_seg, d_out, d_state, d_pos);
+    BASIC_HIP_TRY(hipGetLastError());
+    return BASIC_OK;
+}
+
+int launch_decode(const basic_rans_tables *t, const ArDev &ar, int nstreams, hipStream_t st, const uint32_t *d_words,
+                  const int64_t *d_word_off, const int32_t *d_indexes, const int64_t *d_seg, int32_t *d_out,
+                  uint64_t *d_state, int64_t *d_pos)
+{
+    // LDS-resident tables pay a per-launch copy of the table set; worth it unless the launch is tiny.
+    const bool lds = t->cdf16.size() * sizeof(uint16_t) <= kLdsTableBudget;
+    if (ar.tab)
+        return lds ? launch_decode_v<true, true>(t, ar, nstreams, st, d_words, d_word_off, d_indexes, d_seg, d_out, d_state, d_pos)
+                   : launch_decode_v<true, false>(t, ar, nstreams, st, d_words, d_word_off, d_indexes, d_seg, d_out, d_state, d_pos);
+    return lds ? launch_decode_v<false, true>(t, ar, nstreams, st, d_words, d_word_off, d_indexes, d_seg, d_out, d_state, d_pos)
+               : launch_decode_v<false, false>(t, ar, nstreams, st, d_words, d_word_off, d_indexes, d_seg, d_out, d_state, d_pos);
+}
 
 }  // namespace
 
@@ -606,9 +682,9 @@ extern "C" int basic_rans_decode_batch_dev(const basic_rans_tables *t, const uin
                   "rans_decode_batch: bad argument");
     BASIC_REQUIRE(!t->d_ar, "rans_decode_batch: AR tables are only supported by the host-buffer entry points");
     ArDev ar{};
-    hipLaunchKernelGGL(rans_decode_kernel<false>, dim3(nstreams), dim3(64), 0, as_stream(hip_stream), dev_view(t), ar,
-                       d_words, d_word_off, d_indexes, d_seg, d_out_symbols, d_state, d_pos);
-    BASIC_HIP_TRY(hipGetLastError());
+    int rc = launch_decode(t, ar, nstreams, as_stream(hip_stream), d_words, d_word_off, d_indexes, d_seg, d_out_symbols,
+                           d_state, d_pos);
+    if (rc) return rc;
     return BASIC_OK;
 }
 
@@ -740,15 +816,9 @@ int stream_decode(basic_rans_stream *s, const int32_t *indexes, int64_t n, const
     ArDev ar;
     int rc = stage_ar(t, n, ar_indexes, ar_off0, ar_off1, b_ai, b_o0, b_o1, ar);
     if (rc) return rc;
-    if (ar.tab)
-        hipLaunchKernelGGL(rans_decode_kernel<true>, dim3(1), dim3(64), 0, nullptr, dev_view(t), ar,
-                           s->words.as<uint32_t>(), s->woff.as<int64_t>(), b_idx.as<int32_t>(), b_seg.as<int64_t>(),
-                           b_out.as<int32_t>(), s->state.as<uint64_t>(), s->pos.as<int64_t>());
-    else
-        hipLaunchKernelGGL(rans_decode_kernel<false>, dim3(1), dim3(64), 0, nullptr, dev_view(t), ar,
-                           s->words.as<uint32_t>(), s->woff.as<int64_t>(), b_idx.as<int32_t>(), b_seg.as<int64_t>(),
-                           b_out.as<int32_t>(), s->state.as<uint64_t>(), s->pos.as<int64_t>());
-    BASIC_HIP_TRY(hipGetLastError());
+    rc = launch_decode(t, ar, 1, nullptr, s->words.as<uint32_t>(), s->woff.as<int64_t>(), b_idx.as<int32_t>(),
+                       b_seg.as<int64_t>(), b_out.as<int32_t>(), s->state.as<uint64_t>(), s->pos.as<int64_t>());
+    if (rc) return rc;
     BASIC_HIP_TRY(hipMemcpy(out_symbols, b_out.p, bytes, hipMemcpyDeviceToHost));
     return BASIC_OK;
 }

@@ -28,7 +28,7 @@ def hyperprior_codec(N=128, M=192):
     return GeneralCodec(entropy_coder=ec)
 
 
-def seed_synthetic_weights(codec, seed=0, y_std=4.0):
+def seed_synthetic_weights(codec, seed=0, y_std=0.5):
     """Random-init weights for synthetic benchmarking (no pretrained models exist: reference
     README.md:107-108).  Default torch init under a fixed seed, then the last analysis layer is
     rescaled so the latents use a realistic range of the 64-entry scale table."""
@@ -58,7 +58,14 @@ def seed_synthetic_weights(codec, seed=0, y_std=4.0):
         k = y_std / float(t.std())
         last.weight.mul_(k)
         last.bias.mul_(k)
-        # spread the predicted scales: per-channel bias in [0.1, 8) on the last hyper-synthesis conv
+        # predicted scales: per-channel log-uniform bias in [0.2, 1.2) on the last hyper-synthesis conv and a
+        # damped data-dependent part, so the coded rate lands near a trained model's (~0.5-1 bpp)
         last_hs = [m for m in h_s if isinstance(m, torch.nn.Conv2d)][-1]
-        last_hs.bias.copy_(torch.exp(torch.rand(last_hs.bias.shape, generator=g) * 4.4 - 2.3))
+        last_hs.weight.mul_(0.05)
+        last_hs.bias.copy_(torch.exp(torch.rand(last_hs.bias.shape, generator=g) * 1.8 - 1.6))
+        # keep the reconstruction in a sane range: small output layer, mid-grey bias
+        g_s = ec.latent_generative_modules["y_x"].model
+        last_gs = g_s[len(g_s) - 1]
+        last_gs.weight.mul_(0.05)
+        last_gs.bias.fill_(0.5)
     return codec
