@@ -1,0 +1,457 @@
+"""Topologically-grouped autoregressive Gaussian y-coder --
+GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder (cbench/modules/prior_model/prior_coder/
+pgm_coder.py:983) with its bases TopoGroupPGMPriorCoder (:863-981), GaussianPGMPriorCoderImpl
+(:718-821), NNTrainablePGMPriorCoder (:218-616) and the optional
+TopoGroupDynamicMaskConv2dContextModel (cbench/nn/layers/masked_conv.py:231-305).
+
+Coding loop (identical order of operations to the reference):
+  for each topo group g = 0, 1, ...                                   pgm_coder.py:921-941 / :958-978
+      params = context model( decoded-so-far buffer, prior )           at the positions of g only
+      idx    = argmin_j |scale - table[j]| ;  mu = mean                :802-821, torch_ans.py:279-282
+      encode: sym = round(y - mu); buffer = sym + mu        decode: sym <- rANS; buffer = sym + mu
+  one rANS stream per image over the group-major symbol order          :943-947, :951,:971
+Where the reference evaluates the full H x W context model for EVERY group and gathers with boolean
+masks (nonzero + sync per group), this implementation precomputes, per latent shape, the static
+per-group element / position lists and launches the masked-conv kernels on those positions only.
+
+Stream format: for batch size 1 (how the reference tests, configs/*: batch_size=1) the bytes are the
+reference's.  For batch size > 1 the reference codes ALL images into one serial stream
+(data[mask] spans the batch); ``batch_stream_mode="per_image"`` (default for B > 1) instead emits one
+independent stream per image -- framed as <I n> <n x I length> streams -- which is what lets 256 images
+be coded concurrently; ``"reference"`` reproduces the single stream.
+"""
+import struct
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from ....base import HotPathModule
+from ....nn import kernels as K
+from .... import _lib
+from .compressai_coder import get_scale_table
+from .torch_ans import gaussian_ans_params
+
+
+def default_topo_groups(method: str, channel_groups: int, h: int, w: int) -> np.ndarray:
+    """_get_default_pgm (pgm_coder.py:1416-1491): int64 [G_c, H, W] topo-group ids."""
+    G = channel_groups
+    t = np.zeros((G, h, w), dtype=np.int64)
+    yy, xx = np.meshgrid(np.arange(h), np.arange(w), indexing="ij")
+    checker = ((yy + xx) % 2).astype(np.int64)  # 1 on (even,odd) and (odd,even)
+    if method == "none":
+        pass
+    elif method == "scanline":
+        t[:] = (yy * w + xx)[None]
+    elif method == "zigzag":
+        t[:] = (yy + xx)[None]
+    elif method == "checkerboard":
+        t[:] = checker[None]
+    elif method == "half-checkerboard":
+        t[:] = 1
+        t[:, 1::2, 1::2] = 0
+    elif method == "halfinv-checkerboard":
+        t[:, 1::2, 1::2] = 1
+    elif method == "quarter-checkerboard":
+        t[:] = 1
+        t[:, 1::4, 3::4] = 0
+        t[:, 3::4, 1::4] = 0
+    elif method == "interlace-checkerboard":
+        for i in range(G):
+            t[i] = (1 - checker) if i % 2 == 0 else checker
+    elif method == "raster2x2":
+        t[:, 0::2, 1::2] = 1
+        t[:, 1::2, 0::2] = 2
+        t[:, 1::2, 1::2] = 3
+    elif method == "channelwise":
+        for i in range(G):
+            t[i] = i
+    elif method == "channelwise-checkerboard":
+        for i in range(G):
+            t[i] = i * 2 + checker
+    elif method == "channelwise-scanline":
+        for i in range(G):
+            t[i] = yy * w + xx + i * h * w
+    elif method == "channelwise-g10":
+        splits = [1] * 9 + [G - 9]
+        s = 0
+        for i, n in enumerate(splits):
+            t[s:s + n] = i
+            s += n
+    elif method == "elic":
+        splits = [1, 1, 2, 4, G - 8]
+        s = 0
+        for i, n in enumerate(splits):
+            t[s:s + n] = i * 2 + checker[None]
+            s += n
+    else:
+        raise NotImplementedError(f"Unknown default_topo_group_method {method}")
+    return t
+
+
+class TopoGroupDynamicMaskConv2d(nn.Conv2d):
+    """Parameter holder of cbench/nn/layers/masked_conv.py:69-100 (weights only; the masked
+    convolution itself is csrc/mconv.hip)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, dynamic_channel_groups=1, allow_same_topogroup_conv=False, **kwargs):
+        kwargs.pop("groups", None)
+        for k in ("allow_continuous_topo_groups", "continuous_topo_groups_training_use_uniform_noise",
+                  "continuous_topo_groups_smooth_func", "detach_context_model"):
+            kwargs.pop(k, None)
+        super().__init__(in_channels, out_channels, kernel_size, **kwargs)
+        self.dynamic_channel_groups = dynamic_channel_groups
+        self.allow_same_topogroup_conv = allow_same_topogroup_conv
+
+    def forward(self, *a, **k):
+        raise RuntimeError("masked convolutions run through MaskedConvPlan on the coding positions")
+
+
+class TopoGroupDynamicMaskConv2dContextModel(nn.Module):
+    """masked_conv.py:231-305 parameter layout (context_prediction, param_merger_in, param_merger_out)."""
+
+    def __init__(self, in_channels=192, out_channels=384, kernel_size=5, use_param_merger=True, param_merger_in_channels=None,
+                 param_merger_mid_channels_list=None, param_merger_kernel_size=1, **kwargs):
+        super().__init__()
+        self.in_channels, self.out_channels, self.kernel_size = in_channels, out_channels, kernel_size
+        self.padding = kernel_size // 2
+        self.use_param_merger = use_param_merger
+        self.context_prediction = TopoGroupDynamicMaskConv2d(in_channels, out_channels, kernel_size, padding=self.padding)
+        if use_param_merger:
+            if param_merger_kernel_size != 1:
+                raise NotImplementedError("param merger kernels other than 1x1")
+            self.param_merger_out_channels = out_channels
+            self.param_merger_in_channels = out_channels * 2 if param_merger_in_channels is None else param_merger_in_channels
+            self.param_merger_mid_channels_list = [out_channels * 5 // 3, out_channels * 4 // 3] \
+                if param_merger_mid_channels_list is None else param_merger_mid_channels_list
+            mids = self.param_merger_mid_channels_list
+            self.param_merger_in = TopoGroupDynamicMaskConv2d(self.param_merger_in_channels, mids[0], 1, allow_same_topogroup_conv=True)
+            layers = []
+            for i in range(len(mids) - 1):
+                layers += [nn.LeakyReLU(inplace=True), TopoGroupDynamicMaskConv2d(mids[i], mids[i + 1], 1, allow_same_topogroup_conv=True)]
+            layers += [nn.LeakyReLU(inplace=True), TopoGroupDynamicMaskConv2d(mids[-1], out_channels, 1, allow_same_topogroup_conv=True)]
+            self.param_merger_out = nn.Sequential(*layers)
+
+
+class _GroupPlan:
+    """Static coding schedule of one (H, W) latent shape: per topo group the per-image element list
+    (ascending flat index = boolean-mask order, pgm_coder.py:898-900) and the spatial positions."""
+
+    def __init__(self, topo: np.ndarray, channels: int, device):
+        G, H, W = topo.shape
+        self.h, self.w, self.hw = H, W, H * W
+        per = channels // G
+        full = np.repeat(topo, per, axis=0).reshape(-1)          # post-repeat, :1770
+        self.topo_dev = torch.from_numpy(topo.astype(np.int32)).to(device).contiguous()
+        self.topo_cat_dev = torch.cat([self.topo_dev, torch.full_like(self.topo_dev, -1)], 0).contiguous()
+        self.groups = []
+        base = 0
+        for g in range(int(topo.max()) + 1):
+            elems = np.nonzero(full == g)[0].astype(np.int32)
+            pos = np.nonzero((topo == g).any(axis=0).reshape(-1))[0].astype(np.int32)
+            self.groups.append(dict(elems=torch.from_numpy(elems).to(device), n=int(elems.size), base=base, pos_np=pos))
+            base += int(elems.size)
+        self.per_image = base
+        self._pos_cache = {}
+
+    def positions(self, g, batch, device):
+        key = (g, batch)
+        if key not in self._pos_cache:
+            p = self.groups[g]["pos_np"]
+            allp = (np.arange(batch, dtype=np.int64)[:, None] * self.hw + p[None, :]).reshape(-1).astype(np.int32)
+            self._pos_cache[key] = torch.from_numpy(allp).to(device)
+        return self._pos_cache[key]
+
+
+class GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(HotPathModule):
+    def __init__(self, *args, in_channels=256, channel_groups=1, default_topo_group_method="none", default_num_topo_groups=-1,
+                 topo_group_context_model: Optional[TopoGroupDynamicMaskConv2dContextModel] = None, kernel_size=5,
+                 use_param_merger=True, use_joint_ar_model_impl=False, param_merger_expand_bottleneck=False,
+                 use_autoregressive_encode=True, use_bypass_coding=True, freq_precision=16, bypass_precision=4,
+                 lower_bound_scale=0.11, quantizer_params=None, fixed_input_shape=None,
+                 force_input_prior_shape_aligned=True, batch_stream_mode="auto", **kwargs):
+        super().__init__()
+        if use_joint_ar_model_impl:
+            raise NotImplementedError("use_joint_ar_model_impl (pgm_coder.py:1975-2070) is a 'next' row (SURVEY 8f rank 4)")
+        if not use_autoregressive_encode:
+            raise NotImplementedError("use_autoregressive_encode=False")
+        if quantizer_params is not None and list(quantizer_params)[0::2] != [0.0, 1.0]:
+            raise NotImplementedError("non-identity uniform quantiser")
+        self.in_channels = in_channels
+        self.channel_groups = channel_groups
+        self.default_topo_group_method = default_topo_group_method
+        self.kernel_size = kernel_size
+        self.padding = (kernel_size // 2, kernel_size // 2)
+        self.use_param_merger = use_param_merger
+        self.param_merger_expand_bottleneck = param_merger_expand_bottleneck
+        self.freq_precision, self.use_bypass_coding, self.bypass_precision = freq_precision, use_bypass_coding, bypass_precision
+        self.lower_bound_scale = lower_bound_scale
+        self.fixed_input_shape = fixed_input_shape
+        self.force_input_prior_shape_aligned = force_input_prior_shape_aligned
+        self.batch_stream_mode = batch_stream_mode
+        if default_topo_group_method in ("channelwise-g10", "elic"):  # pgm_coder.py:1164-1171
+            self.channel_groups = in_channels // 16
+            assert self.channel_groups >= (9 if default_topo_group_method == "channelwise-g10" else 8)
+        if in_channels % self.channel_groups:
+            raise ValueError("in_channels must divide into channel_groups")
+        self.out_channels = in_channels * 2  # mean and scale ("split_interleave")
+        G, C2 = self.channel_groups, self.out_channels
+        self.topo_group_context_model = topo_group_context_model
+        if topo_group_context_model is None:
+            # same parameter names as the reference (pgm_coder.py:1185-1239)
+            self.conv_kernel_weight = nn.Parameter(torch.zeros(C2, in_channels, kernel_size, kernel_size))
+            self.conv_kernel_bias = nn.Parameter(torch.zeros(C2))
+            self.context_prediction = TopoGroupDynamicMaskConv2d(in_channels, C2, kernel_size, padding=self.padding,
+                                                                dynamic_channel_groups=G)
+            if use_param_merger:
+                bott = C2 * 4 if param_merger_expand_bottleneck else C2 * 2
+                mk = lambda i, o: TopoGroupDynamicMaskConv2d(i, o, 1, dynamic_channel_groups=G * 2, allow_same_topogroup_conv=True)
+                self.param_merger = nn.Sequential(mk(C2 * 2, bott), nn.LeakyReLU(inplace=True), mk(bott, bott),
+                                                  nn.LeakyReLU(inplace=True), mk(bott, C2 * 2))
+        self.scale_table = get_scale_table()
+        self._tables = None
+        self._layers = None
+        self._layer_key = None
+        self._plans = {}
+        self._scale_table_dev = None
+
+    # ------------------------------------------------------------------ state
+    def update_state(self, *args, **kwargs) -> None:
+        """TorchANSPriorCoder.update_state (torch_ans.py:237-251)."""
+        freqs, nsym, offsets = gaussian_ans_params(self.scale_table, self.freq_precision, self.lower_bound_scale)
+        self._ans_params = (freqs, nsym, offsets)
+        self._tables = K.RansTables(freqs=freqs, nsym=nsym, offsets=offsets, precision=self.freq_precision,
+                                    bypass=self.use_bypass_coding, bypass_precision=self.bypass_precision)
+        self._layers = None
+        self._scale_table_dev = None
+
+    def _ready(self):
+        if self._tables is None:
+            raise AssertionError("Not Initialized! Should call self.update_state() before coding!")
+        if self._scale_table_dev is None or self._scale_table_dev.device != self.device:
+            self._scale_table_dev = self.scale_table.to(self.device).contiguous()
+        key = tuple((p.data_ptr(), p._version) for p in self.parameters())
+        if self._layers is None or key != self._layer_key:
+            self._layers = self._build_layers()
+            self._layer_key = key
+
+    def _build_layers(self):
+        """MaskedConvPlans of the context conv and the merger layers, with the activation that FOLLOWS a
+        layer fused into it."""
+        G, C2 = self.channel_groups, self.out_channels
+        L = dict()
+        cm = self.topo_group_context_model
+        if cm is None:
+            cp = self.context_prediction
+            L["ctx"] = K.MaskedConvPlan(cp.weight, cp.bias, G, G, False)
+            if self.use_param_merger:
+                m = self.param_merger
+                L["m"] = [
+                    (K.MaskedConvPlan(m[0].weight, m[0].bias, 2 * G, 2 * G, True, K.ACT_LEAKY_RELU), "cat", "cat"),
+                    (K.MaskedConvPlan(m[2].weight, m[2].bias, 2 * G, 2 * G, True, K.ACT_LEAKY_RELU), "cat", "cat"),
+                    # only the first G of the 2G output groups survive (pgm_coder.py:1631-1632)
+                    (K.MaskedConvPlan(m[4].weight[:C2], m[4].bias[:C2], 2 * G, G, True, K.ACT_NONE), "cat", "pgm"),
+                ]
+        else:
+            cp = cm.context_prediction
+            L["ctx"] = K.MaskedConvPlan(cp.weight, cp.bias, G, G, False)
+            if cm.use_param_merger:
+                convs = [cm.param_merger_in] + [l for l in cm.param_merger_out if isinstance(l, TopoGroupDynamicMaskConv2d)]
+                # param_merger_in: 2G input groups (pgm, -1), channel_group_mask keeps the first G output groups
+                # (masked_conv.py:289-292); the following layers see pgm on both sides (:293-296)
+                L["m"] = []
+                for i, c in enumerate(convs):
+                    act = K.ACT_LEAKY_RELU if i + 1 < len(convs) else K.ACT_NONE
+                    gi = 2 * G if i == 0 else G
+                    L["m"].append((K.MaskedConvPlan(c.weight, c.bias, gi, G, True, act), "cat" if i == 0 else "pgm", "pgm"))
+        return L
+
+    def _plan(self, h, w):
+        key = (h, w, str(self.device))
+        if key not in self._plans:
+            topo = default_topo_groups(self.default_topo_group_method, self.channel_groups, h, w)
+            self._plans[key] = _GroupPlan(topo, self.in_channels, self.device)
+        return self._plans[key]
+
+    # ------------------------------------------------------------------ context model at one group's positions
+    def _alloc(self, B, H, W, prior):
+        dev, C2 = self.device, self.out_channels
+        ws = dict()
+        ws["ybuf"] = torch.zeros((B, self.in_channels, H, W), device=dev)
+        merger = self._layers.get("m")
+        if merger is None:
+            ws["ctx"] = torch.zeros((B, C2, H, W), device=dev)
+            ws["params"] = torch.empty((B, C2, H, W), device=dev)
+        else:
+            cat = torch.empty((B, 2 * C2, H, W), device=dev)
+            cat[:, :C2].zero_()
+            cat[:, C2:].copy_(prior if prior is not None else torch.zeros((B, C2, H, W), device=dev))
+            ws["cat"] = cat
+            ws["hidden"] = [torch.empty((B, pl.cout, H, W), device=dev) for pl, _, _ in merger]
+            ws["params"] = ws["hidden"][-1]
+        return ws
+
+    def _context(self, ws, plan, g, B, prior):
+        pos = plan.positions(g, B, self.device)
+        topo = dict(pgm=plan.topo_dev, cat=plan.topo_cat_dev)
+        merger = self._layers.get("m")
+        if merger is None:
+            self._layers["ctx"](ws["ybuf"], topo["pgm"], topo["pgm"], pos, ws["ctx"])
+            # no merger: params = ctx + prior (pgm_coder.py:1634-1636); elementwise add on the full map is
+            # cheap plumbing and only the group's positions are read afterwards
+            ws["params"] = ws["ctx"] + prior if prior is not None else ws["ctx"]
+            return ws["params"]
+        self._layers["ctx"](ws["ybuf"], topo["pgm"], topo["pgm"], pos, ws["cat"], out_offset=0)
+        x = ws["cat"]
+        for (pl, tin, tout), out in zip(merger, ws["hidden"]):
+            pl(x, topo[tin], topo[tout], pos, out)
+            x = out
+        return ws["params"]
+
+    # ------------------------------------------------------------------ coding
+    def _check_prior(self, shape, prior):
+        if prior is not None and self.force_input_prior_shape_aligned:
+            assert tuple(shape[2:]) == tuple(prior.shape[2:]), \
+                "Input and prior shape not aligned! Consider setting force_input_prior_shape_aligned = False, which may add a little overhead to the bitstream to save the input shape!"
+        if prior is not None and not self.force_input_prior_shape_aligned:
+            prior = prior[..., : shape[2], : shape[3]]
+        return None if prior is None else prior.contiguous()
+
+    def _per_image(self, B):
+        mode = self.batch_stream_mode
+        if mode == "auto":
+            return B > 1
+        return mode == "per_image"
+
+    def _run_encode(self, y, prior):
+        self._ready()
+        B, C, H, W = y.shape
+        plan = self._plan(H, W)
+        ws = self._alloc(B, H, W, prior)
+        n = plan.per_image
+        sym = torch.empty((B, n), device=self.device, dtype=torch.int32)
+        idx = torch.empty((B, n), device=self.device, dtype=torch.int32)
+        L = _lib.lib()
+        for g, grp in enumerate(plan.groups):
+            if grp["n"] == 0:
+                continue
+            params = self._context(ws, plan, g, B, prior)
+            _lib.check(L.basic_pgm_gauss_encode_group_dev(
+                y.data_ptr(), params.data_ptr(), B, C, H * W, grp["elems"].data_ptr(), grp["n"], self._scale_table_dev.data_ptr(),
+                self._scale_table_dev.numel(), sym.data_ptr(), idx.data_ptr(), n, grp["base"], ws["ybuf"].data_ptr(),
+                K._stream()))
+        return sym, idx, ws["ybuf"], plan
+
+    def forward(self, input, prior=None, pgm=None, quantizer_params=None, **kwargs):
+        """Eval-mode forward (pgm_coder.py:391-539): the dequantised latent.  With autoregressive encoding the
+        reference's encode() quantises y - mu group by group, which is what the decoder reproduces; that buffer
+        is returned here."""
+        self._ready()
+        if pgm is not None:
+            raise NotImplementedError("externally supplied topo groups")
+        input = input.contiguous()
+        prior = self._check_prior(input.shape, prior)
+        _, _, ybuf, _ = self._run_encode(input, prior)
+        return ybuf
+
+    def encode(self, input, *args, prior=None, pgm=None, quantizer_params=None, **kwargs) -> bytes:
+        self._ready()
+        if pgm is not None:
+            raise NotImplementedError("externally supplied topo groups")
+        input = input.contiguous()
+        prior = self._check_prior(input.shape, prior)
+        B = input.shape[0]
+        sym, idx, _, plan = self._run_encode(input, prior)
+        n = plan.per_image
+        if self._per_image(B):
+            strings = self._tables.encode_batch_to_bytes(sym.reshape(-1), idx.reshape(-1), n)
+            body = struct.pack("<I", B) + struct.pack("<%dI" % B, *[len(s) for s in strings]) + b"".join(strings)
+        else:
+            # reference order for a batch: group-major over ALL images (data[mask] spans the batch, :898-900)
+            if B > 1:
+                parts_s, parts_i = [], []
+                for grp in plan.groups:
+                    parts_s.append(sym[:, grp["base"]: grp["base"] + grp["n"]].reshape(-1))
+                    parts_i.append(idx[:, grp["base"]: grp["base"] + grp["n"]].reshape(-1))
+                sym, idx = torch.cat(parts_s), torch.cat(parts_i)
+            body = self._tables.encode_batch_to_bytes(sym.reshape(-1).contiguous(), idx.reshape(-1).contiguous(), B * n)[0]
+        head = b""
+        if self.fixed_input_shape is None and not (self.force_input_prior_shape_aligned and prior is not None):
+            spatial = input.shape[2:]                                    # pgm_coder.py:581-596
+            head = struct.pack("B", len(spatial) + 1) + struct.pack("<H", B) + b"".join(struct.pack("<H", d) for d in spatial)
+        return head + body
+
+    def decode(self, byte_string: bytes, *args, prior=None, pgm=None, quantizer_params=None, **kwargs):
+        self._ready()
+        if pgm is not None:
+            raise NotImplementedError("externally supplied topo groups")
+        ptr = 0
+        if self.fixed_input_shape is not None:
+            B, spatial = self.fixed_input_shape[0], tuple(self.fixed_input_shape[1:])
+        elif self.force_input_prior_shape_aligned and prior is not None:
+            B, spatial = prior.shape[0], tuple(prior.shape[2:])
+        else:
+            nd = byte_string[0]
+            dims = struct.unpack("<%dH" % nd, byte_string[1:1 + 2 * nd])
+            ptr = 1 + 2 * nd
+            B, spatial = dims[0], tuple(dims[1:])
+        H, W = spatial
+        prior = self._check_prior((B, self.in_channels, H, W), prior)
+        body = byte_string[ptr:]
+        plan = self._plan(H, W)
+        n, C = plan.per_image, self.in_channels
+        per_image = self._per_image(B)
+        if per_image:
+            (nb,) = struct.unpack("<I", body[:4])
+            assert nb == B
+            lens = struct.unpack("<%dI" % B, body[4:4 + 4 * B])
+            cur, strings = 4 + 4 * B, []
+            for Ls in lens:
+                strings.append(body[cur:cur + Ls])
+                cur += Ls
+        else:
+            strings = [body]
+        ns = len(strings)
+        for s in strings:
+            if len(s) < 8 or len(s) % 4:
+                raise ValueError("rANS stream must hold >= 2 whole 32-bit words")
+        woff = np.concatenate([[0], np.cumsum([len(s) // 4 for s in strings])]).astype(np.int64)
+        dev = self.device
+        d_words = torch.from_numpy(np.frombuffer(b"".join(strings), dtype=np.int32).copy()).to(dev)
+        d_woff = torch.from_numpy(woff).to(dev)
+        state = torch.zeros((ns,), device=dev, dtype=torch.int64)
+        pos = torch.full((ns,), -1, device=dev, dtype=torch.int64)
+        ws = self._alloc(B, H, W, prior)
+        sym = torch.empty((B, n), device=dev, dtype=torch.int32)
+        idx = torch.empty((B, n), device=dev, dtype=torch.int32)
+        L = _lib.lib()
+        for g, grp in enumerate(plan.groups):
+            ng = grp["n"]
+            if ng == 0:
+                continue
+            params = self._context(ws, plan, g, B, prior)
+            _lib.check(L.basic_pgm_gauss_index_group_dev(params.data_ptr(), B, C, H * W, grp["elems"].data_ptr(), ng,
+                                                        self._scale_table_dev.data_ptr(), self._scale_table_dev.numel(),
+                                                        idx.data_ptr(), n, grp["base"], K._stream()))
+            if per_image:
+                self._decode_group(d_words, d_woff, idx, sym, grp["base"], ng, state, pos)
+            else:
+                # single stream over the whole batch: gather this group's indexes batch-major
+                gi = idx[:, grp["base"]: grp["base"] + ng].reshape(-1).contiguous()
+                go = torch.empty_like(gi)
+                seg = torch.tensor([0, B * ng], device=dev, dtype=torch.int64)
+                self._tables.decode_batch(d_words, d_woff, gi, seg, out=go, state=state, pos=pos)
+                sym[:, grp["base"]: grp["base"] + ng] = go.reshape(B, ng)
+            _lib.check(L.basic_pgm_gauss_scatter_group_dev(sym.data_ptr(), params.data_ptr(), B, C, H * W, grp["elems"].data_ptr(), ng,
+                                                          n, grp["base"], ws["ybuf"].data_ptr(), K._stream()))
+        return ws["ybuf"]
+
+    def _decode_group(self, d_words, d_woff, idx, sym, lo, ng, state, pos):
+        """Per-image streams: stream b continues (decode_stream semantics, pgm_coder.py:971) with the ng symbols
+        whose indexes sit at idx[b, lo:lo+ng]."""
+        B = idx.shape[0]
+        gi = idx[:, lo: lo + ng].contiguous().reshape(-1)
+        go = torch.empty_like(gi)
+        seg = torch.arange(B + 1, device=idx.device, dtype=torch.int64) * ng
+        self._tables.decode_batch(d_words, d_woff, gi, seg, out=go, state=state, pos=pos)
+        sym[:, lo: lo + ng] = go.reshape(B, ng)

@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""Generates the golden vectors under tests/golden/ FROM THE REFERENCE ITSELF, in this container:
+  * the reference's native rANS (cbench/csrc/ans, cbench/csrc/rans compiled to oracle/_ref), and
+  * the reference's own Python (cbench.modules..., imported through tests/golden/ref_import.py).
+Only data is written (inputs and expected outputs as .npz); no reference source is copied.
+Run:  python tests/golden/make_golden.py     (needs /root/reference; never runs on the GPU box)
+"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_import  # noqa: E402
+
+cbench = ref_import.install()
+from cbench import ans as ref_ans, rans as ref_rans  # noqa: E402
+from cbench.utils.bytes_ops import merge_bytes, split_merged_bytes, encode_shape  # noqa: E402
+from cbench.nn.layers.masked_conv import TopoGroupDynamicMaskConv2d, TopoGroupDynamicMaskConv2dContextModel  # noqa: E402
+from cbench.modules.prior_model.prior_coder.pgm_coder import GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder  # noqa: E402
+from cbench.modules.prior_model.prior_coder.compressai_coder import get_scale_table  # noqa: E402
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrays)
+    print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def b2a(b):
+    return np.frombuffer(b, dtype=np.uint8).copy()
+
+
+# ---------------------------------------------------------------- 1. native rANS known-answer vectors
+def rans_kats():
+    out = {}
+    cases = []
+    # SURVEY 8c vectors
+    cases.append(("tiny_nobypass", np.array([[3, 1]]), np.array([2]), np.array([0]), 16, False, np.array([0, 1, 0, 0]), np.zeros(4)))
+    cases.append(("tiny_bypass", np.array([[3, 1]]), np.array([2]), np.array([0]), 16, True, np.array([0, 1, 5, -2]), np.zeros(4)))
+    rng = np.random.default_rng(2024)
+    for i, (nd, ns, n, prec, byp) in enumerate([(8, 512, 3000, 16, True), (5, 40, 777, 12, True), (3, 9, 64, 16, False),
+                                                (64, 64, 4096, 16, True), (2, 2217, 2000, 16, True), (1, 2, 1, 16, True)]):
+        freqs = rng.integers(1, 1024, (nd, ns))
+        nsym = rng.integers(2, ns + 1, nd)
+        off = rng.integers(-6, 6, nd)
+        idx = rng.integers(0, nd, n)
+        if byp:
+            sym = rng.integers(-30, ns + 30, n)
+            sym[::11] = rng.integers(-70000, 70000, sym[::11].size)
+        else:
+            sym = off[idx] + rng.integers(0, 1 << 30, n) % nsym[idx]
+        cases.append((f"rand{i}", freqs, nsym, off, prec, byp, sym, idx))
+    names = []
+    for name, freqs, nsym, off, prec, byp, sym, idx in cases:
+        f, n_, o = (np.asarray(a).astype(np.int32) for a in (freqs, nsym, off))
+        s, ix = np.asarray(sym).astype(np.int32), np.asarray(idx).astype(np.int32)
+        enc = ref_ans.Rans64Encoder(prec, byp, 4)
+        enc.init_params(f, n_, o)
+        data = enc.encode_with_indexes(s, ix)
+        dec = ref_ans.Rans64Decoder(prec, byp, 4)
+        dec.init_params(f, n_, o)
+        assert np.array_equal(dec.decode_with_indexes(data, ix), s)
+        cd = enc.get_cdfs()
+        for r in range(cd.shape[0]):
+            cd[r, n_[r] + 2:] = 0  # get_cdfs leaves the padding uninitialised
+        out.update({f"{name}.freqs": f, f"{name}.nsym": n_, f"{name}.offsets": o, f"{name}.cfg": np.array([prec, int(byp), 4]),
+                    f"{name}.symbols": s, f"{name}.indexes": ix, f"{name}.bytes": b2a(data), f"{name}.cdfs": cd})
+        names.append(name)
+    # SURVEY 8c large vector: only its digest is kept (inputs are a seeded recipe)
+    np.random.seed(0)
+    freqs = np.random.randint(1, 1024, (64, 64)).astype(np.int32)
+    enc = ref_ans.Rans64Encoder(16, True, 4)
+    enc.init_params(freqs, np.full(64, 64, np.int32), np.zeros(64, np.int32))
+    data = np.random.randint(-3, 67, (1, 192, 16, 16)).astype(np.int32)
+    idx = np.random.randint(0, 64, (1, 192, 16, 16)).astype(np.int32)
+    b = enc.encode_with_indexes(data, idx)
+    out["survey_large.sha256"] = np.frombuffer(hashlib.sha256(b).digest(), np.uint8)
+    out["survey_large.nbytes"] = np.array([len(b)])
+    out["pmf_cdf.in"] = np.array([.1, .2, .7], np.float32)
+    out["pmf_cdf.out"] = np.array(ref_ans.pmf_to_quantized_cdf([.1, .2, .7], 16), np.int32)
+    # CompressAI-fork module (cbench.rans): same bitstream from CDF lists
+    cdfs = [ref_rans.pmf_to_quantized_cdf(list(p / p.sum()) + [1e-6], 16) for p in rng.random((6, 30)).astype(np.float32)]
+    sizes = [len(c) for c in cdfs]
+    offs = [-15] * 6
+    sym = rng.integers(-25, 25, 500).tolist()
+    idx = rng.integers(0, 6, 500).tolist()
+    fb = ref_rans.RansEncoder().encode_with_indexes(sym, idx, cdfs, sizes, offs)
+    assert ref_rans.RansDecoder().decode_with_indexes(fb, idx, cdfs, sizes, offs) == sym
+    out.update({"fork.cdfs": np.array(cdfs, np.int32), "fork.sizes": np.array(sizes, np.int32), "fork.offsets": np.array(offs, np.int32),
+                "fork.symbols": np.array(sym, np.int32), "fork.indexes": np.array(idx, np.int32), "fork.bytes": b2a(fb)})
+    out["names"] = np.array(names)
+    save("rans_kat.npz", **out)
+
+
+# ---------------------------------------------------------------- 2. Gaussian PGM tables
+def gauss_tables():
+    c = GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(in_channels=192)
+    c.update_state()
+    f, n, o = c._get_ans_params()
+    cd = c.ans_encoder.get_cdfs()
+    for r in range(cd.shape[0]):
+        cd[r, n[r] + 2:] = 0
+    st = get_scale_table().numpy()
+    sel = c._select_best_indexes(torch.stack([torch.zeros(8), torch.tensor([0.0, 0.11, 0.117, 0.5, 5.0, 100.0, 256.0, 1000.0])], -1)
+                                 .reshape(1, 16, 1, 1))
+    save("gauss_pgm_tables.npz", freqs=f, nsym=n, offsets=o, cdfs=cd, scale_table=st,
+         freqs_sha256=np.frombuffer(hashlib.sha256(f.tobytes()).digest(), np.uint8),
+         select_scales=np.array([0.0, 0.11, 0.117, 0.5, 5.0, 100.0, 256.0, 1000.0], np.float32),
+         select_indexes=sel.reshape(-1).numpy().astype(np.int32))
+
+
+# ---------------------------------------------------------------- 3. topo-group maps
+def topo_maps():
+    out, keys = {}, []
+    for method, G, C in [("none", 1, 16), ("checkerboard", 1, 16), ("raster2x2", 2, 16), ("channelwise", 4, 16),
+                         ("channelwise-checkerboard", 2, 16), ("scanline", 1, 16), ("zigzag", 1, 16), ("elic", 1, 128),
+                         ("half-checkerboard", 1, 16), ("quarter-checkerboard", 1, 16), ("interlace-checkerboard", 2, 16),
+                         ("channelwise-scanline", 2, 16), ("channelwise-g10", 1, 160), ("halfinv-checkerboard", 1, 16)]:
+        c = GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(in_channels=C, channel_groups=G, default_topo_group_method=method)
+        for (h, w) in [(4, 4), (5, 7)]:
+            pgm = c._get_default_pgm((1, c.channel_groups, h, w))
+            k = f"{method}|{G}|{C}|{h}x{w}"
+            out[k] = pgm.numpy().astype(np.int32)
+            keys.append(k)
+    out["keys"] = np.array(keys)
+    save("topo_maps.npz", **out)
+
+
+# ---------------------------------------------------------------- 4. masked convolution
+def masked_conv():
+    out, keys = {}, []
+    g = torch.Generator().manual_seed(11)
+    for i, (cin, cout, k, gi, same, use_mask) in enumerate([(8, 16, 5, 1, False, False), (8, 16, 5, 2, False, False),
+                                                            (16, 24, 1, 4, True, True), (12, 12, 3, 3, True, False)]):
+        conv = TopoGroupDynamicMaskConv2d(cin, cout, k, padding=k // 2, allow_same_topogroup_conv=same)
+        with torch.no_grad():
+            conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) * 0.2)
+            conv.bias.copy_(torch.randn(conv.bias.shape, generator=g) * 0.1)
+        x = torch.randn(2, cin, 5, 6, generator=g)
+        topo = torch.randint(-1 if same else 0, 4, (1, gi, 5, 6), generator=g)
+        mask = ([True] * (gi // 2) + [False] * (gi - gi // 2)) if use_mask else None
+        with torch.no_grad():
+            y = conv(x, topo, channel_group_mask=mask)
+        out.update({f"c{i}.weight": conv.weight.detach().numpy(), f"c{i}.bias": conv.bias.detach().numpy(), f"c{i}.x": x.numpy(),
+                    f"c{i}.topo": topo.numpy().astype(np.int32), f"c{i}.y": y.numpy(),
+                    f"c{i}.cfg": np.array([cin, cout, k, gi, int(same), int(use_mask)])})
+        keys.append(f"c{i}")
+    out["keys"] = np.array(keys)
+    save("masked_conv.npz", **out)
+
+
+# ---------------------------------------------------------------- 5. full AR coder runs
+def ar_coder():
+    out, keys = {}, []
+    cfgs = [("none", 16, 1, False, False, (1, 6, 6)), ("checkerboard", 16, 1, True, False, (1, 6, 6)),
+            ("channelwise", 16, 2, False, False, (1, 5, 7)), ("raster2x2", 16, 1, False, False, (1, 6, 6)),
+            ("scanline", 16, 1, False, True, (1, 4, 4)), ("elic", 128, 1, False, False, (1, 4, 4)),
+            ("checkerboard", 16, 1, False, False, (2, 4, 6)), ("channelwise-checkerboard", 16, 2, True, False, (1, 4, 4))]
+    for i, (method, C, G, expand, ctxm, (B, H, W)) in enumerate(cfgs):
+        torch.manual_seed(100 + i)
+        kw = dict(in_channels=C, channel_groups=G, default_topo_group_method=method, param_merger_expand_bottleneck=expand)
+        if ctxm:
+            kw["topo_group_context_model"] = TopoGroupDynamicMaskConv2dContextModel(in_channels=C, out_channels=2 * C)
+        coder = GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(**kw).eval()
+        # weights by RECIPE (kept out of the fixture): torch.manual_seed(100+i), then for every parameter in
+        # named_parameters() order  p = randn(shape) * (0.05 if p.dim() > 1 else 0.02)
+        pnames, pshapes = [], []
+        torch.manual_seed(100 + i)  # re-seed AFTER construction (module init consumes the generator)
+        with torch.no_grad():
+            for name, p in coder.named_parameters():
+                p.copy_(torch.randn(p.shape) * (0.05 if p.dim() > 1 else 0.02))
+                pnames.append(name)
+                pshapes.append(",".join(str(d) for d in p.shape))
+        coder.update_state()
+        gen = torch.Generator().manual_seed(200 + i)
+        y = torch.randn(B, C, H, W, generator=gen) * 3
+        prior = torch.cat([torch.randn(B, C, H, W, generator=gen), torch.rand(B, C, H, W, generator=gen) * 4 + 0.2], 1)
+        # interleave so that channel 2c = mean, 2c+1 = scale ("split_interleave")
+        prior = prior.reshape(B, 2, C, H, W).transpose(1, 2).reshape(B, 2 * C, H, W).contiguous()
+        captured = {}
+        orig = coder.ans_encoder
+
+        class Spy:
+            def encode_with_indexes(self, data, indexes, **k):
+                captured["symbols"], captured["indexes"] = np.array(data), np.array(indexes)
+                return orig.encode_with_indexes(data, indexes, **k)
+        coder.ans_encoder = Spy()
+        with torch.no_grad():
+            data = coder.encode(y, prior=prior)
+            yhat = coder.decode(data, prior=prior)
+            yfwd = coder(y, prior=prior)
+        k = f"a{i}"
+        out[f"{k}.pnames"] = np.array(pnames)
+        out[f"{k}.pshapes"] = np.array(pshapes)
+        out[f"{k}.wsum"] = np.array([float(sum(p.double().sum() for p in coder.parameters()))])  # recipe checksum
+        out.update({f"{k}.y": y.numpy(), f"{k}.prior": prior.numpy(), f"{k}.bytes": b2a(data), f"{k}.symbols": captured["symbols"].astype(np.int32),
+                    f"{k}.indexes": captured["indexes"].astype(np.int32), f"{k}.yhat": yhat.numpy(), f"{k}.yfwd": yfwd.numpy(),
+                    f"{k}.cfg": np.array([C, G, int(expand), int(ctxm), B, H, W]), f"{k}.method": np.array(method)})
+        keys.append(k)
+        print(f"  {k} {method}: {len(data)} bytes, max|yhat-y| {float((yhat - y).abs().max()):.3f}")
+    out["keys"] = np.array(keys)
+    save("ar_coder.npz", **out)
+
+
+# ---------------------------------------------------------------- 6. framing
+def framing():
+    segs = [b"abc", b"", b"\x00\x01\x02\x03\x04", b"z" * 300]
+    out = {"segs": np.array([len(s) for s in segs]), "raw": b2a(b"".join(segs))}
+    out["merged_all"] = b2a(merge_bytes(segs))
+    out["merged_n4"] = b2a(merge_bytes(segs, num_segments=4))
+    out["merged_2"] = b2a(merge_bytes(segs[:2], num_segments=2))
+    assert split_merged_bytes(merge_bytes(segs, num_segments=4), num_segments=4) == segs
+    out["shape_bytes"] = b2a(encode_shape((1, 192, 16, 16)))
+    save("framing.npz", **out)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["rans", "tables", "topo", "mconv", "ar", "framing"]
+    fn = dict(rans=rans_kats, tables=gauss_tables, topo=topo_maps, mconv=masked_conv, ar=ar_coder, framing=framing)
+    for w in which:
+        fn[w]()
