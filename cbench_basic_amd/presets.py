@@ -28,6 +28,92 @@ def hyperprior_codec(N=128, M=192):
     return GeneralCodec(entropy_coder=ec)
 
 
+def topogroup_ar_codec(method="checkerboard", N=128, M=192, channel_groups=1, expand_bottleneck=True, use_param_merger=True):
+    """configs/lossy_latent_graph_topogroup.py:203-244 ("hyperprior-ar-base" and its topo-group variants
+    :253-781): hyperprior transforms, h_s = HyperpriorHyperSynthesisModel(N, 2M) giving (mean, scale)
+    interleaved, y coded by the topo-group AR Gaussian coder with the in-coder masked param merger."""
+    from .modules.prior_model.prior_coder.pgm_coder import GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder
+    hs = HyperpriorHyperSynthesisModel(N=N, M=2 * M)
+    ec = LatentGraphicalANSEntropyCoder(
+        latent_node_inference_topo_order=["x", "y", "z"],
+        latent_node_generative_topo_order=["z", "y", "x"],
+        latent_node_entropy_coder_dict=dict(
+            x=LossyDummyEntropyCoder(lambda_rd=145.2225),
+            y=GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(in_channels=M, channel_groups=channel_groups,
+                                                                   default_topo_group_method=method, use_param_merger=use_param_merger,
+                                                                   param_merger_expand_bottleneck=expand_bottleneck),
+            z=CompressAIEntropyBottleneckPriorCoder(entropy_bottleneck_channels=N, use_inner_aux_opt=True),
+        ),
+        latent_inference_dict=dict(x_y=HyperpriorAnalysisModel(N=N, M=M), y_z=HyperpriorHyperAnalysisModel(N=N, M=M)),
+        latent_generative_dict=dict(z_y=hs, y_x=HyperpriorSynthesisModel(N=N, M=M)),
+    )
+    return GeneralCodec(entropy_coder=ec)
+
+
+BASIC_WIDTHS = [48, 72, 96, 144, 192]
+
+
+def basic_codec(widths=BASIC_WIDTHS, M=192, num_complex_levels=8):
+    """BaSIC "hyperprior-ar-sc-slimmable-full-dynamic" (configs/presets/lossy_latent_graph_scalable_ar_models.py:
+    73-197): slimmable g_a/g_s, MS-slimmable h_a/h_s, 192-ch EntropyBottleneck, scanline AR y-coder with the
+    masked-conv context model, four slim controller nodes selected per complexity level."""
+    from .modules.prior_model.prior_coder.pgm_coder import (GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder,
+                                                            TopoGroupDynamicMaskConv2dContextModel)
+    from .nn.layers.param_generator import IndexSelectParameterGeneratorWrapper, NNParameterGenerator
+    from .nn.layers.pgm_layers import (HyperpriorAnalysisSlimmableConv2dPGMModel, HyperpriorSynthesisSlimmableConv2dPGMModel,
+                                       MeanScaleHyperpriorHyperAnalysisSlimmableConv2dPGMModel,
+                                       MeanScaleHyperpriorHyperSynthesisSlimmableConv2dPGMModel)
+    n = len(widths)
+
+    def slim_node():
+        return IndexSelectParameterGeneratorWrapper(
+            batched_generator=NNParameterGenerator(shape=(n, 1, 1, n), init_method="value",
+                                                   init_value=torch.eye(n).flip(-1).unsqueeze(1).unsqueeze(1), fix_params=True),
+            fix_for_inference=True)
+
+    ec = LatentGraphicalANSEntropyCoder(
+        node_generator_dict=dict(pgmxy=slim_node(), pgmyx=slim_node(), pgmyz=slim_node(), pgmzy=slim_node()),
+        use_lossy_compression=True, lossy_compression_lambda_rd=145.2225,
+        latent_node_inference_topo_order=["x", "y", "z"],
+        latent_node_generative_topo_order=["z", "y", "x"],
+        latent_node_entropy_coder_dict=dict(
+            y=GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(
+                in_channels=M, default_topo_group_method="scanline",
+                topo_group_context_model=TopoGroupDynamicMaskConv2dContextModel(in_channels=M, out_channels=2 * M)),
+            z=CompressAIEntropyBottleneckPriorCoder(entropy_bottleneck_channels=M, use_inner_aux_opt=True),
+        ),
+        latent_inference_dict=dict(
+            x_y=HyperpriorAnalysisSlimmableConv2dPGMModel(in_channels=3, out_channels=M, mid_channels_list=widths),
+            y_z=MeanScaleHyperpriorHyperAnalysisSlimmableConv2dPGMModel(in_channels=M, out_channels=M, mid_channels_list=widths)),
+        latent_generative_dict=dict(
+            z_y=MeanScaleHyperpriorHyperSynthesisSlimmableConv2dPGMModel(in_channels=M, out_channels=2 * M, mid_channels_list=widths),
+            y_x=HyperpriorSynthesisSlimmableConv2dPGMModel(in_channels=M, out_channels=3, mid_channels_list=widths)),
+        latent_inference_input_mapping=dict(x_y={"pgmxy": "pgm"}, y_z={"pgmyz": "pgm"}),
+        latent_generative_input_mapping=dict(y_x={"pgmyx": "pgm"}, z_y={"pgmzy": "pgm"}, y={"z": "prior"}),
+        complexity_level_greedy_search=True, complexity_level_greedy_search_num_levels=num_complex_levels,
+        complexity_level_controller_nodes=["pgmxy", "pgmyz", "pgmzy", "pgmyx"],
+    )
+    # The searched levels need trained weights + a dataset (latent_graph.py:1397-1640, a "next" row); install a
+    # fixed monotone ladder of controller indices instead (index 0 = widest, n-1 = narrowest; SURVEY 8d cfg-4).
+    ladder = basic_default_ladder(n, num_complex_levels)
+    ec.set_complexity_level_params([{k: ec.node_generators[k](index=i) for k, i in lvl.items()} for lvl in ladder])
+    return GeneralCodec(entropy_coder=ec)
+
+
+def basic_default_ladder(n_widths, num_levels):
+    """num_levels index tuples from all-narrow to all-wide, widening one controller at a time."""
+    names = ["pgmyx", "pgmxy", "pgmzy", "pgmyz"]
+    cur = {k: n_widths - 1 for k in names}
+    steps = [dict(cur)]
+    while any(v > 0 for v in cur.values()):
+        for k in names:
+            if cur[k] > 0:
+                cur[k] -= 1
+                steps.append(dict(cur))
+    pick = [round(i * (len(steps) - 1) / max(1, num_levels - 1)) for i in range(num_levels)]
+    return [steps[i] for i in pick]
+
+
 def seed_synthetic_weights(codec, seed=0, y_std=0.5):
     """Random-init weights for synthetic benchmarking (no pretrained models exist: reference
     README.md:107-108).  Default torch init under a fixed seed, then the last analysis layer is
