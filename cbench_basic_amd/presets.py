@@ -124,34 +124,48 @@ def seed_synthetic_weights(codec, seed=0, y_std=0.5):
             if name.endswith(".weight") and p.dim() == 4:
                 fan_in = p.shape[1] * p.shape[2] * p.shape[3]
                 p.copy_((torch.rand(p.shape, generator=g) * 2 - 1) * (3.0 / fan_in) ** 0.5)
-            elif name.endswith(".bias") and ".model." in name:
+            elif name.endswith(".bias") and (".model." in name or ".pgm_model." in name):
                 p.copy_((torch.rand(p.shape, generator=g) * 2 - 1) * 0.05)
         ec = codec.entropy_coder
-        g_a = ec.latent_inference_modules["x_y"].model
-        h_s = ec.latent_generative_modules["z_y"].model
-        # scale y: calibrate on one seeded image on the CPU reference ops
         import torch.nn.functional as F
+        from .nn.layers.gdn import GDN
+        from .nn.layers.slimmable_layers import DynamicConv2d, DynamicGDN
+
+        def seq_of(m):
+            return m.model if hasattr(m, "model") else m.pgm_model
+
+        def conv_of(m):
+            return m.conv if isinstance(m, DynamicConv2d) else m
+
+        def cpu_forward(seq, t):  # widest configuration, plain torch ops, calibration only
+            for m in seq:
+                if isinstance(m, (torch.nn.Conv2d, DynamicConv2d)) and not getattr(m, "transposed", False) \
+                        and not isinstance(m, torch.nn.ConvTranspose2d):
+                    c = conv_of(m)
+                    pad = m.padding if isinstance(m, DynamicConv2d) else c.padding
+                    t = F.conv2d(t, c.weight[:, : t.shape[1]], c.bias, stride=c.stride, padding=pad)
+                elif isinstance(m, (GDN, DynamicGDN)):
+                    gamma, beta = m.effective() if isinstance(m, GDN) else m.effective(len(m.channels_list) - 1)
+                    C = t.shape[1]
+                    t = t * torch.rsqrt(F.conv2d(t * t, gamma.reshape(C, C, 1, 1), beta))
+            return t
+
+        g_a = seq_of(ec.latent_inference_modules["x_y"])
+        h_s = seq_of(ec.latent_generative_modules["z_y"])
+        g_s = seq_of(ec.latent_generative_modules["y_x"])
         x = torch.rand(1, 3, 64, 64, generator=g)
-        t = x
-        for m in g_a:
-            if isinstance(m, torch.nn.Conv2d):
-                t = F.conv2d(t, m.weight, m.bias, stride=m.stride, padding=m.padding)
-            else:
-                gamma, beta = m.effective()
-                C = t.shape[1]
-                t = t * torch.rsqrt(F.conv2d(t * t, gamma.reshape(C, C, 1, 1), beta))
-        last = g_a[len(g_a) - 1]
+        t = cpu_forward(g_a, x)
+        last = conv_of(g_a[len(g_a) - 1])
         k = y_std / float(t.std())
         last.weight.mul_(k)
         last.bias.mul_(k)
         # predicted scales: per-channel log-uniform bias in [0.2, 1.2) on the last hyper-synthesis conv and a
-        # damped data-dependent part, so the coded rate lands near a trained model's (~0.5-1 bpp)
-        last_hs = [m for m in h_s if isinstance(m, torch.nn.Conv2d)][-1]
+        # damped data-dependent part, so the coded rate lands near a trained model's (~0.5-1.5 bpp)
+        last_hs = conv_of([m for m in h_s if isinstance(m, (torch.nn.Conv2d, DynamicConv2d))][-1])
         last_hs.weight.mul_(0.05)
         last_hs.bias.copy_(torch.exp(torch.rand(last_hs.bias.shape, generator=g) * 1.8 - 1.6))
         # keep the reconstruction in a sane range: small output layer, mid-grey bias
-        g_s = ec.latent_generative_modules["y_x"].model
-        last_gs = g_s[len(g_s) - 1]
+        last_gs = conv_of(g_s[len(g_s) - 1])
         last_gs.weight.mul_(0.05)
         last_gs.bias.fill_(0.5)
     return codec

@@ -212,3 +212,120 @@ def psnr(a, b, max_val=1.0):
     """benchmark/metrics/pytorch_distortion.py:12-15 per image."""
     mse = ((a - b) ** 2).reshape(a.shape[0], -1).mean(1)
     return 20 * math.log10(max_val) - 10 * torch.log10(mse.double())
+
+
+# ============================================================================================
+# Topo-group AR graphs (cfg-3: configs/lossy_latent_graph_topogroup.py:203-244) and the BaSIC
+# slimmable graph (cfg-4: configs/presets/lossy_latent_graph_scalable_ar_models.py:73-197)
+# ============================================================================================
+def run_slimmable(sd, prefix, spec, x, level, out_lists):
+    """SlimmableConv2dPGMModel._forward_slimmable (pgm_layers.py:781-845) in eval mode: DynamicConv2d with
+    W[:co,:ci] (slimmable_layers.py:157-183) and DynamicGDN with the per-width affine (:258-282).
+    spec items: ("conv"|"deconv", stride, k) | ("gdn", inverse) | ("leaky",); out_lists: per conv its channels_list."""
+    ci, conv_i = x.shape[1], 0
+    for i, item in enumerate(spec):
+        key = f"{prefix}.{i}."
+        if item[0] in ("conv", "deconv"):
+            co = out_lists[conv_i][level]
+            conv_i += 1
+            w, b = sd[key + "conv.weight"], sd[key + "conv.bias"]
+            if item[0] == "conv":
+                x = F.conv2d(x, w[:co, :ci].contiguous(), b[:co], stride=item[1], padding=item[2] // 2)
+            else:
+                x = F.conv_transpose2d(x, w[:ci, :co].contiguous(), b[:co], stride=item[1], padding=item[2] // 2, output_padding=item[1] - 1)
+            ci = co
+        elif item[0] == "gdn":
+            C = x.shape[1]
+            rp = lambda v, minimum=0.0: torch.max(v, torch.tensor([(minimum + PEDESTAL) ** 0.5])) ** 2 - torch.tensor([PEDESTAL])
+            beta = rp(sd[key + "beta_scales"][level]) * rp(sd[key + "beta"][:C], 1e-6) + rp(sd[key + "beta_biases"][level])
+            gamma = rp(sd[key + "gamma_scales"][level]) * rp(sd[key + "gamma"][:C, :C]) + rp(sd[key + "gamma_biases"][level])
+            norm = F.conv2d(x * x, gamma.reshape(C, C, 1, 1), beta)
+            x = x * (torch.sqrt(norm) if item[1] else torch.rsqrt(norm))
+        elif item[0] == "leaky":
+            x = F.leaky_relu(x)
+        elif item[0] == "relu":
+            x = F.relu(x)
+    return x
+
+
+class TopoGroupCodecOracle:
+    """Hyperprior transforms + EntropyBottleneck z + topo-group AR Gaussian y-coder (batch 1 streams)."""
+
+    def __init__(self, state_dict, method="checkerboard", channels=192, channel_groups=1, expand_bottleneck=True, use_param_merger=True,
+                 prefix=""):
+        from .pgm_oracle import TopoGroupGaussianOracle
+        self.sd = {k[len(prefix):]: v.detach().float().cpu() for k, v in state_dict.items() if k.startswith(prefix)}
+        self.eb = eb_tables(self.sd, "latent_node_entropy_coders.z.entropy_bottleneck.")
+        self.z_enc, self.z_dec = _coder(*self.eb[:3])
+        ysd = {k[len("latent_node_entropy_coders.y."):]: v for k, v in self.sd.items() if k.startswith("latent_node_entropy_coders.y.")}
+        self.y = TopoGroupGaussianOracle(ysd, channels, channel_groups, method, expand_bottleneck, use_param_merger,
+                                         context_model=any(k.startswith("topo_group_context_model.") for k in ysd))
+
+    def g_a(self, x): return run_sequential(self.sd, "latent_inference_modules.x_y.model", G_A, x)
+    def h_a(self, y): return run_sequential(self.sd, "latent_inference_modules.y_z.model", H_A, y)
+    def h_s(self, z): return run_sequential(self.sd, "latent_generative_modules.z_y.model", H_S, z)
+    def g_s(self, y): return run_sequential(self.sd, "latent_generative_modules.y_x.model", G_S, y)
+
+    def _z(self, z):
+        med = self.eb[3].reshape(1, -1, 1, 1)
+        sym = torch.round(z - med)
+        C = z.shape[1]
+        idx = torch.arange(C, dtype=torch.int32).reshape(1, C, 1, 1).expand_as(sym)
+        strings = [self.z_enc.encode_with_indexes(sym[b].int().numpy(), idx[b].numpy()) for b in range(z.shape[0])]
+        return write_body(z.shape[-2:], strings), sym + med
+
+    def compress(self, x):
+        assert x.shape[0] == 1, "the reference's AR coder writes one stream per call; the oracle follows batch 1"
+        y = self.g_a(x)
+        bz, z_hat = self._z(self.h_a(y))
+        prior = self.h_s(z_hat)
+        by, sym, idx, buf = self.y.encode(y, prior)
+        self.last = dict(y=y, prior=prior, y_sym=sym, y_idx=idx, y_hat=buf)
+        return struct.pack("I", len(bz)) + bz + by
+
+    def decompress(self, data):
+        (nz,) = struct.unpack("I", data[:4])
+        bz, by = data[4:4 + nz], data[4 + nz:]
+        z_strings, zshape = read_body(bz)
+        C = self.eb[3].numel()
+        z_idx = torch.arange(C, dtype=torch.int32).reshape(C, 1, 1).expand(C, *zshape).contiguous().numpy()
+        z_sym = torch.stack([torch.from_numpy(self.z_dec.decode_with_indexes(s, z_idx)) for s in z_strings])
+        z_hat = z_sym.float() + self.eb[3].reshape(1, -1, 1, 1)
+        prior = self.h_s(z_hat)
+        y_hat = self.y.decode(by, prior, (1, self.y.C, prior.shape[2], prior.shape[3]))
+        return self.g_s(y_hat)
+
+
+SL_G_A = [("conv", 2, 5), ("gdn", False), ("conv", 2, 5), ("gdn", False), ("conv", 2, 5), ("gdn", False), ("conv", 2, 5)]
+SL_G_S = [("deconv", 2, 5), ("gdn", True), ("deconv", 2, 5), ("gdn", True), ("deconv", 2, 5), ("gdn", True), ("deconv", 2, 5)]
+SL_MS_H_A = [("conv", 1, 3), ("leaky",), ("conv", 2, 5), ("leaky",), ("conv", 2, 5)]
+SL_MS_H_S = [("deconv", 2, 5), ("leaky",), ("deconv", 2, 5), ("leaky",), ("conv", 1, 3)]
+
+
+class BasicCodecOracle(TopoGroupCodecOracle):
+    """BaSIC graph: slimmable transforms at explicit width levels (level = argmax of the controller one-hot)."""
+
+    def __init__(self, state_dict, widths, M=192, prefix=""):
+        super().__init__(state_dict, method="scanline", channels=M, prefix=prefix)
+        self.widths, self.M = list(widths), M
+        self.levels = dict(xy=len(widths) - 1, yz=len(widths) - 1, zy=len(widths) - 1, yx=len(widths) - 1)
+
+    def set_levels(self, xy, yz, zy, yx):
+        self.levels = dict(xy=xy, yz=yz, zy=zy, yx=yx)
+
+    def g_a(self, x):
+        w, n = self.widths, len(self.widths)
+        return run_slimmable(self.sd, "latent_inference_modules.x_y.pgm_model", SL_G_A, x, self.levels["xy"], [w, w, w, [self.M] * n])
+
+    def h_a(self, y):
+        w, n = self.widths, len(self.widths)
+        return run_slimmable(self.sd, "latent_inference_modules.y_z.pgm_model", SL_MS_H_A, y, self.levels["yz"], [w, w, [self.M] * n])
+
+    def h_s(self, z):
+        w, n = self.widths, len(self.widths)
+        return run_slimmable(self.sd, "latent_generative_modules.z_y.pgm_model", SL_MS_H_S, z, self.levels["zy"],
+                             [w, [c * 3 // 2 for c in w], [2 * self.M] * n])
+
+    def g_s(self, y):
+        w, n = self.widths, len(self.widths)
+        return run_slimmable(self.sd, "latent_generative_modules.y_x.pgm_model", SL_G_S, y, self.levels["yx"], [w, w, w, [3] * n])
