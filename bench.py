@@ -151,16 +151,13 @@ def main():
     dt = time.time() - t0
 
     from cbench_basic_amd.nn import kernels as K
+    from cbench_basic_amd.utils.dist_metrics import reduce_metric_sums
     mse = K.mse_per_image(xhat, x)
     psnr_sum = float((-10 * torch.log10(mse.double())).sum())
-    stats = torch.tensor([dt, float(args.batch * args.steps), float(nbytes), psnr_sum, float(args.batch)], device=dev,
-                         dtype=torch.float64)
-    if dist is not None:
-        tmax = stats[:1].clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(stats, op=dist.ReduceOp.SUM)
-        stats[0] = tmax[0]
-    dt_max, n_img, n_bytes, psnr_tot, n_psnr = [float(v) for v in stats.cpu()]
+    # the ONLY collective of the run: metric sums (analogue of cbench/utils/logging_utils.py:458-465)
+    red = reduce_metric_sums(dict(time_s=dt, images=float(args.batch * args.steps), bytes=float(nbytes), psnr_sum=psnr_sum,
+                                  psnr_n=float(args.batch)), device=dev)
+    dt_max, n_img, n_bytes, psnr_tot, n_psnr = red["time_s"], red["images"], red["bytes"], red["psnr_sum"], red["psnr_n"]
 
     if rank == 0:
         pix = n_img * args.size * args.size

@@ -582,6 +582,145 @@ __global__ __launch_bounds__(64) void rans_decode_kernel(TablesDev T, ArDev ar, 
     if (lane == 0) { state[stream] = x; pos_io[stream] = rd.pos; }
 }
 
+// Fast decoder for the common case (no AR remap, table set resident in LDS, rows <= 4096 entries).
+// The first-level probe of a symbol -- for rows of <= 64 entries the whole row, otherwise the last entry
+// of each of 64 blocks -- depends only on the table row, i.e. on the INDEXES, never on the coder state.
+// It is therefore fetched from LDS two symbols ahead, which takes every memory access of a narrow row off
+// the serial chain: per symbol the chain is compare -> ballot -> two lane broadcasts -> 64-bit multiply-add
+// -> (conditional) next word.
+__global__ __launch_bounds__(64) void rans_decode_fast_kernel(TablesDev T, const uint32_t *__restrict__ words_all,
+                                                              const int64_t *__restrict__ word_off,
+                                                              const int32_t *__restrict__ indexes,
+                                                              const int64_t *__restrict__ seg, int32_t *out_symbols,
+                                                              uint64_t *state, int64_t *pos_io)
+{
+    extern __shared__ uint32_t lds_words[];
+    const uint16_t *lds16 = reinterpret_cast<const uint16_t *>(lds_words);
+    const int stream = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int64_t beg = seg[stream];
+    const int64_t n = seg[stream + 1] - beg;
+    const int32_t *idx = indexes + beg;
+    int32_t *out = out_symbols + beg;
+    {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(T.cdf16);
+        for (int i = lane; i < T.total16 / 2; i += 64) lds_words[i] = src[i];
+        __syncthreads();
+    }
+    WordReader rd;
+    rd.words = words_all + word_off[stream];
+    rd.limit = word_off[stream + 1] - word_off[stream];
+    uint64_t x;
+    const int64_t p0 = pos_io[stream];
+    if (p0 < 0) {
+        rd.pos = 0;
+        rd.fill(lane);
+        const uint32_t w0 = rd.next(lane), w1 = rd.next(lane);
+        x = static_cast<uint64_t>(w0) | (static_cast<uint64_t>(w1) << 32);
+    } else {
+        rd.pos = p0;
+        rd.fill(lane);
+        x = state[stream];
+    }
+    x = uniform_u64(x);
+    const uint32_t prec = static_cast<uint32_t>(T.precision);
+    const uint32_t mask = (1u << prec) - 1u;
+    const uint32_t bprec = static_cast<uint32_t>(T.bypass_precision);
+    const uint32_t maxbv = (1u << bprec) - 1u;
+    const int32_t top = 1 << prec;
+
+    for (int64_t c0 = 0; c0 < n; c0 += 64) {
+        const int64_t i = c0 + lane;
+        int32_t size_l = 2, off_l = 0, base_l = 0;
+        if (i < n) {
+            const int32_t row = clampi(idx[i], 0, T.rows - 1);
+            size_l = T.sizes[row];
+            off_l = T.offsets[row];
+            base_l = T.base[row];
+        }
+        int32_t result = 0;
+        const int cnt = (n - c0) < 64 ? static_cast<int>(n - c0) : 64;
+
+        // this lane's first-level probe value of symbol jj of the chunk
+        auto probe = [&](int jj) -> int32_t {
+            const int32_t sz = static_cast<int32_t>(bcast_u32(static_cast<uint32_t>(size_l), jj));
+            const int32_t rb = static_cast<int32_t>(bcast_u32(static_cast<uint32_t>(base_l), jj));
+            int32_t e = lane;
+            bool live = lane < sz;
+            if (sz > 64) {
+                const int32_t step = (sz + 63) >> 6;
+                e = (lane + 1) * step - 1;
+                if (e > sz - 1) e = sz - 1;
+                live = true;
+            }
+            int32_t v = static_cast<int32_t>(lds16[rb + (live ? e : 0)]);
+            if (e == sz - 1) v = top;  // the final entry 2^precision is implied in the packed copy
+            return live ? v : 0x7FFFFFFF;
+        };
+        auto decode_one = [&](int j, int32_t p) {
+            const int32_t size = static_cast<int32_t>(bcast_u32(static_cast<uint32_t>(size_l), j));
+            const int32_t offset = static_cast<int32_t>(bcast_u32(static_cast<uint32_t>(off_l), j));
+            const uint32_t cf = static_cast<uint32_t>(x) & mask;
+            const uint64_t m = __ballot(static_cast<uint32_t>(p) > cf);
+            const int first = __builtin_ctzll(m);
+            uint32_t c_t, c_s;
+            int32_t s;
+            if (size <= 64) {  // first >= 1 because entry 0 is 0 <= cf
+                c_t = bcast_u32(static_cast<uint32_t>(p), first);
+                c_s = bcast_u32(static_cast<uint32_t>(p), first - 1);
+                s = first - 1;
+            } else {
+                const int32_t rbase = static_cast<int32_t>(bcast_u32(static_cast<uint32_t>(base_l), j));
+                const int32_t step = (size + 63) >> 6;
+                const int32_t lo = first * step;
+                const int32_t span = (lo + step <= size) ? step : (size - lo);
+                int32_t va = 0x7FFFFFFF;
+                if (lane < span) {
+                    va = static_cast<int32_t>(lds16[rbase + lo + lane]);
+                    if (lo + lane == size - 1) va = top;
+                }
+                const uint64_t m2 = __ballot(static_cast<uint32_t>(va) > cf && lane < span);
+                const int tl = __builtin_ctzll(m2);
+                c_t = bcast_u32(static_cast<uint32_t>(va), tl);
+                // entry lo-1 is the last entry of the previous block = that block's probe value
+                c_s = tl > 0 ? bcast_u32(static_cast<uint32_t>(va), tl - 1) : bcast_u32(static_cast<uint32_t>(p), first - 1);
+                s = lo + tl - 1;
+            }
+            const uint32_t freq = c_t - c_s;
+            x = static_cast<uint64_t>(freq) * (x >> prec) + cf - c_s;  // rans64.h:128-142
+            if (x < kRansL) x = (x << 32) | rd.next(lane);
+            int32_t value = s;
+            if (T.bypass && value == size - 2) {
+                uint32_t v = get_raw(x, rd, lane, bprec);
+                uint32_t nb = v;
+                while (v == maxbv) { v = get_raw(x, rd, lane, bprec); nb += v; }
+                uint32_t raw = 0;
+                for (uint32_t k = 0; k < nb; ++k) {
+                    const uint32_t nib = get_raw(x, rd, lane, bprec);
+                    if (k * bprec < 32u) raw |= nib << (k * bprec);
+                }
+                value = static_cast<int32_t>(raw >> 1);
+                if (raw & 1u) value = -value - 1; else value += size - 2;
+            }
+            value += offset;
+            result = (lane == j) ? value : result;
+        };
+
+        int32_t pa = probe(0);
+        int32_t pb = probe(cnt > 1 ? 1 : 0);
+        for (int j = 0; j < cnt; j += 2) {
+            decode_one(j, pa);
+            pa = probe(j + 2 < cnt ? j + 2 : cnt - 1);  // two symbols ahead
+            if (j + 1 < cnt) {
+                decode_one(j + 1, pb);
+                pb = probe(j + 3 < cnt ? j + 3 : cnt - 1);
+            }
+        }
+        if (i < n) out[i] = result;
+    }
+    if (lane == 0) { state[stream] = x; pos_io[stream] = rd.pos; }
+}
+
 // Gather the right-aligned streams of an encode batch into one contiguous buffer.
 __global__ void compact_streams_kernel(const uint32_t *__restrict__ slots, int64_t slot_words,
                                        const int32_t *__restrict__ nwords, const int64_t *__restrict__ out_off,
@@ -640,6 +779,20 @@ int launch_decode(const basic_rans_tables *t, const ArDev &ar, int nstreams, hip
 {
     // LDS-resident tables pay a per-launch copy of the table set; worth it unless the launch is tiny.
     const bool lds = t->cdf16.size() * sizeof(uint16_t) <= kLdsTableBudget;
+    int max_size = 0;
+    for (int v : t->sizes) max_size = v > max_size ? v : max_size;
+    if (!ar.tab && lds && max_size <= 4096) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            BASIC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(rans_decode_fast_kernel),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(rans_decode_fast_kernel, dim3(nstreams), dim3(64), t->cdf16.size() * sizeof(uint16_t), st, dev_view(t),
+                           d_words, d_word_off, d_indexes, d_seg, d_out, d_state, d_pos);
+        BASIC_HIP_TRY(hipGetLastError());
+        return BASIC_OK;
+    }
     if (ar.tab)
         return lds ? launch_decode_v<true, true>(t, ar, nstreams, st, d_words, d_word_off, d_indexes, d_seg, d_out, d_state, d_pos)
                    : launch_decode_v<true, false>(t, ar, nstreams, st, d_words, d_word_off, d_indexes, d_seg, d_out, d_state, d_pos);

@@ -1,0 +1,179 @@
+"""CPU: the C-ABI library loads and exports every declared symbol (no compute), host-side logic of the codec
+mirror (framing, coding schedules, graph traversal with stand-in coders), multi-process sharding over gloo."""
+import ctypes
+import os
+import re
+import struct
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cabi_exports_every_declared_symbol():
+    from cbench_basic_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    hdr = open(os.path.join(ROOT, "include", "basic_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(basic_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(declared) >= 30
+    missing = [n for n in declared if not hasattr(lib, n)]
+    assert not missing, missing
+    assert set(_lib._SIGNATURES) == set(declared)
+    _lib.lib()  # binds argtypes for all of them
+
+
+def test_no_silent_cpu_fallback():
+    """Without a GPU the product refuses to run instead of falling back to a CPU path."""
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from cbench_basic_amd import _lib, ans
+    from cbench_basic_amd.nn import kernels as K
+    with pytest.raises(_lib.BasicHipError):
+        e = ans.Rans64Encoder()
+        e.init_params(np.array([[3, 1]]), np.array([2]), np.array([0]))
+    with pytest.raises(_lib.BasicHipError):
+        K.gc_quantize_index(torch.zeros(4), torch.ones(4), torch.ones(4))
+    # host-only entry point works (table quantisation is host float32 arithmetic)
+    assert ans.pmf_to_quantized_cdf([.1, .2, .7], 16) == [0, 6554, 19661, 65536]
+
+
+def test_write_body_read_body_framing():
+    from cbench_basic_amd.modules.prior_model.prior_coder.compressai_coder import read_body, write_body
+    strings = [[b"abcd"], [b""], [b"\x01" * 9]]
+    data = write_body((4, 6), strings)
+    assert data[:12] == struct.pack(">3I", 4, 6, 3) and data[12:16] == struct.pack(">I", 4)
+    out, shape = read_body(data)
+    assert out == strings and shape == (4, 6)
+
+
+def test_group_plan_matches_boolean_mask_order():
+    """The static element lists reproduce the reference's data[mask] order (pgm_coder.py:886-900)."""
+    from cbench_basic_amd.modules.prior_model.prior_coder.pgm_coder import _GroupPlan, default_topo_groups
+    from oracle.pgm_oracle import TopoGroupGaussianOracle, default_pgm
+    for method, G, C in [("checkerboard", 1, 8), ("channelwise", 4, 8), ("elic", 8, 128), ("scanline", 1, 4), ("raster2x2", 2, 8)]:
+        h, w = 4, 6
+        plan = _GroupPlan(default_topo_groups(method, G, h, w), C, torch.device("cpu"))
+        o = TopoGroupGaussianOracle({}, C, G, method)
+        masks = o.masks(default_pgm(method, G, h, w), (1, C, h, w))
+        assert len(masks) == len(plan.groups)
+        flat = torch.arange(C * h * w).reshape(1, C, h, w)
+        base = 0
+        for m, g in zip(masks, plan.groups):
+            assert torch.equal(flat[m].int(), g["elems"]), method
+            assert g["base"] == base
+            base += g["n"]
+            pos = torch.nonzero(m.reshape(C, -1).any(0)).reshape(-1)
+            assert np.array_equal(pos.numpy(), g["pos_np"])
+        assert plan.per_image == C * h * w
+
+
+def test_latent_graph_traversal_with_standin_coders():
+    """Graph order, prior routing and stream framing of the latent-graph driver, with trivial CPU stand-in nodes."""
+    import torch.nn as nn
+    from cbench_basic_amd.modules.entropy_coder.latent_graph import LatentGraphicalANSEntropyCoder
+    from cbench_basic_amd.utils.bytes_ops import split_merged_bytes
+    log = []
+
+    class Edge(nn.Module):
+        def __init__(self, name, f):
+            super().__init__()
+            self.name, self.f = name, f
+
+        def forward(self, x, **kw):
+            log.append((self.name, tuple(sorted(kw))))
+            return self.f(x)
+
+    class Coder(nn.Module):
+        def __init__(self, name):
+            super().__init__()
+            self.name = name
+
+        def forward(self, x, prior=None, **kw):
+            log.append((self.name + ".fwd", prior is not None))
+            return torch.round(x)
+
+        def encode(self, x, prior=None, **kw):
+            log.append((self.name + ".enc", prior is not None))
+            return torch.round(x).to(torch.int8).numpy().tobytes()
+
+        def decode(self, b, prior=None, **kw):
+            log.append((self.name + ".dec", prior is not None))
+            return torch.from_numpy(np.frombuffer(b, np.int8).astype(np.float32)).reshape(1, -1)
+
+        def update_state(self):
+            log.append((self.name + ".update",))
+
+    ec = LatentGraphicalANSEntropyCoder(
+        latent_node_inference_topo_order=["x", "y", "z"], latent_node_generative_topo_order=["z", "y", "x"],
+        latent_node_entropy_coder_dict=dict(y=Coder("y"), z=Coder("z")),
+        latent_inference_dict=dict(x_y=Edge("g_a", lambda t: t * 2), y_z=Edge("h_a", lambda t: t[:, :2] + 1)),
+        latent_generative_dict=dict(z_y=Edge("h_s", lambda t: t.repeat(1, 2)), y_x=Edge("g_s", lambda t: t / 2)),
+    ).eval()
+    ec.update_state()
+    x = torch.tensor([[1.0, 2.0, 3.0, 4.0]])
+    data = ec.encode(x)
+    zb, yb = split_merged_bytes(data, num_segments=2)
+    assert np.frombuffer(zb, np.int8).tolist() == [3, 5] and np.frombuffer(yb, np.int8).tolist() == [2, 4, 6, 8]
+    assert data[:4] == struct.pack("I", 2)
+    xhat = ec.decode(data)
+    assert torch.equal(xhat, x)
+    names = [l[0] for l in log]
+    assert names == ["y.update", "z.update", "g_a", "h_a", "z.fwd", "z.enc", "h_s", "y.fwd", "y.enc", "z.dec", "h_s", "y.dec", "g_s"]
+    assert ("y.enc", True) in log and ("z.enc", False) in log  # y is coded with the h_s prior, z unconditionally
+
+
+def test_default_ladder_and_node_generators():
+    from cbench_basic_amd.presets import basic_default_ladder
+    from cbench_basic_amd.nn.layers.param_generator import IndexSelectParameterGeneratorWrapper, NNParameterGenerator
+    lad = basic_default_ladder(5, 8)
+    assert len(lad) == 8 and lad[0] == dict(pgmyx=4, pgmxy=4, pgmzy=4, pgmyz=4) and all(v == 0 for v in lad[-1].values())
+    gen = IndexSelectParameterGeneratorWrapper(
+        NNParameterGenerator((5, 1, 1, 5), init_method="value", init_value=torch.eye(5).flip(-1).unsqueeze(1).unsqueeze(1), fix_params=True),
+        fix_for_inference=True).eval()
+    assert gen().reshape(-1).tolist() == [0, 0, 0, 0, 1]       # default index 0 -> widest (level 4)
+    assert gen(index=4).reshape(-1).argmax().item() == 0         # index 4 -> narrowest (level 0)
+
+
+_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from cbench_basic_amd.utils.dist_metrics import shard_indices, reduce_metric_sums, gather_per_image
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+n = 11
+mine = shard_indices(n, rank, world)
+sums = dict(count=len(mine), bytes=sum(100 + i for i in mine), psnr_sum=sum(30.0 + 0.5 * i for i in mine), time_s=1.0 + rank)
+red = reduce_metric_sums(sums)
+assert red["count"] == n and red["bytes"] == sum(100 + i for i in range(n)) and red["time_s"] == float(world)
+assert abs(red["psnr_sum"] - sum(30.0 + 0.5 * i for i in range(n))) < 1e-9
+per = torch.tensor([[100.0 + i, 30.0 + 0.5 * i] for i in mine], dtype=torch.float64).reshape(len(mine), 2)
+full = gather_per_image(per, n, rank, world)
+assert full[:, 0].tolist() == [100.0 + i for i in range(n)]
+if rank == 0:
+    print("GLOO_OK", red["count"])
+dist.destroy_process_group()
+"""
+
+
+def test_sharding_and_metric_reduction_gloo_world2(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29531", str(script), ROOT], capture_output=True, text=True, env=env, timeout=240)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "GLOO_OK 11" in r.stdout
+
+
+def test_shard_indices_cover_everything():
+    from cbench_basic_amd.utils.dist_metrics import shard_indices
+    for n, w in [(256, 8), (24, 8), (5, 8), (0, 2), (7, 1)]:
+        allidx = sorted(i for r in range(w) for i in shard_indices(n, r, w))
+        assert allidx == list(range(n))
