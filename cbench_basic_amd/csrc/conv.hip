@@ -39,6 +39,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kCKConv = 4;    // input channels per LDS stage for many-tap layers (5x5 conv: 25 taps)
 constexpr int kCKFew = 8;     // ... and for few-tap launches (3x3 conv, sub-pixel phases of the 5x5 deconv: <= 9 taps)
 constexpr int kFewTaps = 9;
+constexpr int kCKVeryFew = 16;  // ... and for <= 6 taps (3 of the 4 sub-pixel phases)
+constexpr int kVeryFewTaps = 6;
 constexpr int kMaxTaps = 25;  // 5x5
 constexpr int kThreads = 256;
 constexpr int kTilePos = 128;  // output positions per workgroup
@@ -140,7 +142,7 @@ __global__ __launch_bounds__(kThreads, (MT <= 4 ? 2 : 1)) void conv_tap_mfma_ker
         ge[sl] = e;
     }
 
-    constexpr int kStageTaps = (kCK == kCKConv) ? kMaxTaps : kFewTaps;
+    constexpr int kStageTaps = (kCK == kCKConv) ? kMaxTaps : (kCK == kCKFew ? kFewTaps : kVeryFewTaps);
     constexpr int kWSlots = (kStageTaps * kCK * 32 * MT / 4 + kThreads - 1) / kThreads;
     f32x4 wreg[kWSlots];
     float preg[kPSlots];
@@ -221,7 +223,11 @@ __global__ __launch_bounds__(kThreads, (MT <= 4 ? 2 : 1)) void conv_tap_mfma_ker
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][r] += g.bias[32 * m + 8 * (r >> 2) + 4 * khalf + (r & 3)];
+            for (int rq = 0; rq < 4; ++rq) {  // registers 4rq..4rq+3 are 4 consecutive channels: one 16-byte load
+                const f32x4 b4 = *reinterpret_cast<const f32x4 *>(g.bias + 32 * m + 8 * rq + 4 * khalf);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[m][4 * rq + e] += b4[e];
+            }
     }
 
     if (g.act == BASIC_ACT_GDN || g.act == BASIC_ACT_IGDN) {
@@ -231,15 +237,33 @@ __global__ __launch_bounds__(kThreads, (MT <= 4 ? 2 : 1)) void conv_tap_mfma_ker
         for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int r = 0; r < 16; ++r) nrm[m][r] = 0.f;
+        // gamma^T is walked 32 k-rows at a time through the (now free) weight slab; the next 32 rows are
+        // prefetched through registers while the MFMAs of the current ones run.
+        constexpr int kGSlots = (32 * 32 * MT / 4 + kThreads - 1) / kThreads;
+        f32x4 greg[kGSlots];
+        const int gam_vec = gam_floats / 4;
+#define BASIC_FETCH_GAMMA(MK)                                                                                   \
+    do {                                                                                                       \
+        const f32x4 *src_ = reinterpret_cast<const f32x4 *>(g.gammaT + static_cast<int64_t>(MK) * 32 * g.coutp); \
+        _Pragma("unroll") for (int sl = 0; sl < kGSlots; ++sl) {                                               \
+            const int i_ = tid + sl * kThreads;                                                                \
+            if (i_ < gam_vec) greg[sl] = src_[i_];                                                             \
+        }                                                                                                      \
+    } while (0)
+        BASIC_FETCH_GAMMA(0);
 #pragma unroll
         for (int mk = 0; mk < MT; ++mk) {  // k rows 32mk .. 32mk+31
             __syncthreads();
             {
-                const float4 *src = reinterpret_cast<const float4 *>(g.gammaT + static_cast<int64_t>(mk) * 32 * g.coutp);
-                float4 *dst = reinterpret_cast<float4 *>(wl);
-                for (int i = tid; i < gam_floats / 4; i += kThreads) dst[i] = src[i];
+                f32x4 *dst = reinterpret_cast<f32x4 *>(wl);
+#pragma unroll
+                for (int sl = 0; sl < kGSlots; ++sl) {
+                    const int i = tid + sl * kThreads;
+                    if (i < gam_vec) dst[i] = greg[sl];
+                }
             }
             __syncthreads();
+            if (mk + 1 < MT) BASIC_FETCH_GAMMA(mk + 1);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float x = acc[mk][r];
@@ -253,10 +277,16 @@ __global__ __launch_bounds__(kThreads, (MT <= 4 ? 2 : 1)) void conv_tap_mfma_ker
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float nv = nrm[m][r] + g.beta[32 * m + 8 * (r >> 2) + 4 * khalf + (r & 3)];
-                const float s = sqrtf(nv);
-                acc[m][r] = (g.act == BASIC_ACT_GDN) ? acc[m][r] / s : acc[m][r] * s;
+            for (int rq = 0; rq < 4; ++rq) {
+                const f32x4 b4 = *reinterpret_cast<const f32x4 *>(g.beta + 32 * m + 8 * rq + 4 * khalf);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * rq + e;
+                    const float nv = nrm[m][r] + b4[e];
+                    // v_rsq_f32 / v_sqrt_f32 (1 ulp) instead of the ~10-instruction IEEE division / sqrt sequences:
+                    // 64 of them per lane would cost as much VALU time as dozens of MFMAs
+                    acc[m][r] *= (g.act == BASIC_ACT_GDN) ? __builtin_amdgcn_rsqf(nv) : __builtin_amdgcn_sqrtf(nv);
+                }
             }
     }
 
@@ -283,46 +313,53 @@ __global__ __launch_bounds__(kThreads, (MT <= 4 ? 2 : 1)) void conv_tap_mfma_ker
 // position and produces its 2x2 output pixels x Cout: per input channel 9 LDS reads (the 3x3
 // neighbourhood) feed all 25 taps x Cout FMAs, with the weights as wave-uniform scalar operands.
 // ---------------------------------------------------------------------------------------------
-constexpr int kSmTile = 16;               // 16 x 16 input positions per workgroup
-constexpr int kSmCK = 16;                 // input channels per LDS stage
-constexpr int kSmPatch = kSmTile + 2;     // +-1 halo
+constexpr int kSmTileH = 16;              // input positions per workgroup: 16 rows x 64 columns,
+constexpr int kSmTileW = 64;              // one lane = a 1 x 4 strip -> 2 x 8 output pixels x Cout
+constexpr int kSmCK = 8;                  // input channels per LDS stage
+constexpr int kSmPH = kSmTileH + 2;       // +-1 halo
+constexpr int kSmPW = kSmTileW + 2;
+constexpr int kSmPitch = 68;              // row pitch in floats (16-byte multiple: aligned ds_read_b128)
+constexpr int kSmWRow = 80;               // packed weights per input channel: 25 taps x 3, padded to 5 x 16
 
 struct SmallLaunch {
     const float *in;      // [B][cin][H][W]
     float *out;           // [B][cout][2H][2W]
-    const float *wsm;     // [cin][25][4]   W[ci][co][ky][kx] -> [ci][ky*5+kx][co], zero padded to 4
+    const float *wsm;     // [cin][80]   W[ci][co][ky][kx] -> [ci][(ky*5+kx)*3 + co], zero padded
     const float *bias;    // [4]
     int batch, cin, cout, in_h, in_w, tiles_y, tiles_x, act;
 };
 
-template <int COUT>
-__global__ __launch_bounds__(256) void deconv5s2_small_cout_kernel(const SmallLaunch g)
+typedef float f32x16s __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(256) void deconv5s2_cout3_kernel(const SmallLaunch g)
 {
-    __shared__ float patch[kSmCK][kSmPatch][kSmPatch + 1];
+    __shared__ __attribute__((aligned(16))) float patch[kSmCK][kSmPH][kSmPitch];
     const int tid = threadIdx.x;
     int bid = blockIdx.x;
     const int tx_i = bid % g.tiles_x; bid /= g.tiles_x;
     const int ty_i = bid % g.tiles_y; bid /= g.tiles_y;
     const int b = bid;
-    const int lx = tid & (kSmTile - 1), ly = tid >> 4;
-    const int my = ty_i * kSmTile + ly, mx = tx_i * kSmTile + lx;
+    const int lxq = tid & 15, ly = tid >> 4;
+    const int my = ty_i * kSmTileH + ly, mx0 = tx_i * kSmTileW + 4 * lxq;
     const int64_t plane = static_cast<int64_t>(g.in_h) * g.in_w;
     const float *inb = g.in + static_cast<int64_t>(b) * g.cin * plane;
 
-    float acc[2][2][COUT];
+    float acc[4][2][2][3];  // [position in strip][py][px][co]
 #pragma unroll
-    for (int py = 0; py < 2; ++py)
+    for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int px = 0; px < 2; ++px)
+        for (int py = 0; py < 2; ++py)
 #pragma unroll
-            for (int co = 0; co < COUT; ++co) acc[py][px][co] = 0.f;
+            for (int px = 0; px < 2; ++px)
+#pragma unroll
+                for (int co = 0; co < 3; ++co) acc[q][py][px][co] = 0.f;
 
     for (int c0 = 0; c0 < g.cin; c0 += kSmCK) {
         __syncthreads();
-        for (int i = tid; i < kSmCK * kSmPatch * kSmPatch; i += 256) {
-            const int px = i % kSmPatch, r = i / kSmPatch;
-            const int py = r % kSmPatch, ci = r / kSmPatch;
-            const int gy = ty_i * kSmTile - 1 + py, gx = tx_i * kSmTile - 1 + px, c = c0 + ci;
+        for (int i = tid; i < kSmCK * kSmPH * kSmPW; i += 256) {
+            const int px = i % kSmPW, r = i / kSmPW;
+            const int py = r % kSmPH, ci = r / kSmPH;
+            const int gy = ty_i * kSmTileH - 1 + py, gx = tx_i * kSmTileW - 1 + px, c = c0 + ci;
             float v = 0.f;
             if (gy >= 0 && gy < g.in_h && gx >= 0 && gx < g.in_w && c < g.cin) v = inb[c * plane + gy * g.in_w + gx];
             patch[ci][py][px] = v;
@@ -330,12 +367,19 @@ __global__ __launch_bounds__(256) void deconv5s2_small_cout_kernel(const SmallLa
         __syncthreads();
         const int cmax = (g.cin - c0 < kSmCK) ? g.cin - c0 : kSmCK;
         for (int ci = 0; ci < cmax; ++ci) {
-            float v[3][3];
+            // 3 x 6 neighbourhood of the strip: one aligned 16-byte + one 8-byte LDS read per row
+            float v[3][6];
 #pragma unroll
-            for (int a = 0; a < 3; ++a)
-#pragma unroll
-                for (int c = 0; c < 3; ++c) v[a][c] = patch[ci][ly + a][lx + c];
-            const float *w = g.wsm + static_cast<int64_t>(c0 + ci) * 100;  // wave-uniform -> scalar loads
+            for (int a = 0; a < 3; ++a) {
+                const float *row = &patch[ci][ly + a][4 * lxq];
+                const f32x4 lo = *reinterpret_cast<const f32x4 *>(row);
+                const float2 hi = *reinterpret_cast<const float2 *>(row + 4);
+                v[a][0] = lo[0]; v[a][1] = lo[1]; v[a][2] = lo[2]; v[a][3] = lo[3]; v[a][4] = hi.x; v[a][5] = hi.y;
+            }
+            // 75 weights of this input channel as wave-uniform scalars (5 x s_load_dwordx16)
+            const f32x16s *w16 = reinterpret_cast<const f32x16s *>(g.wsm + static_cast<int64_t>(c0 + ci) * kSmWRow);
+            const f32x16s w0 = w16[0], w1 = w16[1], w2 = w16[2], w3 = w16[3], w4 = w16[4];
+#define BASIC_SM_W(I) ((I) < 16 ? w0[(I) & 15] : (I) < 32 ? w1[(I) & 15] : (I) < 48 ? w2[(I) & 15] : (I) < 64 ? w3[(I) & 15] : w4[(I) & 15])
 #pragma unroll
             for (int ky = 0; ky < 5; ++ky)
 #pragma unroll
@@ -343,27 +387,33 @@ __global__ __launch_bounds__(256) void deconv5s2_small_cout_kernel(const SmallLa
                     // output row 2*my + py receives input row my + dy through ky = py + 2 - 2*dy
                     const int py = ky & 1, px = kx & 1;
                     const int dy = (py + 2 - ky) / 2, dx = (px + 2 - kx) / 2;  // in {-1, 0, 1}
-                    const float x = v[dy + 1][dx + 1];
 #pragma unroll
-                    for (int co = 0; co < COUT; ++co)
-                        acc[py][px][co] = fmaf(x, w[(ky * 5 + kx) * 4 + co], acc[py][px][co]);
+                    for (int co = 0; co < 3; ++co) {
+                        const float w = BASIC_SM_W((ky * 5 + kx) * 3 + co);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) acc[q][py][px][co] = fmaf(v[dy + 1][q + dx + 1], w, acc[q][py][px][co]);
+                    }
                 }
+#undef BASIC_SM_W
         }
     }
-    if (my < g.in_h && mx < g.in_w) {
+    if (my < g.in_h) {
         const int oh = 2 * g.in_h, ow = 2 * g.in_w;
 #pragma unroll
-        for (int co = 0; co < COUT; ++co) {
+        for (int co = 0; co < 3; ++co) {
             if (co >= g.cout) break;
             const float bv = g.bias[co];
-            float *o = g.out + (static_cast<int64_t>(b) * g.cout + co) * oh * ow + static_cast<int64_t>(2 * my) * ow + 2 * mx;
+            float *o = g.out + (static_cast<int64_t>(b) * g.cout + co) * oh * ow + static_cast<int64_t>(2 * my) * ow + 2 * mx0;
 #pragma unroll
-            for (int py = 0; py < 2; ++py) {
-                float2 r;
-                r.x = apply_act(acc[py][0][co] + bv, g.act);
-                r.y = apply_act(acc[py][1][co] + bv, g.act);
-                *reinterpret_cast<float2 *>(o + py * ow) = r;
-            }
+            for (int py = 0; py < 2; ++py)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (mx0 + q >= g.in_w) break;
+                    float2 r;
+                    r.x = apply_act(acc[q][py][0][co] + bv, g.act);
+                    r.y = apply_act(acc[q][py][1][co] + bv, g.act);
+                    *reinterpret_cast<float2 *>(o + py * ow + 2 * q) = r;
+                }
         }
     }
 }
@@ -442,12 +492,12 @@ extern "C" int basic_conv_plan_create(const float *weight, const float *bias, in
     p->s_in = transposed ? 1 : stride;
     p->s_out = transposed ? stride : 1;
 
-    if (transposed && ksize == 5 && stride == 2 && padding == 2 && output_padding == 1 && co_n <= 4 && !gdn) {
-        std::vector<float> ws(static_cast<size_t>(ci_n) * 100, 0.f), b4(4, 0.f);
+    if (transposed && ksize == 5 && stride == 2 && padding == 2 && output_padding == 1 && co_n <= 3 && !gdn) {
+        std::vector<float> ws(static_cast<size_t>(ci_n) * kSmWRow, 0.f), b4(4, 0.f);
         for (int c = 0; c < ci_n; ++c)
             for (int o = 0; o < co_n; ++o)
                 for (int t = 0; t < 25; ++t)
-                    ws[(static_cast<size_t>(c) * 25 + t) * 4 + o] = weight[(static_cast<size_t>(c) * cout + o) * 25 + t];
+                    ws[static_cast<size_t>(c) * kSmWRow + t * 3 + o] = weight[(static_cast<size_t>(c) * cout + o) * 25 + t];
         if (bias) std::memcpy(b4.data(), bias, sizeof(float) * co_n);
         rc = upload(ws, &p->d_wsm);
         if (!rc) rc = upload(b4, &p->d_bias4);
@@ -496,7 +546,7 @@ extern "C" int basic_conv_plan_create(const float *weight, const float *bias, in
                         ++ph.ntaps;
                     }
                 // ---- pack weights: [cin_pad/CK][ntaps][CK][coutp]
-                const int kCK = ph.ntaps <= kFewTaps ? kCKFew : kCKConv;
+                const int kCK = ph.ntaps <= kVeryFewTaps ? kCKVeryFew : (ph.ntaps <= kFewTaps ? kCKFew : kCKConv);
                 ph.ck = kCK;
                 ph.cin_pad = (ci_n + kCK - 1) / kCK * kCK;
                 std::vector<float> wp(static_cast<size_t>(ph.cin_pad) * ph.ntaps * ch.coutp, 0.f);
@@ -584,6 +634,7 @@ int launch_one(const TapLaunch &g, int blocks, size_t lds_bytes, hipStream_t st)
 template <int MT>
 int launch_mt(const TapLaunch &g, int ck, int blocks, size_t lds_bytes, hipStream_t st)
 {
+    if (ck == kCKVeryFew) return launch_one<MT, kCKVeryFew>(g, blocks, lds_bytes, st);
     return ck == kCKFew ? launch_one<MT, kCKFew>(g, blocks, lds_bytes, st) : launch_one<MT, kCKConv>(g, blocks, lds_bytes, st);
 }
 
@@ -603,13 +654,10 @@ extern "C" int basic_conv_forward_dev(const basic_conv_plan *p, const float *d_i
         SmallLaunch g{};
         g.in = d_in; g.out = d_out; g.wsm = p->d_wsm; g.bias = p->d_bias4;
         g.batch = batch; g.cin = p->cin; g.cout = p->cout; g.in_h = in_h; g.in_w = in_w; g.act = p->act;
-        g.tiles_y = (in_h + kSmTile - 1) / kSmTile;
-        g.tiles_x = (in_w + kSmTile - 1) / kSmTile;
+        g.tiles_y = (in_h + kSmTileH - 1) / kSmTileH;
+        g.tiles_x = (in_w + kSmTileW - 1) / kSmTileW;
         const int blocks = batch * g.tiles_y * g.tiles_x;
-        if (p->cout <= 3)
-            hipLaunchKernelGGL(deconv5s2_small_cout_kernel<3>, dim3(blocks), dim3(256), 0, as_stream(hip_stream), g);
-        else
-            hipLaunchKernelGGL(deconv5s2_small_cout_kernel<4>, dim3(blocks), dim3(256), 0, as_stream(hip_stream), g);
+        hipLaunchKernelGGL(deconv5s2_cout3_kernel, dim3(blocks), dim3(256), 0, as_stream(hip_stream), g);
         BASIC_HIP_TRY(hipGetLastError());
         return BASIC_OK;
     }

@@ -38,6 +38,13 @@ struct basic_rans_tables {
     std::vector<int32_t> base;
     uint16_t *d_cdf16 = nullptr;
     int32_t *d_base = nullptr;
+    // Search image of the fast decoder (uint32, copied to LDS by every workgroup): per row a 64-entry
+    // first-level probe vector -- rows of <= 64 entries: the row itself padded with INT_MAX; wider rows:
+    // the last entry of each of 64 blocks -- followed, for wide rows, by the full row.
+    // meta[r] = image offset (dwords) | size << 18   (size <= 4096, image <= 2^18 dwords)
+    std::vector<uint32_t> image, meta;
+    uint32_t *d_image = nullptr, *d_meta = nullptr;
+    bool fast_ok = false;
 };
 
 namespace {
@@ -97,6 +104,34 @@ int upload_tables(basic_rans_tables *t)
     BASIC_HIP_TRY(hipMalloc(&t->d_base, t->base.size() * sizeof(int32_t)));
     BASIC_HIP_TRY(hipMemcpy(t->d_cdf16, t->cdf16.data(), t->cdf16.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     BASIC_HIP_TRY(hipMemcpy(t->d_base, t->base.data(), t->base.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    // fast-decoder image
+    t->image.clear();
+    t->meta.resize(t->rows);
+    t->fast_ok = true;
+    for (int r = 0; r < t->rows; ++r) {
+        const int size = t->sizes[r];
+        const int32_t *row = &t->cdfs[static_cast<size_t>(r) * t->stride];
+        if (size > 4096) { t->fast_ok = false; break; }
+        t->meta[r] = static_cast<uint32_t>(t->image.size()) | (static_cast<uint32_t>(size) << 18);
+        if (size <= 64) {
+            for (int l = 0; l < 64; ++l) t->image.push_back(l < size ? static_cast<uint32_t>(row[l]) : 0x7FFFFFFFu);
+        } else {
+            const int step = (size + 63) >> 6;
+            for (int l = 0; l < 64; ++l) {
+                int e = (l + 1) * step - 1;
+                if (e > size - 1) e = size - 1;
+                t->image.push_back(static_cast<uint32_t>(row[e]));
+            }
+            for (int j = 0; j < size; ++j) t->image.push_back(static_cast<uint32_t>(row[j]));
+        }
+    }
+    if (t->image.size() * 4 > 144 * 1024 || t->image.size() >= (1u << 18)) t->fast_ok = false;
+    if (t->fast_ok) {
+        BASIC_HIP_TRY(hipMalloc(&t->d_image, t->image.size() * sizeof(uint32_t)));
+        BASIC_HIP_TRY(hipMalloc(&t->d_meta, t->meta.size() * sizeof(uint32_t)));
+        BASIC_HIP_TRY(hipMemcpy(t->d_image, t->image.data(), t->image.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        BASIC_HIP_TRY(hipMemcpy(t->d_meta, t->meta.data(), t->meta.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
     return BASIC_OK;
 }
 
@@ -233,6 +268,8 @@ extern "C" void basic_rans_tables_destroy(basic_rans_tables *t)
     if (t->d_ar) (void)hipFree(t->d_ar);
     if (t->d_cdf16) (void)hipFree(t->d_cdf16);
     if (t->d_base) (void)hipFree(t->d_base);
+    if (t->d_image) (void)hipFree(t->d_image);
+    if (t->d_meta) (void)hipFree(t->d_meta);
     delete t;
 }
 
@@ -249,6 +286,8 @@ struct TablesDev {
     const uint16_t *cdf16;  // packed rows (see basic_rans_tables)
     const int32_t *base;
     int total16;            // entries in cdf16 (even)
+    const uint32_t *image, *meta;  // fast-decoder search image (see basic_rans_tables)
+    int image_words;
 };
 
 struct ArDev {
@@ -582,132 +621,135 @@ __global__ __launch_bounds__(64) void rans_decode_kernel(TablesDev T, ArDev ar, 
     if (lane == 0) { state[stream] = x; pos_io[stream] = rd.pos; }
 }
 
-// Fast decoder for the common case (no AR remap, table set resident in LDS, rows <= 4096 entries).
-// The first-level probe of a symbol -- for rows of <= 64 entries the whole row, otherwise the last entry
-// of each of 64 blocks -- depends only on the table row, i.e. on the INDEXES, never on the coder state.
-// It is therefore fetched from LDS two symbols ahead, which takes every memory access of a narrow row off
-// the serial chain: per symbol the chain is compare -> ballot -> two lane broadcasts -> 64-bit multiply-add
-// -> (conditional) next word.
+// Fast decoder for the common case (no AR remap, search image resident in LDS, rows <= 4096 entries).
+// A single wavefront issues roughly one instruction every 4-5 cycles, so the serial loop is bound by its
+// INSTRUCTION COUNT.  Everything that does not depend on the coder state is therefore moved out of it:
+//   * the first-level probe of a symbol (rows <= 64 entries: the whole row) depends only on the table row,
+//     so it is read from LDS two symbols ahead with one broadcast + one add + one ds_read;
+//   * offsets are added lane-parallel after the chunk; row size / image offset travel in one packed word;
+//   * stream words are handed out from a 64-word register cache with 32-bit cursors.
+// Per narrow-row symbol the chain is: mask, compare, ballot, two lane broadcasts, 64-bit multiply-add,
+// (rare) renormalisation.
 __global__ __launch_bounds__(64) void rans_decode_fast_kernel(TablesDev T, const uint32_t *__restrict__ words_all,
                                                               const int64_t *__restrict__ word_off,
                                                               const int32_t *__restrict__ indexes,
                                                               const int64_t *__restrict__ seg, int32_t *out_symbols,
                                                               uint64_t *state, int64_t *pos_io)
 {
-    extern __shared__ uint32_t lds_words[];
-    const uint16_t *lds16 = reinterpret_cast<const uint16_t *>(lds_words);
+    extern __shared__ uint32_t img[];
     const int stream = blockIdx.x;
     const int lane = threadIdx.x;
     const int64_t beg = seg[stream];
-    const int64_t n = seg[stream + 1] - beg;
+    const int n = static_cast<int>(seg[stream + 1] - beg);
     const int32_t *idx = indexes + beg;
     int32_t *out = out_symbols + beg;
+    for (int i = lane; i < T.image_words; i += 64) img[i] = T.image[i];
+    __syncthreads();
+
+    const uint32_t *words = words_all + word_off[stream];
+    const int limit = static_cast<int>(word_off[stream + 1] - word_off[stream]);
+    int pos, wbase;          // next word / first cached word (uniform)
+    uint32_t cache;          // lane k holds word wbase + k
+    uint32_t xl, xh;         // coder state, uniform
     {
-        const uint32_t *src = reinterpret_cast<const uint32_t *>(T.cdf16);
-        for (int i = lane; i < T.total16 / 2; i += 64) lds_words[i] = src[i];
-        __syncthreads();
+        const int64_t p0 = pos_io[stream];
+        pos = p0 < 0 ? 2 : static_cast<int>(p0);
+        wbase = pos & ~63;
+        cache = (wbase + lane < limit) ? words[wbase + lane] : 0u;
+        if (p0 < 0) {
+            // the head words may sit in an earlier cache line only when pos >= 64, which cannot happen for pos = 2
+            xl = bcast_u32(cache, 0);
+            xh = bcast_u32(cache, 1);
+        } else {
+            const uint64_t x0 = state[stream];
+            xl = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(x0));
+            xh = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(x0 >> 32));
+        }
     }
-    WordReader rd;
-    rd.words = words_all + word_off[stream];
-    rd.limit = word_off[stream + 1] - word_off[stream];
-    uint64_t x;
-    const int64_t p0 = pos_io[stream];
-    if (p0 < 0) {
-        rd.pos = 0;
-        rd.fill(lane);
-        const uint32_t w0 = rd.next(lane), w1 = rd.next(lane);
-        x = static_cast<uint64_t>(w0) | (static_cast<uint64_t>(w1) << 32);
-    } else {
-        rd.pos = p0;
-        rd.fill(lane);
-        x = state[stream];
-    }
-    x = uniform_u64(x);
     const uint32_t prec = static_cast<uint32_t>(T.precision);
     const uint32_t mask = (1u << prec) - 1u;
     const uint32_t bprec = static_cast<uint32_t>(T.bypass_precision);
     const uint32_t maxbv = (1u << bprec) - 1u;
-    const int32_t top = 1 << prec;
+    const bool bypass = T.bypass != 0;
 
-    for (int64_t c0 = 0; c0 < n; c0 += 64) {
-        const int64_t i = c0 + lane;
-        int32_t size_l = 2, off_l = 0, base_l = 0;
+    auto next_word = [&]() -> uint32_t {
+        if (pos - wbase >= 64) {
+            wbase = pos & ~63;
+            cache = (wbase + lane < limit) ? words[wbase + lane] : 0u;
+        }
+        const uint32_t w = bcast_u32(cache, pos - wbase);
+        ++pos;
+        return w;
+    };
+    auto get_bits = [&](uint32_t nbits) -> uint32_t {  // Rans64DecGetBits, rans64.cpp:49-65
+        const uint32_t v = xl & ((1u << nbits) - 1u);
+        xl = (xl >> nbits) | (xh << (32u - nbits));
+        xh >>= nbits;
+        if (xh == 0u && xl < 0x80000000u) { xh = xl; xl = next_word(); }
+        return v;
+    };
+
+    for (int c0 = 0; c0 < n; c0 += 64) {
+        const int i = c0 + lane;
+        uint32_t meta_l = 2u << 18;
+        int32_t off_l = 0;
         if (i < n) {
             const int32_t row = clampi(idx[i], 0, T.rows - 1);
-            size_l = T.sizes[row];
+            meta_l = T.meta[row];
             off_l = T.offsets[row];
-            base_l = T.base[row];
         }
         int32_t result = 0;
-        const int cnt = (n - c0) < 64 ? static_cast<int>(n - c0) : 64;
+        const int cnt = (n - c0) < 64 ? (n - c0) : 64;
 
-        // this lane's first-level probe value of symbol jj of the chunk
-        auto probe = [&](int jj) -> int32_t {
-            const int32_t sz = static_cast<int32_t>(bcast_u32(static_cast<uint32_t>(size_l), jj));
-            const int32_t rb = static_cast<int32_t>(bcast_u32(static_cast<uint32_t>(base_l), jj));
-            int32_t e = lane;
-            bool live = lane < sz;
-            if (sz > 64) {
-                const int32_t step = (sz + 63) >> 6;
-                e = (lane + 1) * step - 1;
-                if (e > sz - 1) e = sz - 1;
-                live = true;
-            }
-            int32_t v = static_cast<int32_t>(lds16[rb + (live ? e : 0)]);
-            if (e == sz - 1) v = top;  // the final entry 2^precision is implied in the packed copy
-            return live ? v : 0x7FFFFFFF;
-        };
-        auto decode_one = [&](int j, int32_t p) {
-            const int32_t size = static_cast<int32_t>(bcast_u32(static_cast<uint32_t>(size_l), j));
-            const int32_t offset = static_cast<int32_t>(bcast_u32(static_cast<uint32_t>(off_l), j));
-            const uint32_t cf = static_cast<uint32_t>(x) & mask;
-            const uint64_t m = __ballot(static_cast<uint32_t>(p) > cf);
-            const int first = __builtin_ctzll(m);
+        auto probe = [&](int jj) -> uint32_t { return img[(bcast_u32(meta_l, jj) & 0x3FFFFu) + lane]; };
+        auto decode_one = [&](int j, uint32_t p) {
+            const uint32_t meta = bcast_u32(meta_l, j);
+            const int32_t size = static_cast<int32_t>(meta >> 18);
+            const uint32_t cf = xl & mask;
+            const int first = __builtin_ctzll(__ballot(p > cf));
             uint32_t c_t, c_s;
             int32_t s;
             if (size <= 64) {  // first >= 1 because entry 0 is 0 <= cf
-                c_t = bcast_u32(static_cast<uint32_t>(p), first);
-                c_s = bcast_u32(static_cast<uint32_t>(p), first - 1);
+                c_t = bcast_u32(p, first);
+                c_s = bcast_u32(p, first - 1);
                 s = first - 1;
             } else {
-                const int32_t rbase = static_cast<int32_t>(bcast_u32(static_cast<uint32_t>(base_l), j));
                 const int32_t step = (size + 63) >> 6;
                 const int32_t lo = first * step;
                 const int32_t span = (lo + step <= size) ? step : (size - lo);
-                int32_t va = 0x7FFFFFFF;
-                if (lane < span) {
-                    va = static_cast<int32_t>(lds16[rbase + lo + lane]);
-                    if (lo + lane == size - 1) va = top;
-                }
-                const uint64_t m2 = __ballot(static_cast<uint32_t>(va) > cf && lane < span);
-                const int tl = __builtin_ctzll(m2);
-                c_t = bcast_u32(static_cast<uint32_t>(va), tl);
+                const uint32_t va = (lane < span) ? img[(meta & 0x3FFFFu) + 64 + lo + lane] : 0x7FFFFFFFu;
+                const int tl = __builtin_ctzll(__ballot(va > cf));
+                c_t = bcast_u32(va, tl);
                 // entry lo-1 is the last entry of the previous block = that block's probe value
-                c_s = tl > 0 ? bcast_u32(static_cast<uint32_t>(va), tl - 1) : bcast_u32(static_cast<uint32_t>(p), first - 1);
+                c_s = tl > 0 ? bcast_u32(va, tl - 1) : bcast_u32(p, first - 1);
                 s = lo + tl - 1;
             }
+            // x = freq * (x >> prec) + (cf - c_s)   (rans64.h:128-142), on 32-bit halves
             const uint32_t freq = c_t - c_s;
-            x = static_cast<uint64_t>(freq) * (x >> prec) + cf - c_s;  // rans64.h:128-142
-            if (x < kRansL) x = (x << 32) | rd.next(lane);
+            const uint32_t t_lo = (xl >> prec) | (xh << (32u - prec));
+            const uint32_t t_hi = xh >> prec;
+            const uint64_t prod = static_cast<uint64_t>(freq) * t_lo + (cf - c_s);
+            xl = static_cast<uint32_t>(prod);
+            xh = static_cast<uint32_t>(prod >> 32) + freq * t_hi;
+            if (xh == 0u && xl < 0x80000000u) { xh = xl; xl = next_word(); }
             int32_t value = s;
-            if (T.bypass && value == size - 2) {
-                uint32_t v = get_raw(x, rd, lane, bprec);
+            if (bypass && value == size - 2) {
+                uint32_t v = get_bits(bprec);
                 uint32_t nb = v;
-                while (v == maxbv) { v = get_raw(x, rd, lane, bprec); nb += v; }
+                while (v == maxbv) { v = get_bits(bprec); nb += v; }
                 uint32_t raw = 0;
                 for (uint32_t k = 0; k < nb; ++k) {
-                    const uint32_t nib = get_raw(x, rd, lane, bprec);
+                    const uint32_t nib = get_bits(bprec);
                     if (k * bprec < 32u) raw |= nib << (k * bprec);
                 }
                 value = static_cast<int32_t>(raw >> 1);
                 if (raw & 1u) value = -value - 1; else value += size - 2;
             }
-            value += offset;
             result = (lane == j) ? value : result;
         };
 
-        int32_t pa = probe(0);
-        int32_t pb = probe(cnt > 1 ? 1 : 0);
+        uint32_t pa = probe(0);
+        uint32_t pb = probe(cnt > 1 ? 1 : 0);
         for (int j = 0; j < cnt; j += 2) {
             decode_one(j, pa);
             pa = probe(j + 2 < cnt ? j + 2 : cnt - 1);  // two symbols ahead
@@ -716,9 +758,12 @@ __global__ __launch_bounds__(64) void rans_decode_fast_kernel(TablesDev T, const
                 pb = probe(j + 3 < cnt ? j + 3 : cnt - 1);
             }
         }
-        if (i < n) out[i] = result;
+        if (i < n) out[i] = result + off_l;
     }
-    if (lane == 0) { state[stream] = x; pos_io[stream] = rd.pos; }
+    if (lane == 0) {
+        state[stream] = static_cast<uint64_t>(xl) | (static_cast<uint64_t>(xh) << 32);
+        pos_io[stream] = pos;
+    }
 }
 
 // Gather the right-aligned streams of an encode batch into one contiguous buffer.
@@ -737,7 +782,8 @@ __global__ void compact_streams_kernel(const uint32_t *__restrict__ slots, int64
 TablesDev dev_view(const basic_rans_tables *t)
 {
     return TablesDev{t->d_cdfs, t->d_sizes, t->d_offsets, t->rows, t->stride, t->precision, t->bypass, t->bypass_precision,
-                     t->d_cdf16, t->d_base, static_cast<int>(t->cdf16.size())};
+                     t->d_cdf16, t->d_base, static_cast<int>(t->cdf16.size()),
+                     t->d_image, t->d_meta, static_cast<int>(t->image.size())};
 }
 
 struct DevBuf {
@@ -781,14 +827,15 @@ int launch_decode(const basic_rans_tables *t, const ArDev &ar, int nstreams, hip
     const bool lds = t->cdf16.size() * sizeof(uint16_t) <= kLdsTableBudget;
     int max_size = 0;
     for (int v : t->sizes) max_size = v > max_size ? v : max_size;
-    if (!ar.tab && lds && max_size <= 4096) {
+    (void)max_size;
+    if (!ar.tab && t->fast_ok) {
         static bool attr_set = false;
         if (!attr_set) {
             BASIC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(rans_decode_fast_kernel),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             attr_set = true;
         }
-        hipLaunchKernelGGL(rans_decode_fast_kernel, dim3(nstreams), dim3(64), t->cdf16.size() * sizeof(uint16_t), st, dev_view(t),
+        hipLaunchKernelGGL(rans_decode_fast_kernel, dim3(nstreams), dim3(64), t->image.size() * sizeof(uint32_t), st, dev_view(t),
                            d_words, d_word_off, d_indexes, d_seg, d_out, d_state, d_pos);
         BASIC_HIP_TRY(hipGetLastError());
         return BASIC_OK;
