@@ -49,6 +49,8 @@ _SIGNATURES = {
     "basic_pgm_gauss_encode_group_dev": (_I, [_P, _P, _I, _I, _I, _P, _L, _P, _I, _P, _P, _L, _L, _P, _P]),
     "basic_pgm_gauss_index_group_dev": (_I, [_P, _I, _I, _I, _P, _L, _P, _I, _P, _L, _L, _P]),
     "basic_pgm_gauss_scatter_group_dev": (_I, [_P, _P, _I, _I, _I, _P, _L, _L, _L, _P, _P]),
+    "basic_gauss_nll_per_image_dev": (_I, [_P, _P, _I, _I, _I, _I, _F, _F, _P, _P]),
+    "basic_eb_nll_per_image_dev": (_I, [_P, _P, _I, _I, _I, _F, _P, _P]),
     "basic_conv_plan_create": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _I, _P]),
     "basic_conv_plan_out_hw": (_I, [_P, _I, _I, _P, _P]),
     "basic_conv_forward_dev": (_I, [_P, _P, _I, _I, _I, _P, _P]),

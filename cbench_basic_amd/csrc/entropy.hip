@@ -145,6 +145,88 @@ __global__ void mse_per_image_kernel(const float *__restrict__ a, const float *_
     if (threadIdx.x == 0) mse[img] = red[0] / static_cast<float>(elems);
 }
 
+// ---- rate estimate ("prior_entropy", nats per image): -sum log(max(P(q), bound)) -------------------------------
+// MODE 0: CompressAI GaussianConditional._likelihood (upstream; call site compressai_coder.py:352-375):
+//         zero mean, v = |q|, P = Phi((.5 - v)/s) - Phi((-.5 - v)/s), Phi(t) = .5 erfc(-t/sqrt2), s = max(scale, bound_s)
+// MODE 1: PGM coder (pgm_coder.py:374-389,757-778): Normal(mu, max(scale, bound_s)).cdf(q + .5) - cdf(q - .5) with
+//         torch's cdf = .5 (1 + erf((x - mu) / (s sqrt2))), params "split_interleave" in a [B][2C][HW] tensor.
+template <int MODE>
+__global__ void gauss_nll_per_image_kernel(const float *__restrict__ q, const float *__restrict__ scales_or_params,
+                                           int64_t elems, int hw, float bound_s, float bound_p, float *__restrict__ nll)
+{
+    __shared__ float red[kBlock];
+    const int img = blockIdx.x;
+    const float *pq = q + static_cast<int64_t>(img) * elems;
+    float acc = 0.f;
+    for (int64_t i = threadIdx.x; i < elems; i += blockDim.x) {
+        float p;
+        if (MODE == 0) {
+            const float s = fmaxf(scales_or_params[static_cast<int64_t>(img) * elems + i], bound_s);
+            const float v = fabsf(pq[i]);
+            const float c = -0.70710678118654752440f;
+            p = 0.5f * erfcf(c * ((0.5f - v) / s)) - 0.5f * erfcf(c * ((-0.5f - v) / s));
+        } else {
+            const int64_t c = i / hw, pos = i - c * hw;
+            const float *pp = scales_or_params + static_cast<int64_t>(img) * 2 * elems + (2 * c) * hw + pos;
+            const float mu = pp[0], s = fmaxf(pp[hw], bound_s);
+            const float r = 0.70710678118654752440f / s;  // 1 / (s sqrt2) as torch: (x - mu) * s.reciprocal() / sqrt2
+            p = 0.5f * (1.f + erff((pq[i] + 0.5f - mu) * r)) - 0.5f * (1.f + erff((pq[i] - 0.5f - mu) * r));
+        }
+        acc += -logf(fmaxf(p, bound_p));
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int st = kBlock / 2; st > 0; st >>= 1) {
+        if (static_cast<int>(threadIdx.x) < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) nll[img] = red[0];
+}
+
+// EntropyBottleneck likelihood (upstream _logits_cumulative; call site compressai_coder.py:203-228): per channel a
+// 1-3-3-3-3-1 network with pre-activated parameters coef[c][58] = softplus(M0[3]) b0[3] tanh(f0)[3] | softplus(M1[9]) b1[3]
+// tanh(f1)[3] | M2.. | M3.. | softplus(M4[3]) b4[1].
+__device__ __forceinline__ float eb_logits(const float *k, float v)
+{
+    float h[3], t[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { h[i] = k[i] * v + k[3 + i]; h[i] += k[6 + i] * tanhf(h[i]); }
+    k += 9;
+#pragma unroll
+    for (int l = 0; l < 3; ++l) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { t[i] = k[3 * i] * h[0] + k[3 * i + 1] * h[1] + k[3 * i + 2] * h[2] + k[9 + i]; t[i] += k[12 + i] * tanhf(t[i]); }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) h[i] = t[i];
+        k += 15;
+    }
+    return k[0] * h[0] + k[1] * h[1] + k[2] * h[2] + k[3];
+}
+
+__global__ void eb_nll_per_image_kernel(const float *__restrict__ zq, const float *__restrict__ coef, int channels, int hw,
+                                        float bound_p, float *__restrict__ nll)
+{
+    __shared__ float red[kBlock];
+    const int img = blockIdx.x;
+    const int64_t elems = static_cast<int64_t>(channels) * hw;
+    const float *pz = zq + static_cast<int64_t>(img) * elems;
+    float acc = 0.f;
+    for (int64_t i = threadIdx.x; i < elems; i += blockDim.x) {
+        const float *k = coef + (i / hw) * 58;
+        const float lower = eb_logits(k, pz[i] - 0.5f), upper = eb_logits(k, pz[i] + 0.5f);
+        const float sg = (lower + upper) > 0.f ? -1.f : ((lower + upper) < 0.f ? 1.f : 0.f);
+        const float p = fabsf(1.f / (1.f + expf(-sg * upper)) - 1.f / (1.f + expf(-sg * lower)));
+        acc += -logf(fmaxf(p, bound_p));
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int st = kBlock / 2; st > 0; st >>= 1) {
+        if (static_cast<int>(threadIdx.x) < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) nll[img] = red[0];
+}
+
 }  // namespace
 
 extern "C" int basic_gc_quantize_index_dev(const float *d_y, const float *d_scales, int64_t n, const float *d_table,
@@ -244,6 +326,32 @@ extern "C" int basic_mse_per_image_dev(const float *d_a, const float *d_b, int b
     BASIC_REQUIRE(d_a && d_b && d_mse && batch >= 1 && elems_per_image >= 1, "mse_per_image: bad argument");
     hipLaunchKernelGGL(mse_per_image_kernel, dim3(batch), dim3(kBlock), 0, as_stream(hip_stream), d_a, d_b,
                        elems_per_image, d_mse);
+    BASIC_HIP_TRY(hipGetLastError());
+    return BASIC_OK;
+}
+
+extern "C" int basic_gauss_nll_per_image_dev(const float *d_q, const float *d_scales_or_params, int batch, int channels, int hw,
+                                             int interleaved_mean_scale, float scale_bound, float likelihood_bound, float *d_nll,
+                                             void *hip_stream)
+{
+    BASIC_REQUIRE(d_q && d_scales_or_params && d_nll && batch >= 1 && channels >= 1 && hw >= 1, "gauss_nll_per_image: bad argument");
+    const int64_t elems = static_cast<int64_t>(channels) * hw;
+    if (interleaved_mean_scale)
+        hipLaunchKernelGGL(gauss_nll_per_image_kernel<1>, dim3(batch), dim3(kBlock), 0, as_stream(hip_stream), d_q, d_scales_or_params,
+                           elems, hw, scale_bound, likelihood_bound, d_nll);
+    else
+        hipLaunchKernelGGL(gauss_nll_per_image_kernel<0>, dim3(batch), dim3(kBlock), 0, as_stream(hip_stream), d_q, d_scales_or_params,
+                           elems, hw, scale_bound, likelihood_bound, d_nll);
+    BASIC_HIP_TRY(hipGetLastError());
+    return BASIC_OK;
+}
+
+extern "C" int basic_eb_nll_per_image_dev(const float *d_zq, const float *d_coef, int batch, int channels, int hw,
+                                          float likelihood_bound, float *d_nll, void *hip_stream)
+{
+    BASIC_REQUIRE(d_zq && d_coef && d_nll && batch >= 1 && channels >= 1 && hw >= 1, "eb_nll_per_image: bad argument");
+    hipLaunchKernelGGL(eb_nll_per_image_kernel, dim3(batch), dim3(kBlock), 0, as_stream(hip_stream), d_zq, d_coef, channels, hw,
+                       likelihood_bound, d_nll);
     BASIC_HIP_TRY(hipGetLastError());
     return BASIC_OK;
 }

@@ -103,6 +103,21 @@ class EntropyBottleneck(nn.Module):
     def medians(self):
         return self.quantiles.detach()[:, 0, 1].float()
 
+    def likelihood_coefficients(self):
+        """[C, 58] pre-activated parameters of the cumulative-logit network for basic_eb_nll_per_image_dev:
+        per layer softplus(matrix) row-major, bias, tanh(factor)."""
+        assert self.filters == (3, 3, 3, 3), "the likelihood kernel is specialised for filters (3,3,3,3)"
+        with torch.no_grad():
+            parts = []
+            for i in range(5):
+                parts.append(F.softplus(self.matrices[i].detach().float().cpu()).reshape(self.channels, -1))
+                parts.append(self.biases[i].detach().float().cpu().reshape(self.channels, -1))
+                if i < 4:
+                    parts.append(torch.tanh(self.factors[i].detach().float().cpu()).reshape(self.channels, -1))
+            coef = torch.cat(parts, 1)
+        assert coef.shape[1] == 58
+        return coef.contiguous()
+
     def build_tables(self):
         """EntropyBottleneck.update() (upstream): returns (cdf int32 [C, L], cdf_length, offset)."""
         with torch.no_grad():
@@ -146,13 +161,18 @@ class CompressAIEntropyBottleneckPriorCoder(HotPathModule):
         self._tables = K.RansTables(cdfs=cdf, cdf_sizes=lengths, offsets=offsets, precision=16, bypass=True, bypass_precision=4)
         self._cdf_host = (cdf, lengths, offsets)
         self._medians_dev = None
+        self._coef_dev = None
 
     def forward(self, input, *args, channel_gains=None, channel_gains_inv=None, **kwargs):
-        """Eval-mode forward (:203-228): dequantised latent round(z - median) + median."""
+        """Eval-mode forward (:203-228): dequantised latent round(z - median) + median, and the rate estimate
+        metric_dict["prior_entropy"] = -sum log(likelihood) / batch (nats)."""
         self._ready()
         if channel_gains is not None:
             input = input * channel_gains.reshape(1, -1, 1, 1)
         _, _, zhat = K.eb_quantize_index(input, self._medians_dev)
+        if getattr(self, "_coef_dev", None) is None or self._coef_dev.device != self.device:
+            self._coef_dev = self.entropy_bottleneck.likelihood_coefficients().to(self.device)
+        self.update_cache("metric_dict", prior_entropy=K.eb_nll_per_image(zhat, self._coef_dev, 1e-9).mean())
         if channel_gains_inv is not None:
             zhat = zhat * channel_gains_inv.reshape(1, -1, 1, 1)
         return zhat
@@ -260,7 +280,9 @@ class CompressAIGaussianConditionalCoder(HotPathModule):
         self._ready()
         if channel_gains is not None:
             y = y * channel_gains.reshape(1, -1, 1, 1)
-        _, _, yhat = K.gc_quantize_index(y, self._crop(prior, *y.shape[-2:]), self._scale_table_dev, self.scale_bound)
+        scales = self._crop(prior, *y.shape[-2:])
+        _, _, yhat = K.gc_quantize_index(y, scales, self._scale_table_dev, self.scale_bound)
+        self.update_cache("metric_dict", prior_entropy=K.gauss_nll_per_image(yhat, scales, False, self.scale_bound, 1e-9).mean())
         if channel_gains_inv is not None:
             yhat = yhat * channel_gains_inv.reshape(1, -1, 1, 1)
         return yhat

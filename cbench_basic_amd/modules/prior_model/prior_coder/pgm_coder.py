@@ -189,6 +189,8 @@ class GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(HotPathModule):
         self.fixed_input_shape = fixed_input_shape
         self.force_input_prior_shape_aligned = force_input_prior_shape_aligned
         self.batch_stream_mode = batch_stream_mode
+        self.eps = kwargs.get("eps", 1e-7)
+        self.estimate_rate = False
         if default_topo_group_method in ("channelwise-g10", "elic"):  # pgm_coder.py:1164-1171
             self.channel_groups = in_channels // 16
             assert self.channel_groups >= (9 if default_topo_group_method == "channelwise-g10" else 8)
@@ -292,7 +294,9 @@ class GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(HotPathModule):
         return ws
 
     def _context(self, ws, plan, g, B, prior):
-        pos = plan.positions(g, B, self.device)
+        return self._context_at(ws, plan, plan.positions(g, B, self.device), prior)
+
+    def _context_at(self, ws, plan, pos, prior):
         topo = dict(pgm=plan.topo_dev, cat=plan.topo_cat_dev)
         merger = self._layers.get("m")
         if merger is None:
@@ -343,16 +347,26 @@ class GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(HotPathModule):
         return sym, idx, ws["ybuf"], plan
 
     def forward(self, input, prior=None, pgm=None, quantizer_params=None, **kwargs):
-        """Eval-mode forward (pgm_coder.py:391-539): the dequantised latent.  With autoregressive encoding the
-        reference's encode() quantises y - mu group by group, which is what the decoder reproduces; that buffer
-        is returned here."""
+        """Eval-mode forward (pgm_coder.py:391-539): returns the dequantised latent round(y).  With
+        ``self.estimate_rate = True`` it also evaluates the reference's rate estimate: ONE full-map pass of the
+        context model on round(y) (:421-429), likelihood cdf(q+.5) - cdf(q-.5) under N(mu, max(sigma, 0.11)),
+        metric_dict["prior_entropy"] = -sum log(max(p, eps)) / batch (:374-389,:520-522)."""
         self._ready()
         if pgm is not None:
             raise NotImplementedError("externally supplied topo groups")
         input = input.contiguous()
         prior = self._check_prior(input.shape, prior)
-        _, _, ybuf, _ = self._run_encode(input, prior)
-        return ybuf
+        q = torch.round(input)
+        if getattr(self, "estimate_rate", False):
+            B, C, H, W = input.shape
+            plan = self._plan(H, W)
+            ws = self._alloc(B, H, W, prior)
+            ws["ybuf"] = q
+            allpos = torch.arange(B * H * W, device=self.device, dtype=torch.int32)
+            params = self._context_at(ws, plan, allpos, prior)
+            nll = K.gauss_nll_per_image(q, params, True, self.lower_bound_scale, self.eps)
+            self.update_cache("metric_dict", prior_entropy=nll.mean())
+        return q
 
     def encode(self, input, *args, prior=None, pgm=None, quantizer_params=None, **kwargs) -> bytes:
         self._ready()

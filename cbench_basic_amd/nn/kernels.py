@@ -256,3 +256,23 @@ def mse_per_image(a, b):
     out = torch.empty((a.shape[0],), device=a.device, dtype=torch.float32)
     _lib.check(_lib.lib().basic_mse_per_image_dev(a.data_ptr(), b.data_ptr(), a.shape[0], a.numel() // a.shape[0], out.data_ptr(), _stream()))
     return out
+
+
+def gauss_nll_per_image(q, scales_or_params, interleaved, scale_bound=0.11, likelihood_bound=1e-9):
+    """Rate estimate (nats per image) of a Gaussian-coded latent; see basic_gauss_nll_per_image_dev."""
+    q, sp = _dev(q, torch.float32), _dev(scales_or_params, torch.float32)
+    B, C = q.shape[0], q.shape[1]
+    hw = q.numel() // (B * C)
+    out = torch.empty((B,), device=q.device, dtype=torch.float32)
+    _lib.check(_lib.lib().basic_gauss_nll_per_image_dev(q.data_ptr(), sp.data_ptr(), B, C, hw, int(bool(interleaved)), float(scale_bound),
+                                                        float(likelihood_bound), out.data_ptr(), _stream()))
+    return out
+
+
+def eb_nll_per_image(zq, coef, likelihood_bound=1e-9):
+    zq, coef = _dev(zq, torch.float32), _dev(coef, torch.float32)
+    B, C = zq.shape[0], zq.shape[1]
+    hw = zq.numel() // (B * C)
+    out = torch.empty((B,), device=zq.device, dtype=torch.float32)
+    _lib.check(_lib.lib().basic_eb_nll_per_image_dev(zq.data_ptr(), coef.data_ptr(), B, C, hw, float(likelihood_bound), out.data_ptr(), _stream()))
+    return out

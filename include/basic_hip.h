@@ -147,6 +147,19 @@ int basic_pgm_gauss_scatter_group_dev(const int32_t *d_symbols, const float *d_p
                                       int hw, const int32_t *d_elems, int64_t n_elems, int64_t per_image,
                                       int64_t in_base, float *d_ybuf, void *hip_stream);
 
+/* Rate estimate of the forward() pass ("prior_entropy", nats per image): d_nll[b] = -sum log(max(P(q), likelihood_bound)).
+ *   interleaved_mean_scale == 0: CompressAI GaussianConditional likelihood (call site compressai_coder.py:352-375),
+ *       zero mean, d_scales_or_params = scales [B][C][HW];
+ *   interleaved_mean_scale == 1: PGM coder likelihood (pgm_coder.py:374-389), d_scales_or_params = [B][2C][HW] with
+ *       channel 2c = mean, 2c+1 = scale.  d_q = the quantised latent [B][C][HW]. */
+int basic_gauss_nll_per_image_dev(const float *d_q, const float *d_scales_or_params, int batch, int channels, int hw,
+                                  int interleaved_mean_scale, float scale_bound, float likelihood_bound, float *d_nll,
+                                  void *hip_stream);
+/* EntropyBottleneck likelihood (call site compressai_coder.py:203-228); d_coef float32 [C][58]: the pre-activated
+ * 1-3-3-3-3-1 cumulative-logit network of every channel (softplus(matrix), bias, tanh(factor) per layer). */
+int basic_eb_nll_per_image_dev(const float *d_zq, const float *d_coef, int batch, int channels, int hw,
+                               float likelihood_bound, float *d_nll, void *hip_stream);
+
 /* ======================================================================================
  * 5. Transforms: implicit-GEMM convolution on fp32 MFMA (v_mfma_f32_32x32x2_f32) with fused
  *    bias + activation / (I)GDN epilogue.  Replaces the ATen calls behind

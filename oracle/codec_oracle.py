@@ -208,6 +208,35 @@ class HyperpriorOracle:
         return self.g_s(y_hat)
 
 
+def gc_entropy(y, scales, bound=0.11, lik_bound=1e-9):
+    """GaussianConditional forward's -sum log likelihood / batch (upstream _likelihood, compressai_coder.py:352-375)."""
+    v = torch.abs(torch.round(y))
+    s = torch.max(scales, torch.tensor([bound]))
+    phi = lambda t: 0.5 * torch.erfc(-(2 ** -0.5) * t)
+    lik = torch.max(phi((0.5 - v) / s) - phi((-0.5 - v) / s), torch.tensor([lik_bound]))
+    return (-torch.log(lik)).sum() / y.shape[0]
+
+
+def eb_entropy(sd, prefix, z, lik_bound=1e-9, n_filters=4):
+    """EntropyBottleneck forward's -sum log likelihood / batch (upstream, compressai_coder.py:203-228)."""
+    med = sd[prefix + "quantiles"][:, 0, 1].reshape(1, -1, 1, 1)
+    zq = torch.round(z - med) + med
+    C = z.shape[1]
+    v = zq.permute(1, 0, 2, 3).reshape(C, 1, -1)
+
+    def logits(t):
+        for i in range(n_filters + 1):
+            t = torch.matmul(F.softplus(sd[f"{prefix}matrices.{i}"]), t) + sd[f"{prefix}biases.{i}"]
+            if i < n_filters:
+                t = t + torch.tanh(sd[f"{prefix}factors.{i}"]) * torch.tanh(t)
+        return t
+
+    lower, upper = logits(v - 0.5), logits(v + 0.5)
+    sign = -torch.sign(lower + upper)
+    lik = torch.max(torch.abs(torch.sigmoid(sign * upper) - torch.sigmoid(sign * lower)), torch.tensor([lik_bound]))
+    return (-torch.log(lik)).sum() / z.shape[0]
+
+
 def psnr(a, b, max_val=1.0):
     """benchmark/metrics/pytorch_distortion.py:12-15 per image."""
     mse = ((a - b) ** 2).reshape(a.shape[0], -1).mean(1)

@@ -101,3 +101,43 @@ def test_compress_decompress_vs_oracle(setup, shape):
 def test_smoke_entry():
     import __graft_entry__ as g
     g.smoke()
+
+
+def test_kodak_shaped_image_roundtrip(setup):
+    """BASELINE configs[1] shape: 3x512x768 (Kodak), batch 1 -- y is 192x32x48 = 294,912 symbols in one stream."""
+    from oracle.codec_oracle import psnr
+    codec, oracle = setup
+    torch.manual_seed(24)
+    x = torch.rand(1, 3, 512, 768)
+    data = codec.compress(x)
+    xhat = codec.decompress(data).cpu()
+    ref = oracle.compress(x)
+    xref = oracle.decompress(ref)
+    assert xhat.shape == x.shape
+    assert abs(len(data) - len(ref)) <= 64
+    assert float((psnr(xhat, x) - psnr(xref, x)).abs().max()) < 0.01
+    # cross-decoding: the oracle reads the GPU stream
+    assert _rel(oracle.decompress(data), xhat) < 1e-3
+
+
+def test_rate_estimates_prior_entropy(setup):
+    """forward()'s rate estimate metric (get_raw_cache("metric_dict")["prior_entropy"], nats per image)."""
+    from oracle.codec_oracle import eb_entropy, gc_entropy
+    codec, oracle = setup
+    ec = codec.entropy_coder
+    torch.manual_seed(3)
+    x = torch.rand(2, 3, 128, 128)
+    a = oracle.analyse(x)
+    zc, yc = ec.latent_node_entropy_coders["z"], ec.latent_node_entropy_coders["y"]
+    zc(a["z"].cuda())
+    yc(a["y"].cuda(), prior=a["scales"].cuda())
+    got_z = float(zc.get_raw_cache("metric_dict")["prior_entropy"])
+    got_y = float(yc.get_raw_cache("metric_dict")["prior_entropy"])
+    ref_z = float(eb_entropy(oracle.sd, "latent_node_entropy_coders.z.entropy_bottleneck.", a["z"]))
+    ref_y = float(gc_entropy(a["y"], a["scales"]))
+    assert abs(got_z - ref_z) <= 1e-3 * abs(ref_z), (got_z, ref_z)
+    assert abs(got_y - ref_y) <= 1e-3 * abs(ref_y), (got_y, ref_y)
+    # the estimate tracks the actual coded size (bits within a few percent)
+    data = codec.compress(x)
+    est_bits = (got_z + got_y) * 2 / 0.6931471805599453
+    assert abs(est_bits - len(data) * 8) < 0.1 * len(data) * 8

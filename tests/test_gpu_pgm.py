@@ -87,3 +87,20 @@ def test_per_image_batch_roundtrip_vs_oracle(method, G, ctxm):
         assert float((yhat[b:b + 1] - rbuf).abs().max()) < 1.01  # at most a flipped rounding
     print(f"{method}: {same}/{B} image streams byte-identical to the CPU oracle")
     assert same >= B - 1
+
+
+def test_pgm_forward_rate_estimate():
+    from oracle.pgm_oracle import TopoGroupGaussianOracle
+    z = load("ar_coder.npz")
+    for k in ("a1", "a4", "a5"):
+        sd, c = ar_case(z, k)
+        coder = build(sd, c)
+        coder.estimate_rate = True
+        oracle = TopoGroupGaussianOracle(sd, c["C"], c["G"], c["method"], c["expand"], context_model=c["ctxm"])
+        y, prior = torch.from_numpy(z[f"{k}.y"]), torch.from_numpy(z[f"{k}.prior"])
+        q = coder(y.cuda(), prior=prior.cuda())
+        assert torch.equal(q.cpu(), torch.round(y))
+        assert torch.allclose(q.cpu(), torch.from_numpy(z[f"{k}.yfwd"]))          # the reference's forward() output
+        got = float(coder.get_raw_cache("metric_dict")["prior_entropy"])
+        ref = float(oracle.forward_entropy(y, prior))
+        assert abs(got - ref) <= 2e-3 * abs(ref), (k, got, ref)
