@@ -165,6 +165,14 @@ def main():
         conv_s, launches = measure_conv_kernels(codec, x)
         flops_pass = (enc_f + dec_f) * args.batch
         achieved = flops_pass / conv_s / 1e12
+        # HBM traffic per launch: collected in SEPARATE rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; a profiler
+        # cannot run inside the timed process) and committed under profiles/; null when that file is absent.
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                traffic = json.load(f)["hbm_bytes_per_launch_avg"]
+        except Exception:
+            pass
         out = dict(
             metric="encode+decode Mpix/s", value=pix / dt_max / 1e6, unit="Mpix/s", n_gpus=world, steps=args.steps,
             warmup=args.warmup, ms_per_step=dt_max / args.steps * 1e3, higher_is_better=True, scaling="weak",
@@ -174,7 +182,7 @@ def main():
                         images_per_gpu=args.batch, bpp=n_bytes * 8 / pix, psnr_db=psnr_tot / n_psnr,
                         parallelism=f"image-sharded x{world}, RCCL all-reduce of metric sums only"),
             roofline=dict(bound="mfma", achieved=achieved, peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
-                          frac=achieved / PEAK_FP32_MFMA_TFLOPS, traffic=None,
+                          frac=achieved / PEAK_FP32_MFMA_TFLOPS, traffic=traffic,
                           kernel="conv_tap_mfma_kernel<MT> (all transform launches of one encode+decode pass)",
                           flops_per_launch=flops_pass / launches, launches_per_pass=launches,
                           avg_launch_ms=conv_s / launches * 1e3, pass_ms=conv_s * 1e3),
