@@ -42,6 +42,7 @@ _SIGNATURES = {
     "basic_rans_encode_batch_dev": (_I, [_P, _P, _P, _P, _I, _P, _L, _P, _P]),
     "basic_rans_compact_streams_dev": (_I, [_P, _L, _P, _P, _I, _P, _P]),
     "basic_rans_decode_batch_dev": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _P, _P]),
+    "basic_rans_decode_batch_strided_dev": (_I, [_P, _P, _P, _P, _L, _L, _L, _I, _P, _P, _P, _P]),
     "basic_gc_quantize_index_dev": (_I, [_P, _P, _L, _P, _I, _F, _P, _P, _P, _P]),
     "basic_eb_quantize_index_dev": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P]),
     "basic_eb_dequantize_dev": (_I, [_P, _P, _I, _I, _I, _P, _P]),

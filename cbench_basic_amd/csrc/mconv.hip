@@ -14,7 +14,9 @@
 // slab is skipped when its mask is empty for all 32 positions of the wave -- for causal
 // patterns that removes most of the K loop.
 //
-// Mapping: one wavefront = one 32-row tile of ONE output channel group x 32 listed positions.
+// Mapping: one workgroup (4 wavefronts) = one 32-row tile of ONE output channel group x 32 listed positions;
+// the K loop of every unmasked (tap, input group) slab is split over the 4 waves and unrolled so that several
+// fragment loads are in flight per L2 round trip (tiny launches -- scanline groups -- are latency bound).
 // A fragments are coalesced 128-byte rows of the packed weights [tap][ci][co]; B fragments are
 // gathered from x with the mask applied as a select (so masked garbage, even NaN, never enters
 // the sum -- the reference multiplies by 0 instead, which only differs for non-finite data).
@@ -43,9 +45,16 @@ struct MaskedLaunch {
     int out_total, out_off, ntaps, pad, ksize, allow_same, act;
 };
 
-__global__ __launch_bounds__(64) void masked_conv_pos_kernel(const MaskedLaunch g)
+constexpr int kUnroll = 4;  // channel pairs whose loads are issued together (one L2 round trip per 4 MFMAs)
+
+// kWaves > 1: K is split over the waves of a workgroup and the partial tiles are summed through LDS -- for tiny
+// launches (a scanline group is 1 position per image) where one wave per tile would leave the chip idle.
+template <int kWaves>
+__global__ __launch_bounds__(64 * kWaves) void masked_conv_pos_kernel(const MaskedLaunch g)
 {
-    const int lane = threadIdx.x, col = lane & 31, khalf = lane >> 5;
+    __shared__ float partial[kWaves > 1 ? kWaves - 1 : 1][16][64];
+    const int tid = threadIdx.x, wave = tid >> 6;
+    const int lane = tid & 63, col = lane & 31, khalf = lane >> 5;
     const int tile = blockIdx.y;
     const int grp_o = tile / g.tiles_per_group, ti = tile - grp_o * g.tiles_per_group;
     const int row_in_group = ti * 32 + col;                 // A-fragment row of this lane
@@ -81,31 +90,50 @@ __global__ __launch_bounds__(64) void masked_conv_pos_kernel(const MaskedLaunch 
                 const int32_t tn = g.topo_in[gin * hw + noff];
                 open = g.allow_same ? (tn <= centre) : (tn < centre);
             }
-            if (__ballot(open) == 0ull) continue;  // wave-uniform skip of an all-masked slab
+            if (__ballot(open) == 0ull) continue;  // wave-uniform skip of an all-masked slab (same in every wave)
             const int c_beg = gin * g.gs_in, c_end = c_beg + g.gs_in;
             const float *wt = g.w + (static_cast<int64_t>(t) * g.cin) * g.coutp + co_a;
-            for (int c = c_beg; c < c_end; c += 2) {
-                const int ci = c + khalf;
-                const bool ci_ok = ci < c_end;
-                float bfrag = 0.f, afrag = 0.f;
-                if (open && ci_ok) bfrag = xb[static_cast<int64_t>(ci) * hw + noff];
-                if (row_ok && ci_ok) afrag = wt[static_cast<int64_t>(ci) * g.coutp];
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(afrag, bfrag, acc, 0, 0, 0);
+            // this wave's share of the slab: channel pairs wave, wave + kWaves, ...; kUnroll pairs per round trip
+            for (int c = c_beg + 2 * wave; c < c_end; c += 2 * kWaves * kUnroll) {
+                float af[kUnroll], bf[kUnroll];
+#pragma unroll
+                for (int u = 0; u < kUnroll; ++u) {
+                    const int ci = c + u * 2 * kWaves + khalf;
+                    const bool ci_ok = ci < c_end;
+                    af[u] = (row_ok && ci_ok) ? wt[static_cast<int64_t>(ci) * g.coutp] : 0.f;
+                    bf[u] = (open && ci_ok) ? xb[static_cast<int64_t>(ci) * hw + noff] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < kUnroll; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[u], bf[u], acc, 0, 0, 0);
             }
         }
     }
 
-    if (pos_ok) {
-        float *yb = g.y + (static_cast<int64_t>(b) * g.out_total + g.out_off) * hw + py * g.w_ + px;
+    // sum the K-slices of the waves (fixed order: deterministic, same result in encoder and decoder)
+    if (kWaves > 1) {
+        if (wave > 0) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int rg = ti * 32 + 8 * (r >> 2) + 4 * khalf + (r & 3);
-            if (rg < g.gs_out) {
-                const int co = grp_o * g.gs_out + rg;
-                float v = acc[r] + g.bias[co];
-                if (g.act == BASIC_ACT_LEAKY_RELU) v = v > 0.f ? v : 0.01f * v;
-                else if (g.act == BASIC_ACT_RELU) v = v > 0.f ? v : 0.f;
-                yb[static_cast<int64_t>(co) * hw] = v;
+            for (int r = 0; r < 16; ++r) partial[wave - 1][r][lane] = acc[r];
+        }
+        __syncthreads();
+    }
+    if (wave == 0) {
+#pragma unroll
+        for (int w = 0; w < kWaves - 1; ++w)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] += partial[w][r][lane];
+        if (pos_ok) {
+            float *yb = g.y + (static_cast<int64_t>(b) * g.out_total + g.out_off) * hw + py * g.w_ + px;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rg = ti * 32 + 8 * (r >> 2) + 4 * khalf + (r & 3);
+                if (rg < g.gs_out) {
+                    const int co = grp_o * g.gs_out + rg;
+                    float v = acc[r] + g.bias[co];
+                    if (g.act == BASIC_ACT_LEAKY_RELU) v = v > 0.f ? v : 0.01f * v;
+                    else if (g.act == BASIC_ACT_RELU) v = v > 0.f ? v : 0.f;
+                    yb[static_cast<int64_t>(co) * hw] = v;
+                }
             }
         }
     }
@@ -177,7 +205,11 @@ extern "C" int basic_mconv_forward_pos_dev(const basic_mconv_plan *p, const floa
     g.out_total = out_channels_total; g.out_off = out_channel_offset;
     g.ntaps = p->ksize * p->ksize; g.pad = p->ksize / 2; g.ksize = p->ksize; g.allow_same = p->allow_same; g.act = p->act;
     const dim3 grid(static_cast<unsigned>((n_pos + 31) / 32), static_cast<unsigned>(g.tiles_per_group * g.go));
-    hipLaunchKernelGGL(masked_conv_pos_kernel, grid, dim3(64), 0, as_stream(hip_stream), g);
+    // few tiles -> split K over 4 waves per tile; many tiles -> one wave per tile already fills the chip
+    if (static_cast<int64_t>(grid.x) * grid.y < 4096)
+        hipLaunchKernelGGL(masked_conv_pos_kernel<4>, grid, dim3(256), 0, as_stream(hip_stream), g);
+    else
+        hipLaunchKernelGGL(masked_conv_pos_kernel<1>, grid, dim3(64), 0, as_stream(hip_stream), g);
     BASIC_HIP_TRY(hipGetLastError());
     return BASIC_OK;
 }

@@ -290,6 +290,9 @@ struct TablesDev {
     int image_words;
 };
 
+// Alternative to a seg[] array: stream b codes the elements [first + b*stride, first + b*stride + count).
+struct StridedSeg { int64_t first, stride, count; };
+
 struct ArDev {
     const int32_t *tab;  // nullptr = no AR remap
     int k, order, rows, s1;
@@ -484,14 +487,14 @@ __global__ __launch_bounds__(64) void rans_decode_kernel(TablesDev T, ArDev ar, 
                                                          const int64_t *__restrict__ word_off,
                                                          const int32_t *__restrict__ indexes,
                                                          const int64_t *__restrict__ seg, int32_t *out_symbols,
-                                                         uint64_t *state, int64_t *pos_io)
+                                                         uint64_t *state, int64_t *pos_io, StridedSeg ss)
 {
     extern __shared__ uint32_t lds_words[];
     const uint16_t *lds16 = reinterpret_cast<const uint16_t *>(lds_words);
     const int stream = blockIdx.x;
     const int lane = threadIdx.x;
-    const int64_t beg = seg[stream];
-    const int64_t n = seg[stream + 1] - beg;
+    const int64_t beg = seg ? seg[stream] : ss.first + stream * ss.stride;
+    const int64_t n = seg ? seg[stream + 1] - beg : ss.count;
     const int32_t *idx = indexes + beg;
     int32_t *out = out_symbols + beg;
     if (LDS) {  // whole table set resident in LDS: the serial search never leaves the CU
@@ -634,13 +637,13 @@ __global__ __launch_bounds__(64) void rans_decode_fast_kernel(TablesDev T, const
                                                               const int64_t *__restrict__ word_off,
                                                               const int32_t *__restrict__ indexes,
                                                               const int64_t *__restrict__ seg, int32_t *out_symbols,
-                                                              uint64_t *state, int64_t *pos_io)
+                                                              uint64_t *state, int64_t *pos_io, StridedSeg ss)
 {
     extern __shared__ uint32_t img[];
     const int stream = blockIdx.x;
     const int lane = threadIdx.x;
-    const int64_t beg = seg[stream];
-    const int n = static_cast<int>(seg[stream + 1] - beg);
+    const int64_t beg = seg ? seg[stream] : ss.first + stream * ss.stride;
+    const int n = static_cast<int>(seg ? seg[stream + 1] - beg : ss.count);
     const int32_t *idx = indexes + beg;
     int32_t *out = out_symbols + beg;
     for (int i = lane; i < T.image_words; i += 64) img[i] = T.image[i];
@@ -802,7 +805,7 @@ constexpr size_t kLdsTableBudget = 144 * 1024;  // of the 160 KiB per CU
 template <bool AR, bool LDS>
 int launch_decode_v(const basic_rans_tables *t, const ArDev &ar, int nstreams, hipStream_t st, const uint32_t *d_words,
                     const int64_t *d_word_off, const int32_t *d_indexes, const int64_t *d_seg, int32_t *d_out,
-                    uint64_t *d_state, int64_t *d_pos)
+                    uint64_t *d_state, int64_t *d_pos, StridedSeg ss)
 {
     const size_t lds = LDS ? t->cdf16.size() * sizeof(uint16_t) : 0;
     if (LDS) {
@@ -814,14 +817,14 @@ int launch_decode_v(const basic_rans_tables *t, const ArDev &ar, int nstreams, h
         }
     }
     hipLaunchKernelGGL((rans_decode_kernel<AR, LDS>), dim3(nstreams), dim3(64), lds, st, dev_view(t), ar, d_words, d_word_off,
-                       d_indexes, d_seg, d_out, d_state, d_pos);
+                       d_indexes, d_seg, d_out, d_state, d_pos, ss);
     BASIC_HIP_TRY(hipGetLastError());
     return BASIC_OK;
 }
 
 int launch_decode(const basic_rans_tables *t, const ArDev &ar, int nstreams, hipStream_t st, const uint32_t *d_words,
                   const int64_t *d_word_off, const int32_t *d_indexes, const int64_t *d_seg, int32_t *d_out,
-                  uint64_t *d_state, int64_t *d_pos)
+                  uint64_t *d_state, int64_t *d_pos, StridedSeg ss = StridedSeg{0, 0, 0})
 {
     // LDS-resident tables pay a per-launch copy of the table set; worth it unless the launch is tiny.
     const bool lds = t->cdf16.size() * sizeof(uint16_t) <= kLdsTableBudget;
@@ -836,15 +839,15 @@ int launch_decode(const basic_rans_tables *t, const ArDev &ar, int nstreams, hip
             attr_set = true;
         }
         hipLaunchKernelGGL(rans_decode_fast_kernel, dim3(nstreams), dim3(64), t->image.size() * sizeof(uint32_t), st, dev_view(t),
-                           d_words, d_word_off, d_indexes, d_seg, d_out, d_state, d_pos);
+                           d_words, d_word_off, d_indexes, d_seg, d_out, d_state, d_pos, ss);
         BASIC_HIP_TRY(hipGetLastError());
         return BASIC_OK;
     }
     if (ar.tab)
-        return lds ? launch_decode_v<true, true>(t, ar, nstreams, st, d_words, d_word_off, d_indexes, d_seg, d_out, d_state, d_pos)
-                   : launch_decode_v<true, false>(t, ar, nstreams, st, d_words, d_word_off, d_indexes, d_seg, d_out, d_state, d_pos);
-    return lds ? launch_decode_v<false, true>(t, ar, nstreams, st, d_words, d_word_off, d_indexes, d_seg, d_out, d_state, d_pos)
-               : launch_decode_v<false, false>(t, ar, nstreams, st, d_words, d_word_off, d_indexes, d_seg, d_out, d_state, d_pos);
+        return lds ? launch_decode_v<true, true>(t, ar, nstreams, st, d_words, d_word_off, d_indexes, d_seg, d_out, d_state, d_pos, ss)
+                   : launch_decode_v<true, false>(t, ar, nstreams, st, d_words, d_word_off, d_indexes, d_seg, d_out, d_state, d_pos, ss);
+    return lds ? launch_decode_v<false, true>(t, ar, nstreams, st, d_words, d_word_off, d_indexes, d_seg, d_out, d_state, d_pos, ss)
+               : launch_decode_v<false, false>(t, ar, nstreams, st, d_words, d_word_off, d_indexes, d_seg, d_out, d_state, d_pos, ss);
 }
 
 }  // namespace
@@ -897,6 +900,22 @@ extern "C" int basic_rans_compact_streams_dev(const uint32_t *d_slots, int64_t s
                        d_nwords, d_out_off, d_out);
     BASIC_HIP_TRY(hipGetLastError());
     return BASIC_OK;
+}
+
+extern "C" int basic_rans_decode_batch_strided_dev(const basic_rans_tables *t, const uint32_t *d_words,
+                                                   const int64_t *d_word_off, const int32_t *d_indexes, int64_t first,
+                                                   int64_t stride, int64_t count, int nstreams, int32_t *d_out_symbols,
+                                                   uint64_t *d_state, int64_t *d_pos, void *hip_stream)
+{
+    if (!t) { set_error("ANS not initialized!"); return BASIC_ERR_NOT_INIT; }
+    BASIC_REQUIRE(d_words && d_word_off && d_indexes && d_out_symbols && d_state && d_pos && nstreams >= 1 && first >= 0 &&
+                      stride >= 0 && count >= 0,
+                  "rans_decode_batch_strided: bad argument");
+    BASIC_REQUIRE(!t->d_ar, "rans_decode_batch_strided: AR tables are only supported by the host-buffer entry points");
+    if (count == 0) return BASIC_OK;
+    ArDev ar{};
+    return launch_decode(t, ar, nstreams, as_stream(hip_stream), d_words, d_word_off, d_indexes, nullptr, d_out_symbols, d_state,
+                         d_pos, StridedSeg{first, stride, count});
 }
 
 // ---------------------------------------------------------------------------------------

@@ -216,6 +216,7 @@ class GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(HotPathModule):
         self._layer_key = None
         self._plans = {}
         self._scale_table_dev = None
+        self._graphs = {}
 
     # ------------------------------------------------------------------ state
     def update_state(self, *args, **kwargs) -> None:
@@ -226,6 +227,7 @@ class GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(HotPathModule):
                                     bypass=self.use_bypass_coding, bypass_precision=self.bypass_precision)
         self._layers = None
         self._scale_table_dev = None
+        self._graphs = {}
 
     def _ready(self):
         if self._tables is None:
@@ -236,6 +238,7 @@ class GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(HotPathModule):
         if self._layers is None or key != self._layer_key:
             self._layers = self._build_layers()
             self._layer_key = key
+            self._graphs = {}
 
     def _build_layers(self):
         """MaskedConvPlans of the context conv and the merger layers, with the activation that FOLLOWS a
@@ -327,8 +330,37 @@ class GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(HotPathModule):
             return B > 1
         return mode == "per_image"
 
+    # Many-group patterns (scanline: H*W groups) are launch-bound: ~5 tiny kernels per group.  Their whole
+    # per-group launch sequence is captured once per (batch, H, W) into a HIP graph and replayed.
+    GRAPH_MIN_GROUPS = 8
+
     def _run_encode(self, y, prior):
         self._ready()
+        plan = self._plan(y.shape[2], y.shape[3])
+        if len(plan.groups) < self.GRAPH_MIN_GROUPS or not getattr(self, "use_hip_graphs", True):
+            return self._run_encode_impl(y, prior)
+        key = ("enc", tuple(y.shape), prior is not None)
+        entry = self._graphs.get(key)
+        if entry is None:
+            sy = torch.empty_like(y)
+            sp = torch.empty_like(prior) if prior is not None else None
+            sy.copy_(y)
+            if sp is not None:
+                sp.copy_(prior)
+            self._run_encode_impl(sy, sp)          # eager warm-up: builds position lists, sets kernel attributes
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = self._run_encode_impl(sy, sp)
+            entry = self._graphs[key] = (graph, sy, sp, out)
+        graph, sy, sp, out = entry
+        sy.copy_(y)
+        if sp is not None:
+            sp.copy_(prior)
+        graph.replay()
+        return out
+
+    def _run_encode_impl(self, y, prior):
         B, C, H, W = y.shape
         plan = self._plan(H, W)
         ws = self._alloc(B, H, W, prior)
@@ -431,8 +463,45 @@ class GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(HotPathModule):
                 raise ValueError("rANS stream must hold >= 2 whole 32-bit words")
         woff = np.concatenate([[0], np.cumsum([len(s) // 4 for s in strings])]).astype(np.int64)
         dev = self.device
-        d_words = torch.from_numpy(np.frombuffer(b"".join(strings), dtype=np.int32).copy()).to(dev)
-        d_woff = torch.from_numpy(woff).to(dev)
+        words_np = np.frombuffer(b"".join(strings), dtype=np.int32)
+        use_graph = len(plan.groups) >= self.GRAPH_MIN_GROUPS and getattr(self, "use_hip_graphs", True) and per_image
+        if not use_graph:
+            d_words = torch.from_numpy(words_np.copy()).to(dev)
+            d_woff = torch.from_numpy(woff).to(dev)
+            return self._run_decode_impl(d_words, d_woff, prior, B, H, W, per_image)
+        # static buffers: per-image streams never exceed the encoder's slot bound plus slack
+        cap = B * (3 * n + 4)
+        key = ("dec", B, H, W, prior is not None)
+        entry = self._graphs.get(key)
+        if entry is None:
+            sw = torch.zeros((cap,), device=dev, dtype=torch.int32)
+            so = torch.zeros((B + 1,), device=dev, dtype=torch.int64)
+            sp = torch.empty_like(prior) if prior is not None else None
+            sw[: words_np.size].copy_(torch.from_numpy(words_np.copy()))
+            so.copy_(torch.from_numpy(woff))
+            if sp is not None:
+                sp.copy_(prior)
+            self._run_decode_impl(sw, so, sp, B, H, W, True)   # eager warm-up
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = self._run_decode_impl(sw, so, sp, B, H, W, True)
+            entry = self._graphs[key] = (graph, sw, so, sp, out)
+        graph, sw, so, sp, out = entry
+        if words_np.size > cap:
+            raise ValueError("encoded stream larger than the decoder's static buffer")
+        sw[: words_np.size].copy_(torch.from_numpy(words_np.copy()), non_blocking=False)
+        so.copy_(torch.from_numpy(woff))
+        if sp is not None:
+            sp.copy_(prior)
+        graph.replay()
+        return out.clone()
+
+    def _run_decode_impl(self, d_words, d_woff, prior, B, H, W, per_image):
+        dev, C = self.device, self.in_channels
+        plan = self._plan(H, W)
+        n = plan.per_image
+        ns = B if per_image else 1
         state = torch.zeros((ns,), device=dev, dtype=torch.int64)
         pos = torch.full((ns,), -1, device=dev, dtype=torch.int64)
         ws = self._alloc(B, H, W, prior)
@@ -448,7 +517,11 @@ class GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(HotPathModule):
                                                         self._scale_table_dev.data_ptr(), self._scale_table_dev.numel(),
                                                         idx.data_ptr(), n, grp["base"], K._stream()))
             if per_image:
-                self._decode_group(d_words, d_woff, idx, sym, grp["base"], ng, state, pos)
+                # stream b continues (decode_stream semantics, pgm_coder.py:971) with its ng symbols of this group,
+                # in place on the dense [B][n] arrays
+                _lib.check(L.basic_rans_decode_batch_strided_dev(self._tables._h, d_words.data_ptr(), d_woff.data_ptr(), idx.data_ptr(),
+                                                                 grp["base"], n, ng, B, sym.data_ptr(), state.data_ptr(), pos.data_ptr(),
+                                                                 K._stream()))
             else:
                 # single stream over the whole batch: gather this group's indexes batch-major
                 gi = idx[:, grp["base"]: grp["base"] + ng].reshape(-1).contiguous()
@@ -459,13 +532,3 @@ class GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(HotPathModule):
             _lib.check(L.basic_pgm_gauss_scatter_group_dev(sym.data_ptr(), params.data_ptr(), B, C, H * W, grp["elems"].data_ptr(), ng,
                                                           n, grp["base"], ws["ybuf"].data_ptr(), K._stream()))
         return ws["ybuf"]
-
-    def _decode_group(self, d_words, d_woff, idx, sym, lo, ng, state, pos):
-        """Per-image streams: stream b continues (decode_stream semantics, pgm_coder.py:971) with the ng symbols
-        whose indexes sit at idx[b, lo:lo+ng]."""
-        B = idx.shape[0]
-        gi = idx[:, lo: lo + ng].contiguous().reshape(-1)
-        go = torch.empty_like(gi)
-        seg = torch.arange(B + 1, device=idx.device, dtype=torch.int64) * ng
-        self._tables.decode_batch(d_words, d_woff, gi, seg, out=go, state=state, pos=pos)
-        sym[:, lo: lo + ng] = go.reshape(B, ng)

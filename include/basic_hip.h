@@ -107,6 +107,14 @@ int basic_rans_decode_batch_dev(const basic_rans_tables *t, const uint32_t *d_wo
                                 int nstreams, int32_t *d_out_symbols, uint64_t *d_state, int64_t *d_pos,
                                 void *hip_stream);
 
+/* Same decoder with arithmetic segments instead of a d_seg array: stream b decodes the `count` symbols whose
+ * indexes sit at d_indexes[first + b*stride ...] and writes them at the same positions of d_out_symbols.  This is
+ * the per-topo-group step of the AR coder (decode_stream, pgm_coder.py:971) on dense [B][n] arrays. */
+int basic_rans_decode_batch_strided_dev(const basic_rans_tables *t, const uint32_t *d_words,
+                                        const int64_t *d_word_off, const int32_t *d_indexes, int64_t first,
+                                        int64_t stride, int64_t count, int nstreams, int32_t *d_out_symbols,
+                                        uint64_t *d_state, int64_t *d_pos, void *hip_stream);
+
 /* ======================================================================================
  * 4. Entropy-parameter kernels (coalesced elementwise, fused quantise + table index).
  * ==================================================================================== */
