@@ -33,7 +33,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=256, help="images per GPU per step (weak scaling)")
     ap.add_argument("--size", type=int, default=256)
-    ap.add_argument("--cpu-images", type=int, default=64, help="bounded CPU-baseline sample (images)")
+    ap.add_argument("--cpu-images", type=int, default=2000, help="bounded CPU-baseline sample (images)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 
@@ -92,12 +92,12 @@ def cpu_baseline(codec_cpu_state, n_images, size):
     torch.manual_seed(0)
     oracle.decompress(oracle.compress(torch.rand(1, 3, size, size)))  # warm-up
     t0, done = time.time(), 0
-    for i in range(n_images):  # bounded sample: stop after ~20 s of CPU work
+    for i in range(n_images):  # bounded sample: stop after ~12 s of CPU work
         torch.manual_seed(i)
         x = torch.rand(1, 3, size, size)
         oracle.decompress(oracle.compress(x))
         done += 1
-        if time.time() - t0 > 20.0:
+        if time.time() - t0 > 12.0:
             break
     dt = time.time() - t0
     return dict(value=done * size * size / dt / 1e6, unit="Mpix/s", cores=cores, kind="port",
@@ -114,9 +114,9 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:  # launched by torch.distributed.run: one rank per GPU
         import torch.distributed as dist
-        dist.init_process_group("nccl")  # RCCL over xGMI
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # "nccl" IS RCCL on ROCm (xGMI)
     dev = torch.device("cuda", local_rank)
 
     from cbench_basic_amd.presets import hyperprior_codec, seed_synthetic_weights

@@ -21,7 +21,7 @@ def reduce_metric_sums(sums: Dict[str, float], device=None, time_key: str = "tim
     """All-reduce a dict of per-rank SUMS (count, bytes, psnr_sum, ...).  ``time_key`` is reduced with MAX
     (the job is as slow as its slowest rank); everything else with SUM.  No-op without a process group."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return dict(sums)
     keys = sorted(k for k in sums if k != time_key)
     vec = torch.tensor([float(sums[k]) for k in keys], dtype=torch.float64, device=device)
