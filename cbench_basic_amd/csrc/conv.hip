@@ -44,18 +44,22 @@ constexpr int kVeryFewTaps = 6;
 constexpr int kMaxTaps = 25;  // 5x5
 constexpr int kThreads = 256;
 constexpr int kTilePos = 128;  // output positions per workgroup
-constexpr int kPSlots = 12;             // patch elements per thread (patch <= 3072 floats)
+constexpr int kPSlots = 12;             // patch elements per thread (patch <= 3072 floats) ...
+constexpr int kPSlotsNarrow = 24;       // ... and for launches of <= 2 M-tiles, whose weight staging needs few registers
+constexpr int patch_slots(int mt) { return mt <= 2 ? kPSlotsNarrow : kPSlots; }
 constexpr int kMaxCoutPerLaunch = 192;  // 6 accumulator tiles per wave
+constexpr int kSplitBelowBlocks = 384;   // position grids smaller than this use the 32-channel-slice variant
 
 struct TapLaunch {
     const float *in;
     float *out;
-    const float *wpack;   // [cin_pad/CK][ntaps][CK][coutp]
-    const float *bias;    // [coutp] (zero padded) or nullptr
+    const float *wpack;   // [gridDim.y][cin_pad/CK][ntaps][CK][coutp]
+    const float *bias;    // [gridDim.y][coutp] (zero padded) or nullptr
+    int64_t split_wstride;  // floats between the weight packs of consecutive blockIdx.y output-channel slices
     const float *gammaT;  // [coutp(k)][coutp(i)] effective gamma transposed, zero padded
     const float *beta;    // [coutp]
     int batch, cin, cin_pad, cout, coutp;
-    int out_ctotal, co_base;  // this launch writes channels co_base .. co_base+cout of out_ctotal
+    int out_ctotal, co_base;  // this launch writes channels co_base .. co_base+cout of out_ctotal (slice y: coutp*y onwards)
     int in_h, in_w, out_h, out_w;
     int mh, mw;  // m-grid of this launch
     int s_in, s_out, oy0, ox0;
@@ -79,6 +83,12 @@ template <int MT, int kCK>
 __global__ __launch_bounds__(kThreads, (MT <= 4 ? 2 : 1)) void conv_tap_mfma_kernel(const TapLaunch g)
 {
     extern __shared__ float lds[];
+    constexpr int kPSlots = patch_slots(MT);
+    // output-channel slice of this block (small-grid launches spread Cout over blockIdx.y)
+    const float *const wpack = g.wpack + blockIdx.y * g.split_wstride;
+    const float *const bias = g.bias ? g.bias + blockIdx.y * g.coutp : nullptr;
+    const int co_base = g.co_base + blockIdx.y * g.coutp;
+    const int cout_here = (g.cout - static_cast<int>(blockIdx.y) * g.coutp < g.coutp) ? g.cout - static_cast<int>(blockIdx.y) * g.coutp : g.coutp;
     const int wl_floats = g.ntaps * kCK * g.coutp;
     const int gam_floats = 32 * g.coutp;
     float *wl = lds;                                                  // weight slab / gamma slab
@@ -150,7 +160,7 @@ __global__ __launch_bounds__(kThreads, (MT <= 4 ? 2 : 1)) void conv_tap_mfma_ker
 
 #define BASIC_FETCH_STAGE(C0)                                                                                   \
     do {                                                                                                       \
-        const f32x4 *src_ = reinterpret_cast<const f32x4 *>(g.wpack + static_cast<int64_t>((C0) / kCK) * wl_floats); \
+        const f32x4 *src_ = reinterpret_cast<const f32x4 *>(wpack + static_cast<int64_t>((C0) / kCK) * wl_floats); \
         _Pragma("unroll") for (int sl = 0; sl < kWSlots; ++sl) {                                               \
             const int i_ = tid + sl * kThreads;                                                                \
             if (i_ < wl_vec) wreg[sl] = src_[i_];                                                              \
@@ -219,12 +229,12 @@ __global__ __launch_bounds__(kThreads, (MT <= 4 ? 2 : 1)) void conv_tap_mfma_ker
 
     // ---- epilogue: bias
     // accumulator register r of tile m, lane (khalf, col): channel 32m + 8(r>>2) + 4 khalf + (r&3)
-    if (g.bias) {
+    if (bias) {
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int rq = 0; rq < 4; ++rq) {  // registers 4rq..4rq+3 are 4 consecutive channels: one 16-byte load
-                const f32x4 b4 = *reinterpret_cast<const f32x4 *>(g.bias + 32 * m + 8 * rq + 4 * khalf);
+                const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bias + 32 * m + 8 * rq + 4 * khalf);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[m][4 * rq + e] += b4[e];
             }
@@ -295,13 +305,13 @@ __global__ __launch_bounds__(kThreads, (MT <= 4 ? 2 : 1)) void conv_tap_mfma_ker
     if (lane_live && my < g.mh && mx < g.mw && b < g.batch) {
         const int oy = my * g.s_out + g.oy0, ox = mx * g.s_out + g.ox0;
         const int64_t plane = static_cast<int64_t>(g.out_h) * g.out_w;
-        float *o = g.out + (static_cast<int64_t>(b) * g.out_ctotal + g.co_base) * plane + static_cast<int64_t>(oy) * g.out_w + ox;
+        float *o = g.out + (static_cast<int64_t>(b) * g.out_ctotal + co_base) * plane + static_cast<int64_t>(oy) * g.out_w + ox;
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = 32 * m + 8 * (r >> 2) + 4 * khalf + (r & 3);
-                if (co < g.cout) o[co * plane] = apply_act(acc[m][r], g.act);
+                if (co < cout_here) o[co * plane] = apply_act(acc[m][r], g.act);
             }
     }
 }
@@ -424,10 +434,12 @@ struct Phase {
     int ck = kCKConv, cin_pad = 0;  // channels per LDS stage of this launch, cin rounded up to it
     signed char dy[kMaxTaps], dx[kMaxTaps];
     float *d_wpack = nullptr;
+    int64_t split_wstride = 0;  // floats per output-channel slice of d_wpack
 };
 
 struct Chunk {  // <= 192 output channels handled by one launch family
     int co0 = 0, cout = 0, coutp = 0, mt = 0;
+    int nsplit = 1;  // > 1: cout is cut into nsplit slices of coutp channels over gridDim.y
     std::vector<Phase> phases;
     float *d_bias = nullptr;
 };
@@ -438,6 +450,7 @@ struct basic_conv_plan {
     int cin = 0, cout = 0, ksize = 0, stride = 1, padding = 0, output_padding = 0, transposed = 0, act = 0;
     int s_in = 1, s_out = 1;
     std::vector<Chunk> chunks;
+    std::vector<Chunk> split;  // the same layer as 32-channel slices over gridDim.y (small position grids), may be empty
     float *d_gammaT = nullptr, *d_beta = nullptr;
     float *d_wsm = nullptr, *d_bias4 = nullptr;  // VALU path of the Cout <= 4 synthesis output layer
 };
@@ -445,11 +458,12 @@ struct basic_conv_plan {
 extern "C" void basic_conv_plan_destroy(basic_conv_plan *p)
 {
     if (!p) return;
-    for (auto &ch : p->chunks) {
-        for (auto &ph : ch.phases)
-            if (ph.d_wpack) (void)hipFree(ph.d_wpack);
-        if (ch.d_bias) (void)hipFree(ch.d_bias);
-    }
+    for (auto *list : {&p->chunks, &p->split})
+        for (auto &ch : *list) {
+            for (auto &ph : ch.phases)
+                if (ph.d_wpack) (void)hipFree(ph.d_wpack);
+            if (ch.d_bias) (void)hipFree(ch.d_bias);
+        }
     if (p->d_wsm) (void)hipFree(p->d_wsm);
     if (p->d_bias4) (void)hipFree(p->d_bias4);
     if (p->d_gammaT) (void)hipFree(p->d_gammaT);
@@ -463,6 +477,83 @@ int upload(const std::vector<float> &h, float **d)
 {
     BASIC_HIP_TRY(hipMalloc(d, h.size() * sizeof(float)));
     BASIC_HIP_TRY(hipMemcpy(*d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+    return BASIC_OK;
+}
+
+// Packs the weights of every (output-channel chunk, sub-pixel phase) launch.  per_chunk == 0: balanced chunks of
+// <= 192 channels, one launch family each.  per_chunk == 32: ONE Chunk whose phases hold the packs of all
+// 32-channel slices back to back (slice stride in Phase::split_wstride), launched with gridDim.y = slices.
+int build_chunks(basic_conv_plan *p, const float *weight, const float *bias, int cin, int cout, int slice,
+                 std::vector<Chunk> *out)
+{
+    const int ci_n = p->cin, co_n = p->cout, ksize = p->ksize, stride = p->stride, padding = p->padding;
+    const bool transposed = p->transposed != 0;
+    const int nph = transposed ? stride : 1;
+    const int n_chunks = slice ? 1 : (co_n + kMaxCoutPerLaunch - 1) / kMaxCoutPerLaunch;
+    const int per_chunk = slice ? co_n : ((co_n + n_chunks - 1) / n_chunks + 31) / 32 * 32;  // balanced, whole M-tiles
+    for (int co0 = 0; co0 < co_n; co0 += per_chunk) {
+        Chunk ch;
+        ch.co0 = co0;
+        ch.cout = (co_n - co0 < per_chunk) ? co_n - co0 : per_chunk;
+        ch.mt = slice ? slice / 32 : (ch.cout + 31) / 32;
+        ch.coutp = ch.mt * 32;
+        ch.nsplit = slice ? (ch.cout + slice - 1) / slice : 1;
+        for (int py = 0; py < nph; ++py)
+            for (int px = 0; px < nph; ++px) {
+                Phase ph;
+                ph.oy0 = py; ph.ox0 = px;
+                std::vector<int> kys, kxs, dys, dxs;
+                for (int k = 0; k < ksize; ++k) {
+                    if (!transposed) { kys.push_back(k); dys.push_back(k - padding); }
+                    else if ((py + padding - k) % stride == 0) { kys.push_back(k); dys.push_back((py + padding - k) / stride); }
+                }
+                for (int k = 0; k < ksize; ++k) {
+                    if (!transposed) { kxs.push_back(k); dxs.push_back(k - padding); }
+                    else if ((px + padding - k) % stride == 0) { kxs.push_back(k); dxs.push_back((px + padding - k) / stride); }
+                }
+                if (kys.empty() || kxs.empty()) {  // phase receives only the bias
+                    ph.ntaps = 0;
+                    ch.phases.push_back(ph);
+                    continue;
+                }
+                int dymin = dys[0], dymax = dys[0], dxmin = dxs[0], dxmax = dxs[0];
+                for (int v : dys) { dymin = v < dymin ? v : dymin; dymax = v > dymax ? v : dymax; }
+                for (int v : dxs) { dxmin = v < dxmin ? v : dxmin; dxmax = v > dxmax ? v : dxmax; }
+                ph.dymin = dymin; ph.dxmin = dxmin; ph.span_y = dymax - dymin + 1; ph.span_x = dxmax - dxmin + 1;
+                std::vector<std::pair<int, int>> taps;  // (ky, kx)
+                for (size_t a = 0; a < kys.size(); ++a)
+                    for (size_t b = 0; b < kxs.size(); ++b) {
+                        ph.dy[ph.ntaps] = static_cast<signed char>(dys[a] - dymin);
+                        ph.dx[ph.ntaps] = static_cast<signed char>(dxs[b] - dxmin);
+                        taps.emplace_back(kys[a], kxs[b]);
+                        ++ph.ntaps;
+                    }
+                // ---- pack weights: [slice][cin_pad/CK][ntaps][CK][coutp]
+                const int kCK = ph.ntaps <= kVeryFewTaps ? kCKVeryFew : (ph.ntaps <= kFewTaps ? kCKFew : kCKConv);
+                ph.ck = kCK;
+                ph.cin_pad = (ci_n + kCK - 1) / kCK * kCK;
+                ph.split_wstride = static_cast<int64_t>(ph.cin_pad) * ph.ntaps * ch.coutp;
+                std::vector<float> wp(static_cast<size_t>(ph.split_wstride) * ch.nsplit, 0.f);
+                for (int c = 0; c < ci_n; ++c)
+                    for (int t = 0; t < ph.ntaps; ++t)
+                        for (int o = 0; o < ch.cout; ++o) {
+                            const int ky = taps[t].first, kx = taps[t].second, og = co0 + o;
+                            const float w = transposed
+                                ? weight[((static_cast<size_t>(c) * cout + og) * ksize + ky) * ksize + kx]
+                                : weight[((static_cast<size_t>(og) * cin + c) * ksize + ky) * ksize + kx];
+                            wp[static_cast<size_t>(o / ch.coutp) * ph.split_wstride +
+                               ((static_cast<size_t>(c / kCK) * ph.ntaps + t) * kCK + (c % kCK)) * ch.coutp + o % ch.coutp] = w;
+                        }
+                const int rc = upload(wp, &ph.d_wpack);
+                ch.phases.push_back(ph);
+                if (rc) { out->push_back(ch); return rc; }
+            }
+        std::vector<float> hb(static_cast<size_t>(ch.coutp) * ch.nsplit, 0.f);
+        if (bias) std::memcpy(hb.data(), bias + co0, sizeof(float) * ch.cout);
+        const int rc = upload(hb, &ch.d_bias);
+        out->push_back(ch);
+        if (rc) return rc;
+    }
     return BASIC_OK;
 }
 
@@ -506,67 +597,13 @@ extern "C" int basic_conv_plan_create(const float *weight, const float *bias, in
         return BASIC_OK;
     }
 
-    const int nph = transposed ? stride : 1;
-    const int n_chunks = (co_n + kMaxCoutPerLaunch - 1) / kMaxCoutPerLaunch;
-    const int per_chunk = ((co_n + n_chunks - 1) / n_chunks + 31) / 32 * 32;  // balanced, whole M-tiles
-    for (int co0 = 0; co0 < co_n; co0 += per_chunk) {
-        Chunk ch;
-        ch.co0 = co0;
-        ch.cout = (co_n - co0 < per_chunk) ? co_n - co0 : per_chunk;
-        ch.mt = (ch.cout + 31) / 32;
-        ch.coutp = ch.mt * 32;
-        for (int py = 0; py < nph; ++py)
-            for (int px = 0; px < nph; ++px) {
-                Phase ph;
-                ph.oy0 = py; ph.ox0 = px;
-                std::vector<int> kys, kxs, dys, dxs;
-                for (int k = 0; k < ksize; ++k) {
-                    if (!transposed) { kys.push_back(k); dys.push_back(k - padding); }
-                    else if ((py + padding - k) % stride == 0) { kys.push_back(k); dys.push_back((py + padding - k) / stride); }
-                }
-                for (int k = 0; k < ksize; ++k) {
-                    if (!transposed) { kxs.push_back(k); dxs.push_back(k - padding); }
-                    else if ((px + padding - k) % stride == 0) { kxs.push_back(k); dxs.push_back((px + padding - k) / stride); }
-                }
-                if (kys.empty() || kxs.empty()) {  // phase receives only the bias
-                    ph.ntaps = 0;
-                    ch.phases.push_back(ph);
-                    continue;
-                }
-                int dymin = dys[0], dymax = dys[0], dxmin = dxs[0], dxmax = dxs[0];
-                for (int v : dys) { dymin = v < dymin ? v : dymin; dymax = v > dymax ? v : dymax; }
-                for (int v : dxs) { dxmin = v < dxmin ? v : dxmin; dxmax = v > dxmax ? v : dxmax; }
-                ph.dymin = dymin; ph.dxmin = dxmin; ph.span_y = dymax - dymin + 1; ph.span_x = dxmax - dxmin + 1;
-                std::vector<std::pair<int, int>> taps;  // (ky, kx)
-                for (size_t a = 0; a < kys.size(); ++a)
-                    for (size_t b = 0; b < kxs.size(); ++b) {
-                        ph.dy[ph.ntaps] = static_cast<signed char>(dys[a] - dymin);
-                        ph.dx[ph.ntaps] = static_cast<signed char>(dxs[b] - dxmin);
-                        taps.emplace_back(kys[a], kxs[b]);
-                        ++ph.ntaps;
-                    }
-                // ---- pack weights: [cin_pad/CK][ntaps][CK][coutp]
-                const int kCK = ph.ntaps <= kVeryFewTaps ? kCKVeryFew : (ph.ntaps <= kFewTaps ? kCKFew : kCKConv);
-                ph.ck = kCK;
-                ph.cin_pad = (ci_n + kCK - 1) / kCK * kCK;
-                std::vector<float> wp(static_cast<size_t>(ph.cin_pad) * ph.ntaps * ch.coutp, 0.f);
-                for (int c = 0; c < ci_n; ++c)
-                    for (int t = 0; t < ph.ntaps; ++t)
-                        for (int o = 0; o < ch.cout; ++o) {
-                            const int ky = taps[t].first, kx = taps[t].second, og = co0 + o;
-                            const float w = transposed
-                                ? weight[((static_cast<size_t>(c) * cout + og) * ksize + ky) * ksize + kx]
-                                : weight[((static_cast<size_t>(og) * cin + c) * ksize + ky) * ksize + kx];
-                            wp[((static_cast<size_t>(c / kCK) * ph.ntaps + t) * kCK + (c % kCK)) * ch.coutp + o] = w;
-                        }
-                rc = upload(wp, &ph.d_wpack);
-                ch.phases.push_back(ph);
-                if (rc) { p->chunks.push_back(ch); basic_conv_plan_destroy(p); return rc; }
-            }
-        std::vector<float> hb(ch.coutp, 0.f);
-        if (bias) std::memcpy(hb.data(), bias + co0, sizeof(float) * ch.cout);
-        rc = upload(hb, &ch.d_bias);
-        p->chunks.push_back(ch);
+    rc = build_chunks(p, weight, bias, cin, cout, 0, &p->chunks);
+    if (rc) { basic_conv_plan_destroy(p); return rc; }
+    // Small-grid variant: 32-channel slices spread over blockIdx.y, used when the position grid alone
+    // cannot fill the chip (the 4x4 .. 16x16 maps of the hyper transforms).  GDN needs all channels
+    // of a position in one block, so only the plain-activation layers get it.
+    if (!gdn && co_n >= 64) {
+        rc = build_chunks(p, weight, bias, cin, cout, 32, &p->split);
         if (rc) { basic_conv_plan_destroy(p); return rc; }
     }
     if (gdn) {
@@ -618,7 +655,7 @@ extern "C" int64_t basic_conv_plan_flops(const basic_conv_plan *p, int batch, in
 namespace {
 
 template <int MT, int CK>
-int launch_one(const TapLaunch &g, int blocks, size_t lds_bytes, hipStream_t st)
+int launch_one(const TapLaunch &g, int blocks, int nsplit, size_t lds_bytes, hipStream_t st)
 {
     static bool attr_set = false;
     if (!attr_set) {
@@ -626,16 +663,16 @@ int launch_one(const TapLaunch &g, int blocks, size_t lds_bytes, hipStream_t st)
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_tap_mfma_kernel<MT, CK>), dim3(blocks), dim3(kThreads), lds_bytes, st, g);
+    hipLaunchKernelGGL((conv_tap_mfma_kernel<MT, CK>), dim3(blocks, nsplit), dim3(kThreads), lds_bytes, st, g);
     BASIC_HIP_TRY(hipGetLastError());
     return BASIC_OK;
 }
 
 template <int MT>
-int launch_mt(const TapLaunch &g, int ck, int blocks, size_t lds_bytes, hipStream_t st)
+int launch_mt(const TapLaunch &g, int ck, int blocks, int nsplit, size_t lds_bytes, hipStream_t st)
 {
-    if (ck == kCKVeryFew) return launch_one<MT, kCKVeryFew>(g, blocks, lds_bytes, st);
-    return ck == kCKFew ? launch_one<MT, kCKFew>(g, blocks, lds_bytes, st) : launch_one<MT, kCKConv>(g, blocks, lds_bytes, st);
+    if (ck == kCKVeryFew) return launch_one<MT, kCKVeryFew>(g, blocks, nsplit, lds_bytes, st);
+    return ck == kCKFew ? launch_one<MT, kCKFew>(g, blocks, nsplit, lds_bytes, st) : launch_one<MT, kCKConv>(g, blocks, nsplit, lds_bytes, st);
 }
 
 int ilog2(int v) { int l = 0; while ((1 << (l + 1)) <= v) ++l; return l; }
@@ -661,10 +698,15 @@ extern "C" int basic_conv_forward_dev(const basic_conv_plan *p, const float *d_i
         BASIC_HIP_TRY(hipGetLastError());
         return BASIC_OK;
     }
-    for (const Chunk &ch : p->chunks)
+    // small position grids: spread the output channels over gridDim.y instead of looping them inside a block
+    const int64_t pos_blocks = (static_cast<int64_t>(batch) * ((oh + p->s_out - 1) / p->s_out) * ((ow + p->s_out - 1) / p->s_out) + kTilePos - 1) / kTilePos;
+    const char *dbg_env = getenv("BASIC_CONV_DEBUG");
+    const int dbg = dbg_env ? atoi(dbg_env) : 0;  // profiling ablations: 1 skip staging, 2 skip MFMA loop, 4 force slices, 8 forbid slices
+    const bool use_split = !p->split.empty() && !(dbg & 8) && (pos_blocks < kSplitBelowBlocks || (dbg & 4));
+    for (const Chunk &ch : (use_split ? p->split : p->chunks))
     for (const Phase &ph : ch.phases) {
         TapLaunch g{};
-        g.in = d_in; g.out = d_out; g.wpack = ph.d_wpack; g.bias = ch.d_bias; g.gammaT = p->d_gammaT; g.beta = p->d_beta;
+        g.in = d_in; g.out = d_out; g.wpack = ph.d_wpack; g.split_wstride = ph.split_wstride; g.bias = ch.d_bias; g.gammaT = p->d_gammaT; g.beta = p->d_beta;
         g.batch = batch; g.cin = p->cin; g.cin_pad = ph.ntaps ? ph.cin_pad : 0; g.cout = ch.cout; g.coutp = ch.coutp; g.out_ctotal = p->cout; g.co_base = ch.co0;
         g.in_h = in_h; g.in_w = in_w; g.out_h = oh; g.out_w = ow;
         g.s_in = p->s_in; g.s_out = p->s_out; g.oy0 = ph.oy0; g.ox0 = ph.ox0;
@@ -676,7 +718,7 @@ extern "C" int basic_conv_forward_dev(const basic_conv_plan *p, const float *d_i
         std::memcpy(g.dx, ph.dx, sizeof(g.dx));
         g.act = p->act;
         const int kCK = ph.ck;
-        { const char *e = getenv("BASIC_CONV_DEBUG"); g.debug = e ? atoi(e) : 0; }
+        g.debug = dbg;
         // tile shape: 128 positions = TB images x TH x TW, powers of two, preferring wide rows
         int tw = pow2_ceil(g.mw); if (tw > 16) tw = 16;
         int th = pow2_ceil(g.mh); if (th > kTilePos / tw) th = kTilePos / tw;
@@ -684,7 +726,7 @@ extern "C" int basic_conv_forward_dev(const basic_conv_plan *p, const float *d_i
         g.ph = (th - 1) * g.s_in + ph.span_y;
         g.pw = (tw - 1) * g.s_in + ph.span_x;
         g.pwp = g.pw | 1;  // odd row pitch
-        while (tb > 1 && tb * kCK * g.ph * g.pwp > kPSlots * kThreads) tb >>= 1;  // patch must fit the staging registers
+        while (tb > 1 && tb * kCK * g.ph * g.pwp > patch_slots(ch.mt) * kThreads) tb >>= 1;  // patch must fit the staging registers
         g.tw_log = ilog2(tw); g.th_log = ilog2(th); g.tb_log = ilog2(tb);
         g.tiles_y = (g.mh + th - 1) / th;
         g.tiles_x = (g.mw + tw - 1) / tw;
@@ -692,17 +734,17 @@ extern "C" int basic_conv_forward_dev(const basic_conv_plan *p, const float *d_i
         const int wl_floats = g.ntaps * kCK * g.coutp, gam_floats = 32 * g.coutp;
         const size_t lds_bytes = sizeof(float) * (static_cast<size_t>(wl_floats > gam_floats ? wl_floats : gam_floats) +
                                                  static_cast<size_t>(tb) * kCK * g.ph * g.pwp + kMaxTaps);
-        BASIC_REQUIRE(tb * kCK * g.ph * g.pwp <= kPSlots * kThreads, "conv_forward: input patch exceeds the staging registers");
+        BASIC_REQUIRE(tb * kCK * g.ph * g.pwp <= patch_slots(ch.mt) * kThreads, "conv_forward: input patch exceeds the staging registers");
         BASIC_REQUIRE(static_cast<int64_t>(tb) * p->cin * in_h * in_w < (1ll << 29), "conv_forward: input tile too large");
         BASIC_REQUIRE(lds_bytes <= 160 * 1024, "conv_forward: LDS budget exceeded");
         hipStream_t st = as_stream(hip_stream);
         switch (ch.mt) {
-            case 1: rc = launch_mt<1>(g, kCK, blocks, lds_bytes, st); break;
-            case 2: rc = launch_mt<2>(g, kCK, blocks, lds_bytes, st); break;
-            case 3: rc = launch_mt<3>(g, kCK, blocks, lds_bytes, st); break;
-            case 4: rc = launch_mt<4>(g, kCK, blocks, lds_bytes, st); break;
-            case 5: rc = launch_mt<5>(g, kCK, blocks, lds_bytes, st); break;
-            case 6: rc = launch_mt<6>(g, kCK, blocks, lds_bytes, st); break;
+            case 1: rc = launch_mt<1>(g, kCK, blocks, ch.nsplit, lds_bytes, st); break;
+            case 2: rc = launch_mt<2>(g, kCK, blocks, ch.nsplit, lds_bytes, st); break;
+            case 3: rc = launch_mt<3>(g, kCK, blocks, ch.nsplit, lds_bytes, st); break;
+            case 4: rc = launch_mt<4>(g, kCK, blocks, ch.nsplit, lds_bytes, st); break;
+            case 5: rc = launch_mt<5>(g, kCK, blocks, ch.nsplit, lds_bytes, st); break;
+            case 6: rc = launch_mt<6>(g, kCK, blocks, ch.nsplit, lds_bytes, st); break;
             default: set_error("conv_forward: cout > 192 unsupported"); rc = BASIC_ERR_INVALID;
         }
         if (rc) return rc;
