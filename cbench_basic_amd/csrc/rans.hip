@@ -45,6 +45,15 @@ struct basic_rans_tables {
     std::vector<uint32_t> image, meta;
     uint32_t *d_image = nullptr, *d_meta = nullptr;
     bool fast_ok = false;
+    // Encoder image of the fast encoder: one 16-byte entry per (row, value) --
+    //   x = freq | (2^precision - freq) << 16,  y = post_shift | start' << 8,  z,w = 64-bit reciprocal
+    // with start' = start (+ 2^precision - 1 for freq == 1, whose reciprocal 2^64-1 yields q = x - 1) --
+    // and per row (offset, max_value).  Everything the serial chain needs for a symbol is one gather.
+    std::vector<uint32_t> enc;      // [rows][stride][4]
+    std::vector<int32_t> rowinfo;   // [rows][2]
+    uint32_t *d_enc = nullptr;
+    int32_t *d_rowinfo = nullptr;
+    bool fast_enc_ok = false;
 };
 
 namespace {
@@ -132,6 +141,45 @@ int upload_tables(basic_rans_tables *t)
         BASIC_HIP_TRY(hipMemcpy(t->d_image, t->image.data(), t->image.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         BASIC_HIP_TRY(hipMemcpy(t->d_meta, t->meta.data(), t->meta.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
+    // fast-encoder image
+    t->fast_enc_ok = t->rows <= 2048 && static_cast<size_t>(t->rows) * t->stride <= (4u << 20);
+    if (t->fast_enc_ok) {
+        const uint32_t one = 1u << t->precision;
+        t->enc.assign(static_cast<size_t>(t->rows) * t->stride * 4, 0u);
+        t->rowinfo.resize(static_cast<size_t>(t->rows) * 2);
+        for (int r = 0; r < t->rows && t->fast_enc_ok; ++r) {
+            const int32_t *row = &t->cdfs[static_cast<size_t>(r) * t->stride];
+            t->rowinfo[2 * r] = t->offsets[r];
+            t->rowinfo[2 * r + 1] = t->sizes[r] - 2;
+            for (int v = 0; v + 1 < t->sizes[r]; ++v) {
+                const uint32_t start = static_cast<uint32_t>(row[v]) & 0xFFFFu;           // uint16_t casts, rans64.cpp:289-291
+                const uint32_t freq = static_cast<uint32_t>(row[v + 1] - row[v]) & 0xFFFFu;
+                if (freq == 0 || freq >= one + (t->precision == 16 ? 0u : 1u) || freq > 0xFFFFu) { t->fast_enc_ok = false; break; }
+                uint64_t rcp = ~0ull;
+                uint32_t post_shift = 0, start_adj = start + (one - 1u);
+                if (freq >= 2u) {
+                    uint32_t shift = 0;
+                    while ((1u << shift) < freq) ++shift;  // ceil(log2 freq)
+                    const unsigned __int128 num = (static_cast<unsigned __int128>(1) << (63 + shift)) + (freq - 1u);
+                    rcp = static_cast<uint64_t>(num / freq);
+                    post_shift = shift - 1u;
+                    start_adj = start;
+                }
+                uint32_t *e = &t->enc[(static_cast<size_t>(r) * t->stride + v) * 4];
+                e[0] = freq | ((one - freq) << 16);
+                e[1] = post_shift | (start_adj << 8);
+                e[2] = static_cast<uint32_t>(rcp);
+                e[3] = static_cast<uint32_t>(rcp >> 32);
+            }
+        }
+    }
+    if (t->fast_enc_ok) {
+        BASIC_HIP_TRY(hipMalloc(&t->d_enc, t->enc.size() * sizeof(uint32_t)));
+        BASIC_HIP_TRY(hipMalloc(&t->d_rowinfo, t->rowinfo.size() * sizeof(int32_t)));
+        BASIC_HIP_TRY(hipMemcpy(t->d_enc, t->enc.data(), t->enc.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        BASIC_HIP_TRY(hipMemcpy(t->d_rowinfo, t->rowinfo.data(), t->rowinfo.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
+    t->enc.clear(); t->enc.shrink_to_fit();
     return BASIC_OK;
 }
 
@@ -270,6 +318,8 @@ extern "C" void basic_rans_tables_destroy(basic_rans_tables *t)
     if (t->d_base) (void)hipFree(t->d_base);
     if (t->d_image) (void)hipFree(t->d_image);
     if (t->d_meta) (void)hipFree(t->d_meta);
+    if (t->d_enc) (void)hipFree(t->d_enc);
+    if (t->d_rowinfo) (void)hipFree(t->d_rowinfo);
     delete t;
 }
 
@@ -288,6 +338,8 @@ struct TablesDev {
     int total16;            // entries in cdf16 (even)
     const uint32_t *image, *meta;  // fast-decoder search image (see basic_rans_tables)
     int image_words;
+    const uint4 *enc;        // fast-encoder image [rows][stride] (see basic_rans_tables)
+    const int2 *rowinfo;     // [rows] (offset, max_value)
 };
 
 // Alternative to a seg[] array: stream b codes the elements [first + b*stride, first + b*stride + count).
@@ -445,6 +497,126 @@ __global__ __launch_bounds__(64) void rans_encode_kernel(TablesDev T, ArDev ar, 
             put_symbol(x, em, lane, bcast_u32(start, j), bcast_u32(freq, j), bcast_u64(rcp, j),
                        bcast_u32(post_shift, j), prec);
         }
+    }
+    em.push(static_cast<uint32_t>(x >> 32), lane);  // flush, rans64.h:87-94
+    em.push(static_cast<uint32_t>(x), lane);
+    if (lane == 0) out_nwords[stream] = em.overflow ? -1 : static_cast<int32_t>((slot + slot_words) - em.p);
+}
+
+// Lean encoder for the common case (no AR remap, every frequency in [1, 2^16)).  Same arithmetic as
+// rans_encode_kernel, reorganised around the single-wave issue rate that bounds it:
+//   * the per-symbol division constants come from the encoder image (one 16-byte gather per lane)
+//     instead of two 64-bit divisions per lane and chunk;
+//   * the gathers of chunk k+1 and the symbol/index loads of chunk k+2 are in flight while chunk k is
+//     folded into the state, so the serial chain never waits for memory;
+//   * freq == 1 needs no branch (reciprocal 2^64-1 gives q = x-1, the missing 2^p-1 is folded into start).
+struct EncLane {
+    uint32_t a, b, rl, rh, raw;
+};
+
+__device__ __forceinline__ EncLane enc_prepare(const TablesDev &T, const int2 *rowinfo_lds, bool live, int32_t row, int32_t s)
+{
+    EncLane e{1u | (1u << 16), 0u, ~0u, ~0u, 0u};
+    if (live) {
+        row = clampi(row, 0, T.rows - 1);
+        const int2 ri = rowinfo_lds[row];
+        const int32_t max_value = ri.y;
+        int32_t value = s - ri.x;
+        uint32_t byp = 0;
+        if (T.bypass) {
+            if (value < 0) { e.raw = static_cast<uint32_t>(-2 * value - 1); value = max_value; }
+            else if (value >= max_value) { e.raw = static_cast<uint32_t>(2 * (value - max_value)); value = max_value; }
+            byp = (value == max_value) ? 0x80u : 0u;
+        }
+        value = clampi(value, 0, max_value);  // without bypass the reference is UB out of range
+        const uint4 t = T.enc[static_cast<int64_t>(row) * T.stride + value];
+        e.a = t.x; e.b = t.y | byp; e.rl = t.z; e.rh = t.w;
+    }
+    return e;
+}
+
+__global__ __launch_bounds__(64) void rans_encode_fast_kernel(TablesDev T, const int32_t *__restrict__ symbols,
+                                                              const int32_t *__restrict__ indexes,
+                                                              const int64_t *__restrict__ seg, uint32_t *out_words,
+                                                              int64_t slot_words, int32_t *out_nwords)
+{
+    extern __shared__ uint32_t lds_words[];
+    int2 *rowinfo_lds = reinterpret_cast<int2 *>(lds_words);
+    const int stream = blockIdx.x;
+    const int lane = threadIdx.x;
+    for (int r = lane; r < T.rows; r += 64) rowinfo_lds[r] = T.rowinfo[r];
+    __syncthreads();
+    const int64_t beg = seg[stream];
+    const int64_t n = seg[stream + 1] - beg;
+    const int32_t *sym = symbols + beg;
+    const int32_t *idx = indexes + beg;
+    uint32_t *slot = out_words + static_cast<int64_t>(stream) * slot_words;
+    Emitter em{slot + slot_words, slot, false};
+    uint64_t x = kRansL;
+    const uint32_t xs = 31u - static_cast<uint32_t>(T.precision);  // x >= freq << (63-p)  <=>  (x >> 32) >= freq << (31-p)
+    const uint32_t bprec = static_cast<uint32_t>(T.bypass_precision);
+    const uint32_t maxbv = (1u << bprec) - 1u;
+
+    // software pipeline over chunks of 64 symbols (last chunk first; lane 63 = last symbol of a chunk)
+    int64_t i1 = n - 64 + lane;               // element of this lane in the chunk being prepared
+    int32_t row1 = 0, s1 = 0;
+    if (i1 >= 0) { row1 = idx[i1]; s1 = sym[i1]; }
+    EncLane cur = enc_prepare(T, rowinfo_lds, i1 >= 0, row1, s1);
+    int64_t i2 = i1 - 64;
+    int32_t row2 = 0, s2 = 0;
+    if (i2 >= 0) { row2 = idx[i2]; s2 = sym[i2]; }
+
+    for (int64_t hi = n; hi > 0; hi -= 64) {
+        // next chunk's gather and the loads of the chunk after it, in flight during the serial fold below
+        const EncLane nxt = enc_prepare(T, rowinfo_lds, i2 >= 0, row2, s2);
+        const int64_t i3 = i2 - 64;
+        int32_t row3 = 0, s3 = 0;
+        if (i3 >= 0) { row3 = idx[i3]; s3 = sym[i3]; }
+
+        // The broadcasts of symbol j-1 are issued before the arithmetic of symbol j (two alternating
+        // scalar register sets): a lone wave issues in order, so a readlane consumed right away would
+        // stall the whole chain for its latency.
+#define BASIC_ENC_LOAD(SET, J)                                                                                  \
+        do {                                                                                                   \
+            const int j_ = (J) < 0 ? 0 : (J);                                                                  \
+            SET##a = bcast_u32(cur.a, j_); SET##b = bcast_u32(cur.b, j_);                                      \
+            SET##l = bcast_u32(cur.rl, j_); SET##h = bcast_u32(cur.rh, j_);                                    \
+        } while (0)
+#define BASIC_ENC_STEP(SET, J)                                                                                  \
+        do {                                                                                                   \
+            if (__builtin_expect((SET##b & 0x80u) != 0u, 0)) {                                                 \
+                /* decode order: sentinel, count nibbles, payload low-first  =>  written reversed */          \
+                const uint32_t r = bcast_u32(cur.raw, (J));                                                    \
+                int nb = 0;                                                                                    \
+                while (nb * bprec < 32u && (r >> (nb * bprec)) != 0u) ++nb;                                    \
+                for (int k = nb - 1; k >= 0; --k) put_raw(x, em, lane, (r >> (k * bprec)) & maxbv, bprec);     \
+                put_raw(x, em, lane, static_cast<uint32_t>(nb) % maxbv, bprec);                                \
+                for (uint32_t k = 0; k < static_cast<uint32_t>(nb) / maxbv; ++k) put_raw(x, em, lane, maxbv, bprec); \
+            }                                                                                                  \
+            if (__builtin_expect(static_cast<uint32_t>(x >> 32) >= ((SET##a & 0xFFFFu) << xs), 0)) {           \
+                em.push(static_cast<uint32_t>(x), lane);                                                       \
+                x >>= 32;                                                                                      \
+            }                                                                                                  \
+            const uint64_t rcp_ = static_cast<uint64_t>(SET##l) | (static_cast<uint64_t>(SET##h) << 32);       \
+            const uint64_t q_ = __umul64hi(x, rcp_) >> (SET##b & 63u);                                         \
+            x = x + (SET##b >> 8) + q_ * (SET##a >> 16); /* (q << p) + (x - q*freq) + start */                 \
+        } while (0)
+        const int j_lo = hi >= 64 ? 0 : static_cast<int>(64 - hi);
+        uint32_t e0a, e0b, e0l, e0h, e1a, e1b, e1l, e1h;
+        int j = 63;
+        BASIC_ENC_LOAD(e0, j);
+        while (j - 1 >= j_lo) {
+            BASIC_ENC_LOAD(e1, j - 1);
+            BASIC_ENC_STEP(e0, j);
+            BASIC_ENC_LOAD(e0, j - 2);
+            BASIC_ENC_STEP(e1, j - 1);
+            j -= 2;
+        }
+        if (j >= j_lo) BASIC_ENC_STEP(e0, j);
+#undef BASIC_ENC_LOAD
+#undef BASIC_ENC_STEP
+        cur = nxt;
+        i2 = i3; row2 = row3; s2 = s3;
     }
     em.push(static_cast<uint32_t>(x >> 32), lane);  // flush, rans64.h:87-94
     em.push(static_cast<uint32_t>(x), lane);
@@ -786,7 +958,8 @@ TablesDev dev_view(const basic_rans_tables *t)
 {
     return TablesDev{t->d_cdfs, t->d_sizes, t->d_offsets, t->rows, t->stride, t->precision, t->bypass, t->bypass_precision,
                      t->d_cdf16, t->d_base, static_cast<int>(t->cdf16.size()),
-                     t->d_image, t->d_meta, static_cast<int>(t->image.size())};
+                     t->d_image, t->d_meta, static_cast<int>(t->image.size()),
+                     reinterpret_cast<const uint4 *>(t->d_enc), reinterpret_cast<const int2 *>(t->d_rowinfo)};
 }
 
 struct DevBuf {
@@ -868,6 +1041,14 @@ extern "C" int basic_rans_encode_batch_dev(const basic_rans_tables *t, const int
     BASIC_REQUIRE(d_symbols && d_indexes && d_seg && d_out_words && d_out_nwords && nstreams >= 1 && slot_words >= 2,
                   "rans_encode_batch: bad argument");
     BASIC_REQUIRE(!t->d_ar, "rans_encode_batch: AR tables are only supported by the host-buffer entry points");
+    static const bool no_fast = getenv("BASIC_RANS_NO_FAST_ENCODE") != nullptr;  // profiling ablation
+    if (t->fast_enc_ok && !no_fast) {
+        hipLaunchKernelGGL(rans_encode_fast_kernel, dim3(nstreams), dim3(64), static_cast<size_t>(t->rows) * sizeof(int2),
+                           as_stream(hip_stream), dev_view(t), d_symbols, d_indexes, d_seg, d_out_words, slot_words,
+                           d_out_nwords);
+        BASIC_HIP_TRY(hipGetLastError());
+        return BASIC_OK;
+    }
     ArDev ar{};
     hipLaunchKernelGGL(rans_encode_kernel, dim3(nstreams), dim3(64), 0, as_stream(hip_stream), dev_view(t), ar,
                        d_symbols, d_indexes, d_seg, d_out_words, slot_words, d_out_nwords);
