@@ -845,7 +845,7 @@ __global__ __launch_bounds__(64) void rans_decode_fast_kernel(TablesDev T, const
     const uint32_t mask = (1u << prec) - 1u;
     const uint32_t bprec = static_cast<uint32_t>(T.bypass_precision);
     const uint32_t maxbv = (1u << bprec) - 1u;
-    const bool bypass = T.bypass != 0;
+    const int32_t bsub = T.bypass ? 2 : static_cast<int32_t>(0x80000000u);  // size - bsub = sentinel symbol
 
     auto next_word = [&]() -> uint32_t {
         if (pos - wbase >= 64) {
@@ -876,19 +876,20 @@ __global__ __launch_bounds__(64) void rans_decode_fast_kernel(TablesDev T, const
         int32_t result = 0;
         const int cnt = (n - c0) < 64 ? (n - c0) : 64;
 
-        auto probe = [&](int jj) -> uint32_t { return img[(bcast_u32(meta_l, jj) & 0x3FFFFu) + lane]; };
-        auto decode_one = [&](int j, uint32_t p) {
-            const uint32_t meta = bcast_u32(meta_l, j);
+        // (row word, first-level probe) of a symbol, fetched two symbols ahead of its use
+        auto fetch = [&](int jj, uint32_t &m, uint32_t &p) {
+            m = bcast_u32(meta_l, jj);
+            p = img[(m & 0x3FFFFu) + lane];
+        };
+        auto decode_one = [&](int j, uint32_t meta, uint32_t p) {
             const int32_t size = static_cast<int32_t>(meta >> 18);
             const uint32_t cf = xl & mask;
             const int first = __builtin_ctzll(__ballot(p > cf));
-            uint32_t c_t, c_s;
-            int32_t s;
-            if (size <= 64) {  // first >= 1 because entry 0 is 0 <= cf
-                c_t = bcast_u32(p, first);
-                c_s = bcast_u32(p, first - 1);
-                s = first - 1;
-            } else {
+            // rows of <= 64 entries: the probe vector is the row (first >= 1 because entry 0 is 0 <= cf)
+            uint32_t c_t = bcast_u32(p, first);
+            uint32_t c_s = bcast_u32(p, first - 1);  // lane select is taken mod 64; unused when first == 0 (wide rows only)
+            int32_t s = first - 1;
+            if (__builtin_expect(size > 64, 0)) {
                 const int32_t step = (size + 63) >> 6;
                 const int32_t lo = first * step;
                 const int32_t span = (lo + step <= size) ? step : (size - lo);
@@ -896,7 +897,7 @@ __global__ __launch_bounds__(64) void rans_decode_fast_kernel(TablesDev T, const
                 const int tl = __builtin_ctzll(__ballot(va > cf));
                 c_t = bcast_u32(va, tl);
                 // entry lo-1 is the last entry of the previous block = that block's probe value
-                c_s = tl > 0 ? bcast_u32(va, tl - 1) : bcast_u32(p, first - 1);
+                if (tl > 0) c_s = bcast_u32(va, tl - 1);
                 s = lo + tl - 1;
             }
             // x = freq * (x >> prec) + (cf - c_s)   (rans64.h:128-142), on 32-bit halves
@@ -906,9 +907,9 @@ __global__ __launch_bounds__(64) void rans_decode_fast_kernel(TablesDev T, const
             const uint64_t prod = static_cast<uint64_t>(freq) * t_lo + (cf - c_s);
             xl = static_cast<uint32_t>(prod);
             xh = static_cast<uint32_t>(prod >> 32) + freq * t_hi;
-            if (xh == 0u && xl < 0x80000000u) { xh = xl; xl = next_word(); }
+            if (__builtin_expect((xh | (xl >> 31)) == 0u, 0)) { xh = xl; xl = next_word(); }
             int32_t value = s;
-            if (bypass && value == size - 2) {
+            if (__builtin_expect(value == size - bsub, 0)) {  // the bypass sentinel (never matches without bypass coding)
                 uint32_t v = get_bits(bprec);
                 uint32_t nb = v;
                 while (v == maxbv) { v = get_bits(bprec); nb += v; }
@@ -923,16 +924,17 @@ __global__ __launch_bounds__(64) void rans_decode_fast_kernel(TablesDev T, const
             result = (lane == j) ? value : result;
         };
 
-        uint32_t pa = probe(0);
-        uint32_t pb = probe(cnt > 1 ? 1 : 0);
-        for (int j = 0; j < cnt; j += 2) {
-            decode_one(j, pa);
-            pa = probe(j + 2 < cnt ? j + 2 : cnt - 1);  // two symbols ahead
-            if (j + 1 < cnt) {
-                decode_one(j + 1, pb);
-                pb = probe(j + 3 < cnt ? j + 3 : cnt - 1);
-            }
+        uint32_t ma, pa, mb, pb;
+        fetch(0, ma, pa);
+        fetch(cnt > 1 ? 1 : 0, mb, pb);
+        int j = 0;
+        for (; j + 1 < cnt; j += 2) {
+            decode_one(j, ma, pa);
+            fetch(j + 2 < cnt ? j + 2 : cnt - 1, ma, pa);  // two symbols ahead
+            decode_one(j + 1, mb, pb);
+            fetch(j + 3 < cnt ? j + 3 : cnt - 1, mb, pb);
         }
+        if (j < cnt) decode_one(j, ma, pa);
         if (i < n) out[i] = result + off_l;
     }
     if (lane == 0) {
