@@ -37,7 +37,11 @@ L = [("g_a.1 3->128 s2 gdn @256", 3, 128, 5, 2, False, K.ACT_GDN, B, 256, 256),
      ("g_s.1 192->128 T igdn @16", 192, 128, 5, 2, True, K.ACT_IGDN, B, 16, 16),
      ("g_s.2 128->128 T igdn @32", 128, 128, 5, 2, True, K.ACT_IGDN, B, 32, 32),
      ("g_s.3 128->128 T igdn @64", 128, 128, 5, 2, True, K.ACT_IGDN, B, 64, 64),
-     ("g_s.4 128->3 T @128", 128, 3, 5, 2, True, K.ACT_NONE, B, 128, 128)]
+     ("g_s.4 128->3 T @128", 128, 3, 5, 2, True, K.ACT_NONE, B, 128, 128),
+     # ablations (not layers of the codec): the two big layers without their GDN epilogue
+     ("x_a.2 128->128 s2 relu @128", 128, 128, 5, 2, False, K.ACT_RELU, B, 128, 128),
+     ("x_s.3 128->128 T relu @64", 128, 128, 5, 2, True, K.ACT_RELU, B, 64, 64),
+     ("y_a.2 512->128 s2 relu @128 (4x longer K)", 512, 128, 5, 2, False, K.ACT_RELU, B // 4, 128, 128)]
 for l in L:
-    if which == "all" or which in l[0]:
+    if (which == "all" and not l[0].startswith("x_")) or which in l[0]:
         bench(*l)
