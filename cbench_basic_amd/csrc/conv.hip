@@ -36,16 +36,16 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kCKConv = 4;    // input channels per LDS stage for many-tap layers (5x5 conv: 25 taps)
-constexpr int kCKFew = 8;     // ... and for few-tap launches (3x3 conv, sub-pixel phases of the 5x5 deconv: <= 9 taps)
+constexpr int kCKConv = 2;    // input channels per LDS stage for many-tap layers (5x5 conv: 25 taps)
+constexpr int kCKFew = 4;     // ... and for few-tap launches (3x3 conv, sub-pixel phases of the 5x5 deconv: <= 9 taps)
 constexpr int kFewTaps = 9;
-constexpr int kCKVeryFew = 16;  // ... and for <= 6 taps (3 of the 4 sub-pixel phases)
+constexpr int kCKVeryFew = 8;   // ... and for <= 6 taps (3 of the 4 sub-pixel phases)
 constexpr int kVeryFewTaps = 6;
 constexpr int kMaxTaps = 25;  // 5x5
 constexpr int kThreads = 256;
 constexpr int kTilePos = 128;  // output positions per workgroup
-constexpr int kPSlots = 12;             // patch elements per thread (patch <= 3072 floats) ...
-constexpr int kPSlotsNarrow = 24;       // ... and for launches of <= 2 M-tiles, whose weight staging needs few registers
+constexpr int kPSlots = 12;             // patch elements per thread and stage (patch <= 3072 floats) ...
+constexpr int kPSlotsNarrow = 24;       // ... and for launches of <= 2 M-tiles, which have the registers for more descriptors
 constexpr int patch_slots(int mt) { return mt <= 2 ? kPSlotsNarrow : kPSlots; }
 constexpr int kMaxCoutPerLaunch = 192;  // 6 accumulator tiles per wave
 constexpr int kSplitBelowBlocks = 384;   // position grids smaller than this use the 32-channel-slice variant
@@ -53,10 +53,10 @@ constexpr int kSplitBelowBlocks = 384;   // position grids smaller than this use
 struct TapLaunch {
     const float *in;
     float *out;
-    const float *wpack;   // [gridDim.y][cin_pad/CK][ntaps][CK][coutp]
+    const float *wpack;   // [gridDim.y][cin_pad/CK][ntaps][CK][32][MTP]  (MTP = mtile_pitch(coutp / 32))
     const float *bias;    // [gridDim.y][coutp] (zero padded) or nullptr
     int64_t split_wstride;  // floats between the weight packs of consecutive blockIdx.y output-channel slices
-    const float *gammaT;  // [coutp(k)][coutp(i)] effective gamma transposed, zero padded
+    const float *gammaT;  // [coutp(k)][32][MTP]: gamma[i = 32 m + col][k] at [k][col][m], zero padded
     const float *beta;    // [coutp]
     int batch, cin, cin_pad, cout, coutp;
     int out_ctotal, co_base;  // this launch writes channels co_base .. co_base+cout of out_ctotal (slice y: coutp*y onwards)
@@ -79,21 +79,53 @@ __device__ __forceinline__ float apply_act(float v, int act)
     return v;
 }
 
-template <int MT, int kCK>
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_cvoid;
+
+__device__ const float basic_zero_page[64] = {0.f};  // source of every zero-filled patch element
+
+// One lane's A fragments of a (tap, channel) step: MTP consecutive floats = one ds_read_b32/b64/b128 (two for MTP 8).
+template <int MTP>
+__device__ __forceinline__ void load_a(const float *p, float (&d)[MTP])
+{
+    if constexpr (MTP == 1) {
+        d[0] = p[0];
+    } else if constexpr (MTP == 2) {
+        const f32x2 v = *reinterpret_cast<const f32x2 *>(p);
+        d[0] = v[0]; d[1] = v[1];
+    } else {
+#pragma unroll
+        for (int q = 0; q < MTP / 4; ++q) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(p + 4 * q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) d[4 * q + e] = v[e];
+        }
+    }
+}
+
+constexpr int mtile_pitch(int mt) { return mt <= 1 ? 1 : (mt <= 2 ? 2 : (mt <= 4 ? 4 : 8)); }
+
+// KH x KW > 0: the launch's taps form a dense KH x KW grid (tap t = row t / KW, column t % KW of the
+// patch) and the whole stage is unrolled with compile-time LDS offsets; KH = 0: runtime tap table.
+template <int MT, int kCK, int KH, int KW>
 __global__ __launch_bounds__(kThreads, (MT <= 4 ? 2 : 1)) void conv_tap_mfma_kernel(const TapLaunch g)
 {
     extern __shared__ float lds[];
     constexpr int kPSlots = patch_slots(MT);
+    constexpr int MTP = mtile_pitch(MT);  // A fragments of a lane sit MTP floats apart: [tap][ci][col][MTP]
     // output-channel slice of this block (small-grid launches spread Cout over blockIdx.y)
     const float *const wpack = g.wpack + blockIdx.y * g.split_wstride;
     const float *const bias = g.bias ? g.bias + blockIdx.y * g.coutp : nullptr;
     const int co_base = g.co_base + blockIdx.y * g.coutp;
     const int cout_here = (g.cout - static_cast<int>(blockIdx.y) * g.coutp < g.coutp) ? g.cout - static_cast<int>(blockIdx.y) * g.coutp : g.coutp;
-    const int wl_floats = g.ntaps * kCK * g.coutp;
-    const int gam_floats = 32 * g.coutp;
-    float *wl = lds;                                                  // weight slab / gamma slab
-    float *patch = lds + (wl_floats > gam_floats ? wl_floats : gam_floats);  // input patch
-
+    // LDS: two stage buffers { weight slab [tap][ci][col][MTP] | input patch [TB][CK][PH][PWP] }, filled by
+    // LDS-DMA (global_load_lds: no VGPR round trip, no ds_write) one stage ahead of the MFMAs that read
+    // them, then the tap-offset table of the runtime-tap variant.  The DMA image is lane-linear, which is
+    // why both regions are padded to whole wave-instructions (1024 / 256 floats per 256 threads).
+    const int wl_floats = g.ntaps * kCK * 32 * MTP;
+    const int gam_floats = 32 * 32 * MTP;
+    const int wl_pad = ((wl_floats > gam_floats ? wl_floats : gam_floats) + 1023) & ~1023;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int khalf = lane >> 5, col = lane & 31;
@@ -115,7 +147,7 @@ __global__ __launch_bounds__(kThreads, (MT <= 4 ? 2 : 1)) void conv_tap_mfma_ker
 
     const int chan_stride = g.ph * g.pwp;
     const int lane_b_base = ((tb * kCK + khalf) * g.ph + ty * g.s_in) * g.pwp + tx * g.s_in;
-    const int lane_a_base = khalf * g.coutp + col;
+    const int lane_a_base = (khalf * 32 + col) * MTP;
 
     f32x16 acc[MT];
 #pragma unroll
@@ -124,105 +156,131 @@ __global__ __launch_bounds__(kThreads, (MT <= 4 ? 2 : 1)) void conv_tap_mfma_ker
         for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
 
     const int patch_elems = TB * kCK * chan_stride;
+    const int patch_pad = (patch_elems + 255) & ~255;
+    const int stage_floats = wl_pad + patch_pad;
+    const int n_wslots = wl_pad >> 10, n_pslots = patch_pad >> 8;
+    const int nstages = g.cin_pad / kCK;
     const int gy0 = my0 * g.s_in + g.dymin, gx0 = mx0 * g.s_in + g.dxmin;
     const int64_t in_plane = static_cast<int64_t>(g.in_h) * g.in_w;
     const int64_t in_img = static_cast<int64_t>(g.cin) * in_plane;
     const float *in_b0 = g.in + static_cast<int64_t>(b0) * in_img;
 
-    // Per-thread gather descriptors, computed once: patch element i = tid + 256*s reads the global
-    // offset ge[s] >> 2 (relative to image b0, first channel of the stage) of in-stage channel
-    // ge[s] & 3, or is zero-filled when ge[s] < 0.  They live in registers so that each stage's
-    // global loads are independent and can be issued back to back, one stage AHEAD of the MFMAs.
-    int *tapoff = reinterpret_cast<int *>(patch + patch_elems);  // [ntaps] LDS offsets of the taps
-    if (tid < g.ntaps) tapoff[tid] = g.dy[tid] * g.pwp + g.dx[tid];
-    int ge[kPSlots];
+    int *tapoff = reinterpret_cast<int *>(lds + 2 * stage_floats);  // [ntaps] LDS offsets of the taps
+    if (KH == 0 && tid < g.ntaps) tapoff[tid] = g.dy[tid] * g.pwp + g.dx[tid];
+
+    // Per-thread gather descriptors, computed once: patch element i = tid + 256*s of every stage is DMA'd
+    // from pp[s], which then advances by pstride[s] bytes (CK channels); elements outside the image (and the
+    // padding of the patch) read a zero word and never move.  Slots whose channel does not exist in the last
+    // stage (cin not a multiple of CK) are flagged in lastmask.
+    const float *pp[kPSlots];
+    int pstride[kPSlots];
+    unsigned lastmask = 0;
 #pragma unroll
     for (int sl = 0; sl < kPSlots; ++sl) {
         int r = tid + sl * kThreads;
-        int e = -1;
+        const float *ptr = basic_zero_page;
+        int stride = 0;
         if (r < patch_elems) {
             const int px = r % g.pwp; r /= g.pwp;
             const int py = r % g.ph; r /= g.ph;
             const int ci = r % kCK;
             const int pb = r / kCK;
             const int gy = gy0 + py, gx = gx0 + px;
-            if (px < g.pw && gy >= 0 && gy < g.in_h && gx >= 0 && gx < g.in_w && b0 + pb < g.batch)
-                e = ((pb * static_cast<int>(in_img) + gy * g.in_w + gx) << 4) | ci;
+            if (px < g.pw && gy >= 0 && gy < g.in_h && gx >= 0 && gx < g.in_w && b0 + pb < g.batch && ci < g.cin) {
+                ptr = in_b0 + pb * in_img + ci * in_plane + gy * g.in_w + gx;
+                stride = static_cast<int>(kCK * in_plane * 4);
+                if ((nstages - 1) * kCK + ci >= g.cin) lastmask |= 1u << sl;
+            }
         }
-        ge[sl] = e;
+        pp[sl] = ptr;
+        pstride[sl] = stride;
     }
 
     constexpr int kStageTaps = (kCK == kCKConv) ? kMaxTaps : (kCK == kCKFew ? kFewTaps : kVeryFewTaps);
-    constexpr int kWSlots = (kStageTaps * kCK * 32 * MT / 4 + kThreads - 1) / kThreads;
-    f32x4 wreg[kWSlots];
-    float preg[kPSlots];
-    const int wl_vec = wl_floats / 4;
+    constexpr int kWSlotsMax = (((KH > 0 ? KH * KW : kStageTaps) * kCK * 32 * MTP > 32 * 32 * MTP
+                                     ? (KH > 0 ? KH * KW : kStageTaps) * kCK * 32 * MTP : 32 * 32 * MTP) + 1023) / 1024;
 
-#define BASIC_FETCH_STAGE(C0)                                                                                   \
+// DMA of stage S (weights + patch) into buffer BUF; advances the patch pointers to stage S+1.
+#define BASIC_ISSUE_STAGE(S, BUF)                                                                              \
     do {                                                                                                       \
-        const f32x4 *src_ = reinterpret_cast<const f32x4 *>(wpack + static_cast<int64_t>((C0) / kCK) * wl_floats); \
-        _Pragma("unroll") for (int sl = 0; sl < kWSlots; ++sl) {                                               \
-            const int i_ = tid + sl * kThreads;                                                                \
-            if (i_ < wl_vec) wreg[sl] = src_[i_];                                                              \
+        float *dstw_ = lds + (BUF) * stage_floats;                                                             \
+        const float *srcw_ = wpack + static_cast<int64_t>(S) * wl_floats + tid * 4;                            \
+        _Pragma("unroll") for (int sl = 0; sl < kWSlotsMax; ++sl)                                              \
+            if (sl < n_wslots)                                                                                 \
+                __builtin_amdgcn_global_load_lds((glb_cvoid *)(srcw_ + sl * 1024),                             \
+                                                 (lds_void *)(dstw_ + sl * 1024 + wave * 256), 16, 0, 0);      \
+        if ((S) == nstages - 1 && lastmask) {                                                                  \
+            _Pragma("unroll") for (int sl = 0; sl < kPSlots; ++sl)                                             \
+                if ((lastmask >> sl) & 1u) pp[sl] = basic_zero_page;                                           \
         }                                                                                                      \
-        const float *in_c0_ = in_b0 + static_cast<int64_t>(C0) * in_plane;                                     \
-        _Pragma("unroll") for (int sl = 0; sl < kPSlots; ++sl) {                                               \
-            const int e_ = ge[sl];                                                                             \
-            float v_ = 0.f;                                                                                    \
-            if (e_ >= 0 && (C0) + (e_ & (kCK - 1)) < g.cin) v_ = in_c0_[(e_ >> 4) + (e_ & (kCK - 1)) * in_plane];              \
-            preg[sl] = v_;                                                                                     \
-        }                                                                                                      \
-    } while (0)
-#define BASIC_COMMIT_STAGE()                                                                                   \
-    do {                                                                                                       \
-        f32x4 *dst_ = reinterpret_cast<f32x4 *>(wl);                                                           \
-        _Pragma("unroll") for (int sl = 0; sl < kWSlots; ++sl) {                                               \
-            const int i_ = tid + sl * kThreads;                                                                \
-            if (i_ < wl_vec) dst_[i_] = wreg[sl];                                                              \
-        }                                                                                                      \
-        _Pragma("unroll") for (int sl = 0; sl < kPSlots; ++sl) {                                               \
-            const int i_ = tid + sl * kThreads;                                                                \
-            if (i_ < patch_elems) patch[i_] = preg[sl];                                                        \
-        }                                                                                                      \
+        float *dstp_ = dstw_ + wl_pad;                                                                         \
+        _Pragma("unroll") for (int sl = 0; sl < kPSlots; ++sl)                                                 \
+            if (sl < n_pslots) {                                                                               \
+                __builtin_amdgcn_global_load_lds((glb_cvoid *)pp[sl], (lds_void *)(dstp_ + sl * 256 + wave * 64), 4, 0, 0); \
+                pp[sl] = reinterpret_cast<const float *>(reinterpret_cast<const char *>(pp[sl]) + pstride[sl]); \
+            }                                                                                                  \
     } while (0)
 
-    if (g.cin_pad > 0 && !(g.debug & 1)) BASIC_FETCH_STAGE(0);
-    for (int c0 = 0; c0 < g.cin_pad; c0 += kCK) {
-        __syncthreads();  // every wave is done reading the previous stage
-        if (!(g.debug & 1)) BASIC_COMMIT_STAGE();
+    if (nstages > 0 && !(g.debug & 1)) BASIC_ISSUE_STAGE(0, 0);
+    for (int stg = 0; stg < nstages; ++stg) {
+        // my DMAs of this stage have landed (vmcnt(0), part of the barrier's fence) + every wave is past the
+        // previous stage, whose buffer the next DMA overwrites
         __syncthreads();
-        if (c0 + kCK < g.cin_pad && !(g.debug & 1)) BASIC_FETCH_STAGE(c0 + kCK);  // in flight during the MFMAs below
+        if (stg + 1 < nstages && !(g.debug & 1)) BASIC_ISSUE_STAGE(stg + 1, (stg + 1) & 1);  // in flight during the MFMAs below
+        const float *wl = lds + (stg & 1) * stage_floats;
+        const float *patch = wl + wl_pad;
         // ---- MFMA over (tap, channel pair) steps.  The fragment reads of the next step are issued
         // before the MFMAs of the current one, on two alternating register sets (no copies, so the
         // compiler's counted lgkmcnt waits keep the next step's reads in flight while the matrix
         // core works); sched_barriers pin that order against the machine scheduler.
         if (!(g.debug & 2)) {
-            constexpr int kPairs = kCK / 2;  // even: the two register sets alternate statically
-            float fa[2][MT], fb[2];
-            int toff = tapoff[0];
-            fb[0] = patch[lane_b_base + toff];
+            constexpr int kPairs = kCK / 2;
+            float fa[2][MTP], fb[2];
+            if constexpr (KH > 0) {
+                // Straight-line stage: every fragment address is lane base + compile-time offset (plus one
+                // wave-uniform row/channel term), so a step is one ds_read_b32 (B), one ds_read_b128 (A) and
+                // MT MFMAs.  The matrix pipe loses throughput to every other instruction the SIMD issues, so
+                // nothing else may sit between the MFMAs.
+                constexpr int kSteps = KH * KW * kPairs;
+                const float *a_lane = wl + lane_a_base;
+                const float *b_lane = patch + lane_b_base;
+                fb[0] = b_lane[0];
+                load_a<MTP>(a_lane, fa[0]);
 #pragma unroll
-            for (int m = 0; m < MT; ++m) fa[0][m] = wl[lane_a_base + m * 32];
-            for (int t = 0; t < g.ntaps; ++t) {
-                const int tn = (t + 1 < g.ntaps) ? t + 1 : t;
-                const int toff_n = tapoff[tn];
-#pragma unroll
-                for (int cp = 0; cp < kPairs; ++cp) {
-                    const int cur = cp & 1, nxt = cur ^ 1;
-                    // next step: (t, cp+1) or (t+1, 0); at the very end a harmless re-read
-                    const bool wrap = (cp + 1 == kPairs);
-                    const int nt = wrap ? tn : t, ncp = wrap ? 0 : cp + 1;
-                    fb[nxt] = patch[lane_b_base + (wrap ? toff_n : toff) + ncp * 2 * chan_stride];
-                    const float *wn = wl + (nt * kCK + ncp * 2) * g.coutp + lane_a_base;
-#pragma unroll
-                    for (int m = 0; m < MT; ++m) fa[nxt][m] = wn[m * 32];
+                for (int st = 0; st < kSteps; ++st) {
+                    const int cur = st & 1, nxt = cur ^ 1;
+                    const int sn = (st + 1 < kSteps) ? st + 1 : st;  // at the very end a harmless re-read
+                    const int tn = sn / kPairs, cpn = sn % kPairs;
+                    fb[nxt] = b_lane[(tn / KW) * g.pwp + cpn * 2 * chan_stride + (tn % KW)];
+                    load_a<MTP>(a_lane + (tn * kCK + cpn * 2) * 32 * MTP, fa[nxt]);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int m = 0; m < MT; ++m)
                         acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][m], fb[cur], acc[m], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                toff = toff_n;
+            } else {
+                // Runtime tap table, one step = (tap, channel pair).
+                const int nsteps = g.ntaps * kPairs;
+                fb[0] = patch[lane_b_base + tapoff[0]];
+                load_a<MTP>(wl + lane_a_base, fa[0]);
+                for (int st = 0; st < nsteps; st += 2) {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {  // two steps per iteration: the register sets alternate statically
+                        const int cur = u, nxt = u ^ 1;
+                        const int sn = (st + u + 1 < nsteps) ? st + u + 1 : st + u;
+                        const int tn = sn / kPairs, cpn = sn % kPairs;
+                        fb[nxt] = patch[lane_b_base + tapoff[tn] + cpn * 2 * chan_stride];
+                        load_a<MTP>(wl + (tn * kCK + cpn * 2) * 32 * MTP + lane_a_base, fa[nxt]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (st + u < nsteps) {
+#pragma unroll
+                            for (int m = 0; m < MT; ++m)
+                                acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][m], fb[cur], acc[m], 0, 0, 0);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
             }
         }
     }
@@ -247,41 +305,30 @@ __global__ __launch_bounds__(kThreads, (MT <= 4 ? 2 : 1)) void conv_tap_mfma_ker
         for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int r = 0; r < 16; ++r) nrm[m][r] = 0.f;
-        // gamma^T is walked 32 k-rows at a time through the (now free) weight slab; the next 32 rows are
-        // prefetched through registers while the MFMAs of the current ones run.
-        constexpr int kGSlots = (32 * 32 * MT / 4 + kThreads - 1) / kThreads;
-        f32x4 greg[kGSlots];
-        const int gam_vec = gam_floats / 4;
-#define BASIC_FETCH_GAMMA(MK)                                                                                   \
+        // gamma^T is walked 32 k-rows at a time through the two (now free) stage buffers, again by LDS-DMA
+        // one chunk ahead of the MFMAs that read it.
+#define BASIC_ISSUE_GAMMA(MK)                                                                                   \
     do {                                                                                                       \
-        const f32x4 *src_ = reinterpret_cast<const f32x4 *>(g.gammaT + static_cast<int64_t>(MK) * 32 * g.coutp); \
-        _Pragma("unroll") for (int sl = 0; sl < kGSlots; ++sl) {                                               \
-            const int i_ = tid + sl * kThreads;                                                                \
-            if (i_ < gam_vec) greg[sl] = src_[i_];                                                             \
-        }                                                                                                      \
+        float *dst_ = lds + ((nstages + (MK)) & 1) * stage_floats;                                             \
+        const float *src_ = g.gammaT + static_cast<int64_t>(MK) * gam_floats + tid * 4;                        \
+        _Pragma("unroll") for (int sl = 0; sl < MTP; ++sl)                                                     \
+            __builtin_amdgcn_global_load_lds((glb_cvoid *)(src_ + sl * 1024), (lds_void *)(dst_ + sl * 1024 + wave * 256), 16, 0, 0); \
     } while (0)
-        BASIC_FETCH_GAMMA(0);
+        BASIC_ISSUE_GAMMA(0);
 #pragma unroll
         for (int mk = 0; mk < MT; ++mk) {  // k rows 32mk .. 32mk+31
-            __syncthreads();
-            {
-                f32x4 *dst = reinterpret_cast<f32x4 *>(wl);
-#pragma unroll
-                for (int sl = 0; sl < kGSlots; ++sl) {
-                    const int i = tid + sl * kThreads;
-                    if (i < gam_vec) dst[i] = greg[sl];
-                }
-            }
-            __syncthreads();
-            if (mk + 1 < MT) BASIC_FETCH_GAMMA(mk + 1);
+            __syncthreads();  // chunk mk landed; every wave is done with the buffer the next chunk overwrites
+            if (mk + 1 < MT) BASIC_ISSUE_GAMMA(mk + 1);
+            const float *wl = lds + ((nstages + mk) & 1) * stage_floats;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float x = acc[mk][r];
                 const float bfrag = x * x;  // k = 32mk + 8(r>>2) + (r&3) [+4 for lanes 32..63]
-                const float *gk = wl + (8 * (r >> 2) + (r & 3) + 4 * khalf) * g.coutp + col;
+                float gk[MTP];
+                load_a<MTP>(wl + ((8 * (r >> 2) + (r & 3) + 4 * khalf) * 32 + col) * MTP, gk);
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
-                    nrm[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(gk[m * 32], bfrag, nrm[m], 0, 0, 0);
+                    nrm[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(gk[m], bfrag, nrm[m], 0, 0, 0);
             }
         }
 #pragma unroll
@@ -432,6 +479,7 @@ struct Phase {
     int ntaps = 0, dymin = 0, dxmin = 0, span_y = 1, span_x = 1;
     int oy0 = 0, ox0 = 0;
     int ck = kCKConv, cin_pad = 0;  // channels per LDS stage of this launch, cin rounded up to it
+    int kh = 0, kw = 0;             // the taps form a dense kh x kw grid, tap t at (t / kw, t % kw)
     signed char dy[kMaxTaps], dx[kMaxTaps];
     float *d_wpack = nullptr;
     int64_t split_wstride = 0;  // floats per output-channel slice of d_wpack
@@ -520,30 +568,40 @@ int build_chunks(basic_conv_plan *p, const float *weight, const float *bias, int
                 for (int v : dys) { dymin = v < dymin ? v : dymin; dymax = v > dymax ? v : dymax; }
                 for (int v : dxs) { dxmin = v < dxmin ? v : dxmin; dxmax = v > dxmax ? v : dxmax; }
                 ph.dymin = dymin; ph.dxmin = dxmin; ph.span_y = dymax - dymin + 1; ph.span_x = dxmax - dxmin + 1;
-                std::vector<std::pair<int, int>> taps;  // (ky, kx)
+                // taps sorted by patch position: tap t reads patch offset (t / kw, t % kw)
+                ph.kh = ph.span_y; ph.kw = ph.span_x;
+                std::vector<std::pair<int, int>> taps(static_cast<size_t>(ph.kh) * ph.kw, {-1, -1});  // (ky, kx)
                 for (size_t a = 0; a < kys.size(); ++a)
                     for (size_t b = 0; b < kxs.size(); ++b) {
-                        ph.dy[ph.ntaps] = static_cast<signed char>(dys[a] - dymin);
-                        ph.dx[ph.ntaps] = static_cast<signed char>(dxs[b] - dxmin);
-                        taps.emplace_back(kys[a], kxs[b]);
-                        ++ph.ntaps;
+                        const int t = (dys[a] - dymin) * ph.kw + (dxs[b] - dxmin);
+                        taps[t] = {kys[a], kxs[b]};
                     }
-                // ---- pack weights: [slice][cin_pad/CK][ntaps][CK][coutp]
+                ph.ntaps = ph.kh * ph.kw;
+                for (int t = 0; t < ph.ntaps; ++t) {
+                    ph.dy[t] = static_cast<signed char>(t / ph.kw);
+                    ph.dx[t] = static_cast<signed char>(t % ph.kw);
+                }
+                // ---- pack weights: [slice][cin_pad/CK][ntaps][CK][32][MTP]
                 const int kCK = ph.ntaps <= kVeryFewTaps ? kCKVeryFew : (ph.ntaps <= kFewTaps ? kCKFew : kCKConv);
+                const int mtp = mtile_pitch(ch.mt);
                 ph.ck = kCK;
                 ph.cin_pad = (ci_n + kCK - 1) / kCK * kCK;
-                ph.split_wstride = static_cast<int64_t>(ph.cin_pad) * ph.ntaps * ch.coutp;
+                ph.split_wstride = static_cast<int64_t>(ph.cin_pad) * ph.ntaps * 32 * mtp;
                 std::vector<float> wp(static_cast<size_t>(ph.split_wstride) * ch.nsplit, 0.f);
                 for (int c = 0; c < ci_n; ++c)
-                    for (int t = 0; t < ph.ntaps; ++t)
+                    for (int t = 0; t < ph.ntaps; ++t) {
+                        const int ky = taps[t].first, kx = taps[t].second;
+                        if (ky < 0) continue;  // a hole in the grid keeps zero weights
                         for (int o = 0; o < ch.cout; ++o) {
-                            const int ky = taps[t].first, kx = taps[t].second, og = co0 + o;
+                            const int og = co0 + o, ol = o % ch.coutp;
                             const float w = transposed
                                 ? weight[((static_cast<size_t>(c) * cout + og) * ksize + ky) * ksize + kx]
                                 : weight[((static_cast<size_t>(og) * cin + c) * ksize + ky) * ksize + kx];
                             wp[static_cast<size_t>(o / ch.coutp) * ph.split_wstride +
-                               ((static_cast<size_t>(c / kCK) * ph.ntaps + t) * kCK + (c % kCK)) * ch.coutp + o % ch.coutp] = w;
+                               (((static_cast<size_t>(c / kCK) * ph.ntaps + t) * kCK + (c % kCK)) * 32 + ol % 32) * mtp + ol / 32] = w;
                         }
+                    }
+                wp.resize(wp.size() + 1024, 0.f);  // the DMA copies whole 4 KB pieces and may read past the last stage
                 const int rc = upload(wp, &ph.d_wpack);
                 ch.phases.push_back(ph);
                 if (rc) { out->push_back(ch); return rc; }
@@ -608,13 +666,15 @@ extern "C" int basic_conv_plan_create(const float *weight, const float *bias, in
     }
     if (gdn) {
         if (p->chunks.size() != 1) { basic_conv_plan_destroy(p); set_error("conv_plan_create: GDN needs cout <= 192"); return BASIC_ERR_INVALID; }
-        const int coutp = p->chunks[0].coutp;
-        // gamma [cout][cout] effective -> gammaT[k][i] = gamma[i][k], zero padded; beta padded with 1
-        std::vector<float> gt(static_cast<size_t>(coutp) * coutp, 0.f), bt(coutp, 1.f);
+        const int coutp = p->chunks[0].coutp, mtp = mtile_pitch(p->chunks[0].mt);
+        // effective gamma [cout][cout] -> A-fragment order [k][col][m] = gamma[i = 32 m + col][k], zero padded; beta padded with 1
+        std::vector<float> gt(static_cast<size_t>(coutp) * 32 * mtp, 0.f), bt(coutp, 1.f);
         for (int i = 0; i < co_n; ++i) {
             bt[i] = beta[i];
-            for (int k = 0; k < co_n; ++k) gt[static_cast<size_t>(k) * coutp + i] = gamma[static_cast<size_t>(i) * cout + k];
+            for (int k = 0; k < co_n; ++k)
+                gt[(static_cast<size_t>(k) * 32 + i % 32) * mtp + i / 32] = gamma[static_cast<size_t>(i) * cout + k];
         }
+        gt.resize(gt.size() + 1024, 0.f);
         rc = upload(gt, &p->d_gammaT);
         if (!rc) rc = upload(bt, &p->d_beta);
         if (rc) { basic_conv_plan_destroy(p); return rc; }
@@ -654,25 +714,37 @@ extern "C" int64_t basic_conv_plan_flops(const basic_conv_plan *p, int batch, in
 
 namespace {
 
-template <int MT, int CK>
+template <int MT, int CK, int KH, int KW>
 int launch_one(const TapLaunch &g, int blocks, int nsplit, size_t lds_bytes, hipStream_t st)
 {
     static bool attr_set = false;
     if (!attr_set) {
-        BASIC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_tap_mfma_kernel<MT, CK>),
+        BASIC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_tap_mfma_kernel<MT, CK, KH, KW>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_tap_mfma_kernel<MT, CK>), dim3(blocks, nsplit), dim3(kThreads), lds_bytes, st, g);
+    hipLaunchKernelGGL((conv_tap_mfma_kernel<MT, CK, KH, KW>), dim3(blocks, nsplit), dim3(kThreads), lds_bytes, st, g);
     BASIC_HIP_TRY(hipGetLastError());
     return BASIC_OK;
 }
 
+// Unrolled instantiations for the tap grids of the codec's layers (5x5 and 3x3 convolutions, the four
+// sub-pixel phases of the 5x5 stride-2 transposed convolution); anything else takes the runtime tap table.
 template <int MT>
-int launch_mt(const TapLaunch &g, int ck, int blocks, int nsplit, size_t lds_bytes, hipStream_t st)
+int launch_mt(const TapLaunch &g, int ck, int kh, int kw, int blocks, int nsplit, size_t lds_bytes, hipStream_t st)
 {
-    if (ck == kCKVeryFew) return launch_one<MT, kCKVeryFew>(g, blocks, nsplit, lds_bytes, st);
-    return ck == kCKFew ? launch_one<MT, kCKFew>(g, blocks, nsplit, lds_bytes, st) : launch_one<MT, kCKConv>(g, blocks, nsplit, lds_bytes, st);
+    if (ck == kCKConv) {
+        if (kh == 5 && kw == 5) return launch_one<MT, kCKConv, 5, 5>(g, blocks, nsplit, lds_bytes, st);
+        return launch_one<MT, kCKConv, 0, 0>(g, blocks, nsplit, lds_bytes, st);
+    }
+    if (ck == kCKFew) {
+        if (kh == 3 && kw == 3) return launch_one<MT, kCKFew, 3, 3>(g, blocks, nsplit, lds_bytes, st);
+        return launch_one<MT, kCKFew, 0, 0>(g, blocks, nsplit, lds_bytes, st);
+    }
+    if (kh == 3 && kw == 2) return launch_one<MT, kCKVeryFew, 3, 2>(g, blocks, nsplit, lds_bytes, st);
+    if (kh == 2 && kw == 3) return launch_one<MT, kCKVeryFew, 2, 3>(g, blocks, nsplit, lds_bytes, st);
+    if (kh == 2 && kw == 2) return launch_one<MT, kCKVeryFew, 2, 2>(g, blocks, nsplit, lds_bytes, st);
+    return launch_one<MT, kCKVeryFew, 0, 0>(g, blocks, nsplit, lds_bytes, st);
 }
 
 int ilog2(int v) { int l = 0; while ((1 << (l + 1)) <= v) ++l; return l; }
@@ -731,20 +803,22 @@ extern "C" int basic_conv_forward_dev(const basic_conv_plan *p, const float *d_i
         g.tiles_y = (g.mh + th - 1) / th;
         g.tiles_x = (g.mw + tw - 1) / tw;
         const int blocks = ((batch + tb - 1) / tb) * g.tiles_y * g.tiles_x;
-        const int wl_floats = g.ntaps * kCK * g.coutp, gam_floats = 32 * g.coutp;
-        const size_t lds_bytes = sizeof(float) * (static_cast<size_t>(wl_floats > gam_floats ? wl_floats : gam_floats) +
-                                                 static_cast<size_t>(tb) * kCK * g.ph * g.pwp + kMaxTaps);
+        const int mtp = mtile_pitch(ch.mt);
+        const int wl_floats = g.ntaps * kCK * 32 * mtp, gam_floats = 32 * 32 * mtp;
+        const int wl_pad = ((wl_floats > gam_floats ? wl_floats : gam_floats) + 1023) & ~1023;
+        const int patch_pad = (tb * kCK * g.ph * g.pwp + 255) & ~255;
+        const size_t lds_bytes = sizeof(float) * (2 * static_cast<size_t>(wl_pad + patch_pad) + kMaxTaps);  // two stage buffers + tap table
         BASIC_REQUIRE(tb * kCK * g.ph * g.pwp <= patch_slots(ch.mt) * kThreads, "conv_forward: input patch exceeds the staging registers");
         BASIC_REQUIRE(static_cast<int64_t>(tb) * p->cin * in_h * in_w < (1ll << 29), "conv_forward: input tile too large");
         BASIC_REQUIRE(lds_bytes <= 160 * 1024, "conv_forward: LDS budget exceeded");
         hipStream_t st = as_stream(hip_stream);
         switch (ch.mt) {
-            case 1: rc = launch_mt<1>(g, kCK, blocks, ch.nsplit, lds_bytes, st); break;
-            case 2: rc = launch_mt<2>(g, kCK, blocks, ch.nsplit, lds_bytes, st); break;
-            case 3: rc = launch_mt<3>(g, kCK, blocks, ch.nsplit, lds_bytes, st); break;
-            case 4: rc = launch_mt<4>(g, kCK, blocks, ch.nsplit, lds_bytes, st); break;
-            case 5: rc = launch_mt<5>(g, kCK, blocks, ch.nsplit, lds_bytes, st); break;
-            case 6: rc = launch_mt<6>(g, kCK, blocks, ch.nsplit, lds_bytes, st); break;
+            case 1: rc = launch_mt<1>(g, kCK, ph.kh, ph.kw, blocks, ch.nsplit, lds_bytes, st); break;
+            case 2: rc = launch_mt<2>(g, kCK, ph.kh, ph.kw, blocks, ch.nsplit, lds_bytes, st); break;
+            case 3: rc = launch_mt<3>(g, kCK, ph.kh, ph.kw, blocks, ch.nsplit, lds_bytes, st); break;
+            case 4: rc = launch_mt<4>(g, kCK, ph.kh, ph.kw, blocks, ch.nsplit, lds_bytes, st); break;
+            case 5: rc = launch_mt<5>(g, kCK, ph.kh, ph.kw, blocks, ch.nsplit, lds_bytes, st); break;
+            case 6: rc = launch_mt<6>(g, kCK, ph.kh, ph.kw, blocks, ch.nsplit, lds_bytes, st); break;
             default: set_error("conv_forward: cout > 192 unsupported"); rc = BASIC_ERR_INVALID;
         }
         if (rc) return rc;
