@@ -36,11 +36,17 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kCKConv = 2;    // input channels per LDS stage for many-tap layers (5x5 conv: 25 taps)
-constexpr int kCKFew = 4;     // ... and for few-tap launches (3x3 conv, sub-pixel phases of the 5x5 deconv: <= 9 taps)
-constexpr int kFewTaps = 9;
-constexpr int kCKVeryFew = 8;   // ... and for <= 6 taps (3 of the 4 sub-pixel phases)
-constexpr int kVeryFewTaps = 6;
+// Input channels per LDS stage: as many as two stage buffers allow (2 x ~31 KB per 4-wave workgroup at two
+// workgroups per CU, 2 x ~72 KB for the 8-wave workgroup that has the CU to itself).
+constexpr int kFewTaps = 9;      // 3x3 conv, the 3x3 sub-pixel phase of the 5x5 stride-2 transposed conv
+constexpr int kVeryFewTaps = 6;  // its other three phases
+constexpr int stage_channels(int ntaps, int waves)
+{
+    return (ntaps > kFewTaps ? 2 : (ntaps > kVeryFewTaps ? 4 : 8)) * (waves == 8 ? 2 : 1);
+}
+// 8-wave workgroups pay off for the 25-tap, 128-channel convolutions (measured: +3..5 %); the few-tap phases of
+// the transposed convolutions run faster as two 4-wave workgroups per CU.
+constexpr int plan_waves(int mt, int ntaps) { return (mt == 4 && ntaps > kFewTaps) ? 8 : 4; }
 constexpr int kMaxTaps = 25;  // 5x5
 constexpr int kThreads = 256;
 constexpr int kTilePos = 128;  // output positions per workgroup
@@ -108,10 +114,14 @@ constexpr int mtile_pitch(int mt) { return mt <= 1 ? 1 : (mt <= 2 ? 2 : (mt <= 4
 
 // KH x KW > 0: the launch's taps form a dense KH x KW grid (tap t = row t / KW, column t % KW of the
 // patch) and the whole stage is unrolled with compile-time LDS offsets; KH = 0: runtime tap table.
-template <int MT, int kCK, int KH, int KW>
-__global__ __launch_bounds__(kThreads, (MT <= 4 ? 2 : 1)) void conv_tap_mfma_kernel(const TapLaunch g)
+// WAVES = 4: 128 positions per workgroup, two workgroups per CU (MT <= 4); WAVES = 8: 256 positions, one
+// workgroup per CU with twice the LDS per stage -- half as many barriers and weight DMAs per MFMA.
+template <int MT, int kCK, int KH, int KW, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, (MT <= 4 && WAVES == 4 ? 2 : 1)) void conv_tap_mfma_kernel(const TapLaunch g)
 {
     extern __shared__ float lds[];
+    constexpr int kThreads = 64 * WAVES;   // shadows the 4-wave default of the host code
+    constexpr int kWPiece = kThreads * 4;  // floats one 16-byte DMA instruction of the whole workgroup moves
     constexpr int kPSlots = patch_slots(MT);
     constexpr int MTP = mtile_pitch(MT);  // A fragments of a lane sit MTP floats apart: [tap][ci][col][MTP]
     // output-channel slice of this block (small-grid launches spread Cout over blockIdx.y)
@@ -122,10 +132,11 @@ __global__ __launch_bounds__(kThreads, (MT <= 4 ? 2 : 1)) void conv_tap_mfma_ker
     // LDS: two stage buffers { weight slab [tap][ci][col][MTP] | input patch [TB][CK][PH][PWP] }, filled by
     // LDS-DMA (global_load_lds: no VGPR round trip, no ds_write) one stage ahead of the MFMAs that read
     // them, then the tap-offset table of the runtime-tap variant.  The DMA image is lane-linear, which is
-    // why both regions are padded to whole wave-instructions (1024 / 256 floats per 256 threads).
+    // why both regions are padded to whole instructions of the workgroup (16 / 4 bytes per thread).
     const int wl_floats = g.ntaps * kCK * 32 * MTP;
     const int gam_floats = 32 * 32 * MTP;
-    const int wl_pad = ((wl_floats > gam_floats ? wl_floats : gam_floats) + 1023) & ~1023;
+    const int wl_pad = ((wl_floats > gam_floats ? wl_floats : gam_floats) + kWPiece - 1) / kWPiece * kWPiece;
+
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int khalf = lane >> 5, col = lane & 31;
@@ -156,9 +167,9 @@ __global__ __launch_bounds__(kThreads, (MT <= 4 ? 2 : 1)) void conv_tap_mfma_ker
         for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
 
     const int patch_elems = TB * kCK * chan_stride;
-    const int patch_pad = (patch_elems + 255) & ~255;
+    const int patch_pad = (patch_elems + kThreads - 1) / kThreads * kThreads;
     const int stage_floats = wl_pad + patch_pad;
-    const int n_wslots = wl_pad >> 10, n_pslots = patch_pad >> 8;
+    const int n_wslots = wl_pad / kWPiece, n_pslots = patch_pad / kThreads;
     const int nstages = g.cin_pad / kCK;
     const int gy0 = my0 * g.s_in + g.dymin, gx0 = mx0 * g.s_in + g.dxmin;
     const int64_t in_plane = static_cast<int64_t>(g.in_h) * g.in_w;
@@ -196,9 +207,9 @@ __global__ __launch_bounds__(kThreads, (MT <= 4 ? 2 : 1)) void conv_tap_mfma_ker
         pstride[sl] = stride;
     }
 
-    constexpr int kStageTaps = (kCK == kCKConv) ? kMaxTaps : (kCK == kCKFew ? kFewTaps : kVeryFewTaps);
+    constexpr int kStageTaps = (kCK == stage_channels(kMaxTaps, WAVES)) ? kMaxTaps : (kCK == stage_channels(kFewTaps, WAVES) ? kFewTaps : kVeryFewTaps);
     constexpr int kWSlotsMax = (((KH > 0 ? KH * KW : kStageTaps) * kCK * 32 * MTP > 32 * 32 * MTP
-                                     ? (KH > 0 ? KH * KW : kStageTaps) * kCK * 32 * MTP : 32 * 32 * MTP) + 1023) / 1024;
+                                     ? (KH > 0 ? KH * KW : kStageTaps) * kCK * 32 * MTP : 32 * 32 * MTP) + kWPiece - 1) / kWPiece;
 
 // DMA of stage S (weights + patch) into buffer BUF; advances the patch pointers to stage S+1.
 #define BASIC_ISSUE_STAGE(S, BUF)                                                                              \
@@ -207,8 +218,8 @@ __global__ __launch_bounds__(kThreads, (MT <= 4 ? 2 : 1)) void conv_tap_mfma_ker
         const float *srcw_ = wpack + static_cast<int64_t>(S) * wl_floats + tid * 4;                            \
         _Pragma("unroll") for (int sl = 0; sl < kWSlotsMax; ++sl)                                              \
             if (sl < n_wslots)                                                                                 \
-                __builtin_amdgcn_global_load_lds((glb_cvoid *)(srcw_ + sl * 1024),                             \
-                                                 (lds_void *)(dstw_ + sl * 1024 + wave * 256), 16, 0, 0);      \
+                __builtin_amdgcn_global_load_lds((glb_cvoid *)(srcw_ + sl * kWPiece),                          \
+                                                 (lds_void *)(dstw_ + sl * kWPiece + wave * 256), 16, 0, 0);   \
         if ((S) == nstages - 1 && lastmask) {                                                                  \
             _Pragma("unroll") for (int sl = 0; sl < kPSlots; ++sl)                                             \
                 if ((lastmask >> sl) & 1u) pp[sl] = basic_zero_page;                                           \
@@ -216,7 +227,7 @@ __global__ __launch_bounds__(kThreads, (MT <= 4 ? 2 : 1)) void conv_tap_mfma_ker
         float *dstp_ = dstw_ + wl_pad;                                                                         \
         _Pragma("unroll") for (int sl = 0; sl < kPSlots; ++sl)                                                 \
             if (sl < n_pslots) {                                                                               \
-                __builtin_amdgcn_global_load_lds((glb_cvoid *)pp[sl], (lds_void *)(dstp_ + sl * 256 + wave * 64), 4, 0, 0); \
+                __builtin_amdgcn_global_load_lds((glb_cvoid *)pp[sl], (lds_void *)(dstp_ + sl * kThreads + wave * 64), 4, 0, 0); \
                 pp[sl] = reinterpret_cast<const float *>(reinterpret_cast<const char *>(pp[sl]) + pstride[sl]); \
             }                                                                                                  \
     } while (0)
@@ -311,8 +322,8 @@ __global__ __launch_bounds__(kThreads, (MT <= 4 ? 2 : 1)) void conv_tap_mfma_ker
     do {                                                                                                       \
         float *dst_ = lds + ((nstages + (MK)) & 1) * stage_floats;                                             \
         const float *src_ = g.gammaT + static_cast<int64_t>(MK) * gam_floats + tid * 4;                        \
-        _Pragma("unroll") for (int sl = 0; sl < MTP; ++sl)                                                     \
-            __builtin_amdgcn_global_load_lds((glb_cvoid *)(src_ + sl * 1024), (lds_void *)(dst_ + sl * 1024 + wave * 256), 16, 0, 0); \
+        _Pragma("unroll") for (int sl = 0; sl < (32 * 32 * MTP + kWPiece - 1) / kWPiece; ++sl)                 \
+            __builtin_amdgcn_global_load_lds((glb_cvoid *)(src_ + sl * kWPiece), (lds_void *)(dst_ + sl * kWPiece + wave * 256), 16, 0, 0); \
     } while (0)
         BASIC_ISSUE_GAMMA(0);
 #pragma unroll
@@ -478,8 +489,9 @@ __global__ __launch_bounds__(256) void deconv5s2_cout3_kernel(const SmallLaunch 
 struct Phase {
     int ntaps = 0, dymin = 0, dxmin = 0, span_y = 1, span_x = 1;
     int oy0 = 0, ox0 = 0;
-    int ck = kCKConv, cin_pad = 0;  // channels per LDS stage of this launch, cin rounded up to it
+    int ck = 2, cin_pad = 0;        // channels per LDS stage of this launch, cin rounded up to it
     int kh = 0, kw = 0;             // the taps form a dense kh x kw grid, tap t at (t / kw, t % kw)
+    int waves = 4;                  // wavefronts per workgroup of this launch (32 positions each)
     signed char dy[kMaxTaps], dx[kMaxTaps];
     float *d_wpack = nullptr;
     int64_t split_wstride = 0;  // floats per output-channel slice of d_wpack
@@ -582,7 +594,8 @@ int build_chunks(basic_conv_plan *p, const float *weight, const float *bias, int
                     ph.dx[t] = static_cast<signed char>(t % ph.kw);
                 }
                 // ---- pack weights: [slice][cin_pad/CK][ntaps][CK][32][MTP]
-                const int kCK = ph.ntaps <= kVeryFewTaps ? kCKVeryFew : (ph.ntaps <= kFewTaps ? kCKFew : kCKConv);
+                ph.waves = plan_waves(ch.mt, ph.ntaps);
+                const int kCK = stage_channels(ph.ntaps, ph.waves);
                 const int mtp = mtile_pitch(ch.mt);
                 ph.ck = kCK;
                 ph.cin_pad = (ci_n + kCK - 1) / kCK * kCK;
@@ -601,7 +614,7 @@ int build_chunks(basic_conv_plan *p, const float *weight, const float *bias, int
                                (((static_cast<size_t>(c / kCK) * ph.ntaps + t) * kCK + (c % kCK)) * 32 + ol % 32) * mtp + ol / 32] = w;
                         }
                     }
-                wp.resize(wp.size() + 1024, 0.f);  // the DMA copies whole 4 KB pieces and may read past the last stage
+                wp.resize(wp.size() + 2048, 0.f);  // the DMA copies whole 4 / 8 KB pieces and may read past the last stage
                 const int rc = upload(wp, &ph.d_wpack);
                 ch.phases.push_back(ph);
                 if (rc) { out->push_back(ch); return rc; }
@@ -674,7 +687,7 @@ extern "C" int basic_conv_plan_create(const float *weight, const float *bias, in
             for (int k = 0; k < co_n; ++k)
                 gt[(static_cast<size_t>(k) * 32 + i % 32) * mtp + i / 32] = gamma[static_cast<size_t>(i) * cout + k];
         }
-        gt.resize(gt.size() + 1024, 0.f);
+        gt.resize(gt.size() + 2048, 0.f);
         rc = upload(gt, &p->d_gammaT);
         if (!rc) rc = upload(bt, &p->d_beta);
         if (rc) { basic_conv_plan_destroy(p); return rc; }
@@ -714,16 +727,16 @@ extern "C" int64_t basic_conv_plan_flops(const basic_conv_plan *p, int batch, in
 
 namespace {
 
-template <int MT, int CK, int KH, int KW>
+template <int MT, int CK, int KH, int KW, int WAVES>
 int launch_one(const TapLaunch &g, int blocks, int nsplit, size_t lds_bytes, hipStream_t st)
 {
     static bool attr_set = false;
     if (!attr_set) {
-        BASIC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_tap_mfma_kernel<MT, CK, KH, KW>),
+        BASIC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_tap_mfma_kernel<MT, CK, KH, KW, WAVES>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_tap_mfma_kernel<MT, CK, KH, KW>), dim3(blocks, nsplit), dim3(kThreads), lds_bytes, st, g);
+    hipLaunchKernelGGL((conv_tap_mfma_kernel<MT, CK, KH, KW, WAVES>), dim3(blocks, nsplit), dim3(64 * WAVES), lds_bytes, st, g);
     BASIC_HIP_TRY(hipGetLastError());
     return BASIC_OK;
 }
@@ -731,20 +744,22 @@ int launch_one(const TapLaunch &g, int blocks, int nsplit, size_t lds_bytes, hip
 // Unrolled instantiations for the tap grids of the codec's layers (5x5 and 3x3 convolutions, the four
 // sub-pixel phases of the 5x5 stride-2 transposed convolution); anything else takes the runtime tap table.
 template <int MT>
-int launch_mt(const TapLaunch &g, int ck, int kh, int kw, int blocks, int nsplit, size_t lds_bytes, hipStream_t st)
+int launch_mt(const TapLaunch &g, int kh, int kw, int blocks, int nsplit, size_t lds_bytes, hipStream_t st)
 {
-    if (ck == kCKConv) {
-        if (kh == 5 && kw == 5) return launch_one<MT, kCKConv, 5, 5>(g, blocks, nsplit, lds_bytes, st);
-        return launch_one<MT, kCKConv, 0, 0>(g, blocks, nsplit, lds_bytes, st);
+    constexpr int WM = plan_waves(MT, kMaxTaps), WF = plan_waves(MT, kFewTaps), WV = plan_waves(MT, kVeryFewTaps);
+    constexpr int kMany = stage_channels(kMaxTaps, WM), kFew = stage_channels(kFewTaps, WF), kVeryFew = stage_channels(kVeryFewTaps, WV);
+    if (g.ntaps > kFewTaps) {
+        if (kh == 5 && kw == 5) return launch_one<MT, kMany, 5, 5, WM>(g, blocks, nsplit, lds_bytes, st);
+        return launch_one<MT, kMany, 0, 0, WM>(g, blocks, nsplit, lds_bytes, st);
     }
-    if (ck == kCKFew) {
-        if (kh == 3 && kw == 3) return launch_one<MT, kCKFew, 3, 3>(g, blocks, nsplit, lds_bytes, st);
-        return launch_one<MT, kCKFew, 0, 0>(g, blocks, nsplit, lds_bytes, st);
+    if (g.ntaps > kVeryFewTaps) {
+        if (kh == 3 && kw == 3) return launch_one<MT, kFew, 3, 3, WF>(g, blocks, nsplit, lds_bytes, st);
+        return launch_one<MT, kFew, 0, 0, WF>(g, blocks, nsplit, lds_bytes, st);
     }
-    if (kh == 3 && kw == 2) return launch_one<MT, kCKVeryFew, 3, 2>(g, blocks, nsplit, lds_bytes, st);
-    if (kh == 2 && kw == 3) return launch_one<MT, kCKVeryFew, 2, 3>(g, blocks, nsplit, lds_bytes, st);
-    if (kh == 2 && kw == 2) return launch_one<MT, kCKVeryFew, 2, 2>(g, blocks, nsplit, lds_bytes, st);
-    return launch_one<MT, kCKVeryFew, 0, 0>(g, blocks, nsplit, lds_bytes, st);
+    if (kh == 3 && kw == 2) return launch_one<MT, kVeryFew, 3, 2, WV>(g, blocks, nsplit, lds_bytes, st);
+    if (kh == 2 && kw == 3) return launch_one<MT, kVeryFew, 2, 3, WV>(g, blocks, nsplit, lds_bytes, st);
+    if (kh == 2 && kw == 2) return launch_one<MT, kVeryFew, 2, 2, WV>(g, blocks, nsplit, lds_bytes, st);
+    return launch_one<MT, kVeryFew, 0, 0, WV>(g, blocks, nsplit, lds_bytes, st);
 }
 
 int ilog2(int v) { int l = 0; while ((1 << (l + 1)) <= v) ++l; return l; }
@@ -793,32 +808,37 @@ extern "C" int basic_conv_forward_dev(const basic_conv_plan *p, const float *d_i
         g.debug = dbg;
         // tile shape: 128 positions = TB images x TH x TW, powers of two, preferring wide rows
         int tw = pow2_ceil(g.mw); if (tw > 16) tw = 16;
-        int th = pow2_ceil(g.mh); if (th > kTilePos / tw) th = kTilePos / tw;
-        int tb = kTilePos / (tw * th);
+        const int threads = 64 * ph.waves, tile_pos = 32 * ph.waves;  // one position per half-wave lane
+        int th = pow2_ceil(g.mh); if (th > tile_pos / tw) th = tile_pos / tw;
+        int tb = tile_pos / (tw * th);
         g.ph = (th - 1) * g.s_in + ph.span_y;
         g.pw = (tw - 1) * g.s_in + ph.span_x;
         g.pwp = g.pw | 1;  // odd row pitch
-        while (tb > 1 && tb * kCK * g.ph * g.pwp > patch_slots(ch.mt) * kThreads) tb >>= 1;  // patch must fit the staging registers
+        const int mtp = mtile_pitch(ch.mt);
+        const int wl_floats = g.ntaps * kCK * 32 * mtp, gam_floats = 32 * 32 * mtp;
+        const int wl_pad = ((wl_floats > gam_floats ? wl_floats : gam_floats) + 4 * threads - 1) / (4 * threads) * (4 * threads);
+        auto lds_need = [&](int tbv) {  // two stage buffers + tap table
+            const int patch_pad = (tbv * kCK * g.ph * g.pwp + threads - 1) / threads * threads;
+            return sizeof(float) * (2 * static_cast<size_t>(wl_pad + patch_pad) + kMaxTaps);
+        };
+        // the patch must fit the gather descriptors and both stage buffers the LDS
+        while (tb > 1 && (tb * kCK * g.ph * g.pwp > patch_slots(ch.mt) * threads || lds_need(tb) > 160 * 1024)) tb >>= 1;
         g.tw_log = ilog2(tw); g.th_log = ilog2(th); g.tb_log = ilog2(tb);
         g.tiles_y = (g.mh + th - 1) / th;
         g.tiles_x = (g.mw + tw - 1) / tw;
         const int blocks = ((batch + tb - 1) / tb) * g.tiles_y * g.tiles_x;
-        const int mtp = mtile_pitch(ch.mt);
-        const int wl_floats = g.ntaps * kCK * 32 * mtp, gam_floats = 32 * 32 * mtp;
-        const int wl_pad = ((wl_floats > gam_floats ? wl_floats : gam_floats) + 1023) & ~1023;
-        const int patch_pad = (tb * kCK * g.ph * g.pwp + 255) & ~255;
-        const size_t lds_bytes = sizeof(float) * (2 * static_cast<size_t>(wl_pad + patch_pad) + kMaxTaps);  // two stage buffers + tap table
-        BASIC_REQUIRE(tb * kCK * g.ph * g.pwp <= patch_slots(ch.mt) * kThreads, "conv_forward: input patch exceeds the staging registers");
+        const size_t lds_bytes = lds_need(tb);
+        BASIC_REQUIRE(tb * kCK * g.ph * g.pwp <= patch_slots(ch.mt) * threads, "conv_forward: input patch exceeds the gather descriptors");
         BASIC_REQUIRE(static_cast<int64_t>(tb) * p->cin * in_h * in_w < (1ll << 29), "conv_forward: input tile too large");
         BASIC_REQUIRE(lds_bytes <= 160 * 1024, "conv_forward: LDS budget exceeded");
         hipStream_t st = as_stream(hip_stream);
         switch (ch.mt) {
-            case 1: rc = launch_mt<1>(g, kCK, ph.kh, ph.kw, blocks, ch.nsplit, lds_bytes, st); break;
-            case 2: rc = launch_mt<2>(g, kCK, ph.kh, ph.kw, blocks, ch.nsplit, lds_bytes, st); break;
-            case 3: rc = launch_mt<3>(g, kCK, ph.kh, ph.kw, blocks, ch.nsplit, lds_bytes, st); break;
-            case 4: rc = launch_mt<4>(g, kCK, ph.kh, ph.kw, blocks, ch.nsplit, lds_bytes, st); break;
-            case 5: rc = launch_mt<5>(g, kCK, ph.kh, ph.kw, blocks, ch.nsplit, lds_bytes, st); break;
-            case 6: rc = launch_mt<6>(g, kCK, ph.kh, ph.kw, blocks, ch.nsplit, lds_bytes, st); break;
+            case 1: rc = launch_mt<1>(g, ph.kh, ph.kw, blocks, ch.nsplit, lds_bytes, st); break;
+            case 2: rc = launch_mt<2>(g, ph.kh, ph.kw, blocks, ch.nsplit, lds_bytes, st); break;
+            case 3: rc = launch_mt<3>(g, ph.kh, ph.kw, blocks, ch.nsplit, lds_bytes, st); break;
+            case 4: rc = launch_mt<4>(g, ph.kh, ph.kw, blocks, ch.nsplit, lds_bytes, st); break;
+            case 5: rc = launch_mt<5>(g, ph.kh, ph.kw, blocks, ch.nsplit, lds_bytes, st); break;
+            case 6: rc = launch_mt<6>(g, ph.kh, ph.kw, blocks, ch.nsplit, lds_bytes, st); break;
             default: set_error("conv_forward: cout > 192 unsupported"); rc = BASIC_ERR_INVALID;
         }
         if (rc) return rc;
