@@ -398,6 +398,30 @@ struct SmallLaunch {
 };
 
 typedef float f32x16s __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(4))) f32x16s cf32x16s;
+
+// The 75 weights of input channel C as wave-uniform scalars (5 x s_load_dwordx16) times the pair table pr[3][5]
+// of a lane's strip: 150 packed FMAs into acc[pair][py][px][co].
+#define BASIC_SM_ACCUMULATE(C)                                                                                 \
+    do {                                                                                                       \
+        /* constant address space: keeps these wave-uniform loads on the scalar unit (s_load_dwordx16) even */ \
+        /* after the LDS-DMA intrinsic, which the compiler treats as a store that could alias them          */ \
+        const cf32x16s *w16 = (const cf32x16s *)(g.wsm + static_cast<int64_t>(C) * kSmWRow);                   \
+        const f32x16s w0 = w16[0], w1 = w16[1], w2 = w16[2], w3 = w16[3], w4 = w16[4];                         \
+        _Pragma("unroll") for (int ky = 0; ky < 5; ++ky)                                                       \
+        _Pragma("unroll") for (int kx = 0; kx < 5; ++kx) {                                                     \
+            /* output row 2*my + py receives input row my + dy through ky = py + 2 - 2*dy */                   \
+            const int py = ky & 1, px = kx & 1;                                                                \
+            const int dy = (py + 2 - ky) / 2, dx = (px + 2 - kx) / 2; /* in {-1, 0, 1} */                      \
+            _Pragma("unroll") for (int co = 0; co < 3; ++co) {                                                 \
+                const int wi = (ky * 5 + kx) * 3 + co;                                                         \
+                const float w = wi < 16 ? w0[wi & 15] : wi < 32 ? w1[wi & 15] : wi < 48 ? w2[wi & 15] : wi < 64 ? w3[wi & 15] : w4[wi & 15]; \
+                const f32x2 ww = {w, w};                                                                       \
+                _Pragma("unroll") for (int qp = 0; qp < 2; ++qp)                                               \
+                    acc[qp][py][px][co] = __builtin_elementwise_fma(pr[dy + 1][2 * qp + dx + 1], ww, acc[qp][py][px][co]); \
+            }                                                                                                  \
+        }                                                                                                      \
+    } while (0)
 
 __global__ __launch_bounds__(256) void deconv5s2_cout3_kernel(const SmallLaunch g)
 {
@@ -412,15 +436,15 @@ __global__ __launch_bounds__(256) void deconv5s2_cout3_kernel(const SmallLaunch 
     const int64_t plane = static_cast<int64_t>(g.in_h) * g.in_w;
     const float *inb = g.in + static_cast<int64_t>(b) * g.cin * plane;
 
-    float acc[4][2][2][3];  // [position in strip][py][px][co]
+    f32x2 acc[2][2][2][3];  // [pair of strip positions][py][px][co]
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int qp = 0; qp < 2; ++qp)
 #pragma unroll
         for (int py = 0; py < 2; ++py)
 #pragma unroll
             for (int px = 0; px < 2; ++px)
 #pragma unroll
-                for (int co = 0; co < 3; ++co) acc[q][py][px][co] = 0.f;
+                for (int co = 0; co < 3; ++co) acc[qp][py][px][co] = f32x2{0.f, 0.f};
 
     for (int c0 = 0; c0 < g.cin; c0 += kSmCK) {
         __syncthreads();
@@ -435,34 +459,22 @@ __global__ __launch_bounds__(256) void deconv5s2_cout3_kernel(const SmallLaunch 
         __syncthreads();
         const int cmax = (g.cin - c0 < kSmCK) ? g.cin - c0 : kSmCK;
         for (int ci = 0; ci < cmax; ++ci) {
-            // 3 x 6 neighbourhood of the strip: one aligned 16-byte + one 8-byte LDS read per row
-            float v[3][6];
+            // 3 x 6 neighbourhood of the strip as the five overlapping pairs (v0 v1) (v1 v2) ... (v4 v5) per row:
+            // every FMA below is then a packed one on two neighbouring strip positions, with the weight as a
+            // broadcast scalar operand and no register shuffling.
+            f32x2 pr[3][5];
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
                 const float *row = &patch[ci][ly + a][4 * lxq];
                 const f32x4 lo = *reinterpret_cast<const f32x4 *>(row);
-                const float2 hi = *reinterpret_cast<const float2 *>(row + 4);
-                v[a][0] = lo[0]; v[a][1] = lo[1]; v[a][2] = lo[2]; v[a][3] = lo[3]; v[a][4] = hi.x; v[a][5] = hi.y;
+                const f32x2 hi = *reinterpret_cast<const f32x2 *>(row + 4);
+                pr[a][0] = f32x2{lo[0], lo[1]};
+                pr[a][2] = f32x2{lo[2], lo[3]};
+                pr[a][4] = hi;
+                pr[a][1] = f32x2{row[1], row[2]};  // odd pairs: ds_read2_b32
+                pr[a][3] = f32x2{row[3], row[4]};
             }
-            // 75 weights of this input channel as wave-uniform scalars (5 x s_load_dwordx16)
-            const f32x16s *w16 = reinterpret_cast<const f32x16s *>(g.wsm + static_cast<int64_t>(c0 + ci) * kSmWRow);
-            const f32x16s w0 = w16[0], w1 = w16[1], w2 = w16[2], w3 = w16[3], w4 = w16[4];
-#define BASIC_SM_W(I) ((I) < 16 ? w0[(I) & 15] : (I) < 32 ? w1[(I) & 15] : (I) < 48 ? w2[(I) & 15] : (I) < 64 ? w3[(I) & 15] : w4[(I) & 15])
-#pragma unroll
-            for (int ky = 0; ky < 5; ++ky)
-#pragma unroll
-                for (int kx = 0; kx < 5; ++kx) {
-                    // output row 2*my + py receives input row my + dy through ky = py + 2 - 2*dy
-                    const int py = ky & 1, px = kx & 1;
-                    const int dy = (py + 2 - ky) / 2, dx = (px + 2 - kx) / 2;  // in {-1, 0, 1}
-#pragma unroll
-                    for (int co = 0; co < 3; ++co) {
-                        const float w = BASIC_SM_W((ky * 5 + kx) * 3 + co);
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) acc[q][py][px][co] = fmaf(v[dy + 1][q + dx + 1], w, acc[q][py][px][co]);
-                    }
-                }
-#undef BASIC_SM_W
+            BASIC_SM_ACCUMULATE(c0 + ci);
         }
     }
     if (my < g.in_h) {
@@ -478,8 +490,122 @@ __global__ __launch_bounds__(256) void deconv5s2_cout3_kernel(const SmallLaunch 
                 for (int q = 0; q < 4; ++q) {
                     if (mx0 + q >= g.in_w) break;
                     float2 r;
-                    r.x = apply_act(acc[q][py][0][co] + bv, g.act);
-                    r.y = apply_act(acc[q][py][1][co] + bv, g.act);
+                    r.x = apply_act(acc[q >> 1][py][0][co][q & 1] + bv, g.act);
+                    r.y = apply_act(acc[q >> 1][py][1][co][q & 1] + bv, g.act);
+                    *reinterpret_cast<float2 *>(o + py * ow + 2 * q) = r;
+                }
+        }
+    }
+}
+
+// The same layer with LDS-DMA staging (needs in_w % 4 == 0): an LDS row is the 16-byte aligned global span
+// [x0 - 4, x0 + 68) of an input row -- 18 chunks that are each entirely inside or entirely outside the image --
+// so a stage is a lane-linear image of 16-byte pieces, double buffered one stage ahead of the FMAs.
+constexpr int kSmDCK = 4;                                   // input channels per stage
+constexpr int kSmDRow = 18;                                 // 16-byte chunks per LDS row (pitch 72 floats)
+constexpr int kSmDChunks = kSmDCK * kSmPH * kSmDRow;        // chunks per stage
+constexpr int kSmDSlots = (kSmDChunks + 255) / 256;         // DMA instructions per thread and stage
+constexpr int kSmDStage = kSmDSlots * 256 * 4;              // floats per stage buffer (whole instructions)
+
+__global__ __launch_bounds__(256) void deconv5s2_cout3_dma_kernel(const SmallLaunch g)
+{
+    __shared__ __attribute__((aligned(16))) float buf[2 * kSmDStage];
+    const int tid = threadIdx.x, wave = tid >> 6;
+    int bid = blockIdx.x;
+    const int tx_i = bid % g.tiles_x; bid /= g.tiles_x;
+    const int ty_i = bid % g.tiles_y; bid /= g.tiles_y;
+    const int b = bid;
+    const int lxq = tid & 15, ly = tid >> 4;
+    const int my = ty_i * kSmTileH + ly, mx0 = tx_i * kSmTileW + 4 * lxq;
+    const int64_t plane = static_cast<int64_t>(g.in_h) * g.in_w;
+    const float *inb = g.in + static_cast<int64_t>(b) * g.cin * plane;
+    const int nstages = (g.cin + kSmDCK - 1) / kSmDCK;
+
+    // gather descriptors (see conv_tap_mfma_kernel): chunk k = tid + 256 s of every stage comes from pp[s]
+    const float *pp[kSmDSlots];
+    int pstride[kSmDSlots];
+    unsigned lastmask = 0;
+#pragma unroll
+    for (int sl = 0; sl < kSmDSlots; ++sl) {
+        const int k = tid + sl * 256;
+        const float *ptr = basic_zero_page;
+        int stride = 0;
+        if (k < kSmDChunks) {
+            const int j = k % kSmDRow, r = k / kSmDRow;
+            const int py = r % kSmPH, ci = r / kSmPH;
+            const int gy = ty_i * kSmTileH - 1 + py, gx = tx_i * kSmTileW - 4 + 4 * j;
+            if (gy >= 0 && gy < g.in_h && gx >= 0 && gx < g.in_w && ci < g.cin) {
+                ptr = inb + ci * plane + static_cast<int64_t>(gy) * g.in_w + gx;
+                stride = static_cast<int>(kSmDCK * plane * 4);
+                if ((nstages - 1) * kSmDCK + ci >= g.cin) lastmask |= 1u << sl;
+            }
+        }
+        pp[sl] = ptr;
+        pstride[sl] = stride;
+    }
+#define BASIC_SM_ISSUE(S)                                                                                      \
+    do {                                                                                                       \
+        if ((S) == nstages - 1 && lastmask) {                                                                  \
+            _Pragma("unroll") for (int sl = 0; sl < kSmDSlots; ++sl)                                           \
+                if ((lastmask >> sl) & 1u) pp[sl] = basic_zero_page;                                           \
+        }                                                                                                      \
+        float *dst_ = buf + ((S) & 1) * kSmDStage + wave * 256;                                                \
+        _Pragma("unroll") for (int sl = 0; sl < kSmDSlots; ++sl) {                                             \
+            __builtin_amdgcn_global_load_lds((glb_cvoid *)pp[sl], (lds_void *)(dst_ + sl * 1024), 16, 0, 0);   \
+            pp[sl] = reinterpret_cast<const float *>(reinterpret_cast<const char *>(pp[sl]) + pstride[sl]);    \
+        }                                                                                                      \
+    } while (0)
+
+    f32x2 acc[2][2][2][3];  // [pair of strip positions][py][px][co]
+#pragma unroll
+    for (int qp = 0; qp < 2; ++qp)
+#pragma unroll
+        for (int py = 0; py < 2; ++py)
+#pragma unroll
+            for (int px = 0; px < 2; ++px)
+#pragma unroll
+                for (int co = 0; co < 3; ++co) acc[qp][py][px][co] = f32x2{0.f, 0.f};
+
+    BASIC_SM_ISSUE(0);
+    for (int stg = 0; stg < nstages; ++stg) {
+        __syncthreads();  // this stage has landed; every wave is done with the buffer the next DMA overwrites
+        if (stg + 1 < nstages) BASIC_SM_ISSUE(stg + 1);
+        const float *st = buf + (stg & 1) * kSmDStage;
+        const int c0 = stg * kSmDCK;
+        const int cmax = (g.cin - c0 < kSmDCK) ? g.cin - c0 : kSmDCK;
+        for (int ci = 0; ci < cmax; ++ci) {
+            // the strip's 3 x 6 neighbourhood starts one float before chunk lxq + 1 of rows ly .. ly + 2
+            f32x2 pr[3][5];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const float *row = st + ((ci * kSmPH + ly + a) * kSmDRow + lxq) * 4 + 3;
+                const float v0 = row[0], v5 = row[5];
+                const f32x4 mid = *reinterpret_cast<const f32x4 *>(row + 1);
+                pr[a][0] = f32x2{v0, mid[0]};
+                pr[a][1] = f32x2{mid[0], mid[1]};
+                pr[a][2] = f32x2{mid[1], mid[2]};
+                pr[a][3] = f32x2{mid[2], mid[3]};
+                pr[a][4] = f32x2{mid[3], v5};
+            }
+            BASIC_SM_ACCUMULATE(c0 + ci);
+        }
+    }
+#undef BASIC_SM_ISSUE
+    if (my < g.in_h) {
+        const int oh = 2 * g.in_h, ow = 2 * g.in_w;
+#pragma unroll
+        for (int co = 0; co < 3; ++co) {
+            if (co >= g.cout) break;
+            const float bv = g.bias[co];
+            float *o = g.out + (static_cast<int64_t>(b) * g.cout + co) * oh * ow + static_cast<int64_t>(2 * my) * ow + 2 * mx0;
+#pragma unroll
+            for (int py = 0; py < 2; ++py)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (mx0 + q >= g.in_w) break;
+                    float2 r;
+                    r.x = apply_act(acc[q >> 1][py][0][co][q & 1] + bv, g.act);
+                    r.y = apply_act(acc[q >> 1][py][1][co][q & 1] + bv, g.act);
                     *reinterpret_cast<float2 *>(o + py * ow + 2 * q) = r;
                 }
         }
@@ -781,7 +907,10 @@ extern "C" int basic_conv_forward_dev(const basic_conv_plan *p, const float *d_i
         g.tiles_y = (in_h + kSmTileH - 1) / kSmTileH;
         g.tiles_x = (in_w + kSmTileW - 1) / kSmTileW;
         const int blocks = batch * g.tiles_y * g.tiles_x;
-        hipLaunchKernelGGL(deconv5s2_cout3_kernel, dim3(blocks), dim3(256), 0, as_stream(hip_stream), g);
+        if (in_w % 4 == 0 && (reinterpret_cast<uintptr_t>(d_in) & 15) == 0)
+            hipLaunchKernelGGL(deconv5s2_cout3_dma_kernel, dim3(blocks), dim3(256), 0, as_stream(hip_stream), g);
+        else
+            hipLaunchKernelGGL(deconv5s2_cout3_kernel, dim3(blocks), dim3(256), 0, as_stream(hip_stream), g);
         BASIC_HIP_TRY(hipGetLastError());
         return BASIC_OK;
     }
