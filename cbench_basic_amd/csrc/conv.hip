@@ -375,6 +375,202 @@ __global__ __launch_bounds__(64 * WAVES, (MT <= 4 && WAVES == 4 ? 2 : 1)) void c
 }
 
 // ---------------------------------------------------------------------------------------------
+// First analysis layer (5x5 taps, <= 4 input channels, 128 output channels, GDN): its whole reduction
+// is one stage, so the generic kernel spends most of a workgroup's life waiting for the DMA of the
+// weight slab and of gamma (64 KB per 456 MFMAs of a wave).  Here both stay RESIDENT in LDS and a
+// persistent 8-wave workgroup per CU walks the tiles: per tile one patch DMA (double buffered, issued a
+// tile ahead), 50 conv steps, 64 GDN steps straight from the resident gamma, one barrier.
+// Same packed weights / gamma / TapLaunch as conv_tap_mfma_kernel<4, 4, 5, 5, 8>.
+// ---------------------------------------------------------------------------------------------
+constexpr int kFirstSlots = 10;  // patch elements per thread (512 threads): <= 5120 floats, checked by the host
+
+__global__ __launch_bounds__(512, 1) void conv5x5_cin4_gdn_persistent_kernel(const TapLaunch g, int ntiles)
+{
+    extern __shared__ float lds[];
+    constexpr int MT = 4, kCK = 4, KW = 5, kSteps = 25 * 2;
+    constexpr int kWFloats = 25 * kCK * 32 * 4;  // 12800
+    constexpr int kGFloats = 128 * 32 * 4;       // 16384
+    float *wl = lds;
+    float *gl = lds + kWFloats;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int khalf = lane >> 5, col = lane & 31;
+    const int TB = 1 << g.tb_log, TH = 1 << g.th_log, TW = 1 << g.tw_log;
+    const int chan_stride = g.ph * g.pwp;
+    const int patch_elems = TB * kCK * chan_stride;
+    const int patch_pad = (patch_elems + 511) / 512 * 512;
+    const int n_pslots = patch_pad / 512;
+    float *pbuf = gl + kGFloats;  // two patch buffers of patch_pad floats
+
+    // resident operands: weight slab (6 whole 8 KB pieces + 2 KB) and gamma (8 pieces)
+    {
+        const float *srcw = g.wpack + tid * 4;
+#pragma unroll
+        for (int sl = 0; sl < 6; ++sl)
+            __builtin_amdgcn_global_load_lds((glb_cvoid *)(srcw + sl * 2048), (lds_void *)(wl + sl * 2048 + wave * 256), 16, 0, 0);
+        if (wave < 2)
+            __builtin_amdgcn_global_load_lds((glb_cvoid *)(srcw + 6 * 2048), (lds_void *)(wl + 6 * 2048 + wave * 256), 16, 0, 0);
+        const float *srcg = g.gammaT + tid * 4;
+#pragma unroll
+        for (int sl = 0; sl < 8; ++sl)
+            __builtin_amdgcn_global_load_lds((glb_cvoid *)(srcg + sl * 2048), (lds_void *)(gl + sl * 2048 + wave * 256), 16, 0, 0);
+    }
+
+    // this lane's output position inside a tile
+    const int q = wave * 32 + col;
+    const int tx = q & (TW - 1);
+    const int ty = (q >> g.tw_log) & (TH - 1);
+    const int tb_raw = q >> (g.tw_log + g.th_log);
+    const bool lane_live = tb_raw < TB;
+    const int tb = lane_live ? tb_raw : 0;
+    const int lane_b_base = ((tb * kCK + khalf) * g.ph + ty * g.s_in) * g.pwp + tx * g.s_in;
+    const int lane_a_base = (khalf * 32 + col) * 4;
+
+    // tile-independent part of the gather descriptors: patch element tid + 512 s sits at (pb, ci, py, px)
+    const int64_t in_plane = static_cast<int64_t>(g.in_h) * g.in_w;
+    const int64_t in_img = static_cast<int64_t>(g.cin) * in_plane;
+    int poff[kFirstSlots], pyx[kFirstSlots];  // offset from the tile's first element / (pb << 24 | py << 12 | px), -1 = padding
+#pragma unroll
+    for (int sl = 0; sl < kFirstSlots; ++sl) {
+        int r = tid + sl * 512;
+        int off = 0, code = -1;
+        if (r < patch_elems) {
+            const int px = r % g.pwp; r /= g.pwp;
+            const int py = r % g.ph; r /= g.ph;
+            const int ci = r % kCK;
+            const int pb = r / kCK;
+            if (px < g.pw && ci < g.cin) {
+                off = static_cast<int>(pb * in_img + ci * in_plane + py * g.in_w + px);
+                code = (pb << 24) | (py << 12) | px;
+            }
+        }
+        poff[sl] = off;
+        pyx[sl] = code;
+    }
+
+#define BASIC_FIRST_ISSUE_PATCH(TILE, BUF)                                                                     \
+    do {                                                                                                       \
+        int bid_ = (TILE);                                                                                     \
+        const int txi_ = bid_ % g.tiles_x; bid_ /= g.tiles_x;                                                  \
+        const int tyi_ = bid_ % g.tiles_y; bid_ /= g.tiles_y;                                                  \
+        const int b0_ = bid_ * TB;                                                                             \
+        const int gy0_ = tyi_ * TH * g.s_in + g.dymin, gx0_ = txi_ * TW * g.s_in + g.dxmin;                    \
+        const float *org_ = g.in + static_cast<int64_t>(b0_) * in_img + static_cast<int64_t>(gy0_) * g.in_w + gx0_; \
+        float *dst_ = pbuf + (BUF) * patch_pad + wave * 64;                                                    \
+        _Pragma("unroll") for (int sl = 0; sl < kFirstSlots; ++sl)                                             \
+            if (sl < n_pslots) {                                                                               \
+                const int c_ = pyx[sl];                                                                        \
+                const int gy_ = gy0_ + ((c_ >> 12) & 0xFFF), gx_ = gx0_ + (c_ & 0xFFF);                        \
+                const bool ok_ = c_ >= 0 && gy_ >= 0 && gy_ < g.in_h && gx_ >= 0 && gx_ < g.in_w && b0_ + (c_ >> 24) < g.batch; \
+                const float *src_ = ok_ ? org_ + poff[sl] : basic_zero_page;                                   \
+                __builtin_amdgcn_global_load_lds((glb_cvoid *)src_, (lds_void *)(dst_ + sl * 512), 4, 0, 0);   \
+            }                                                                                                  \
+    } while (0)
+
+    int tile = blockIdx.x;
+    if (tile < ntiles) BASIC_FIRST_ISSUE_PATCH(tile, 0);
+    for (int it = 0; tile < ntiles; tile += gridDim.x, ++it) {
+        __syncthreads();  // this tile's patch (and, the first time, weights and gamma) landed; all waves left the previous tile
+        if (tile + static_cast<int>(gridDim.x) < ntiles && !(g.debug & 1)) BASIC_FIRST_ISSUE_PATCH(tile + gridDim.x, (it + 1) & 1);
+        const float *patch = pbuf + (it & 1) * patch_pad;
+
+        f32x16 acc[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+        if (!(g.debug & 2)) {
+            float fa[2][4], fb[2];
+            const float *a_lane = wl + lane_a_base;
+            const float *b_lane = patch + lane_b_base;
+            fb[0] = b_lane[0];
+            load_a<4>(a_lane, fa[0]);
+#pragma unroll
+            for (int st = 0; st < kSteps; ++st) {
+                const int cur = st & 1, nxt = cur ^ 1;
+                const int sn = (st + 1 < kSteps) ? st + 1 : st;
+                const int tn = sn / 2, cpn = sn % 2;
+                fb[nxt] = b_lane[(tn / KW) * g.pwp + cpn * 2 * chan_stride + (tn % KW)];
+                load_a<4>(a_lane + (tn * kCK + cpn * 2) * 32 * 4, fa[nxt]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][m], fb[cur], acc[m], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (g.bias) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    const f32x4 b4 = *reinterpret_cast<const f32x4 *>(g.bias + 32 * m + 8 * rq + 4 * khalf);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[m][4 * rq + e] += b4[e];
+                }
+        }
+        if ((g.act == BASIC_ACT_GDN || g.act == BASIC_ACT_IGDN) && !(g.debug & 4)) {
+            f32x16 nrm[MT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) nrm[m][r] = 0.f;
+            float gk[2][4];
+            load_a<4>(gl + ((4 * khalf) * 32 + col) * 4, gk[0]);
+#pragma unroll
+            for (int st = 0; st < 64; ++st) {  // k = 32 mk + 8 (r >> 2) + (r & 3) [+4 for lanes 32..63], st = 16 mk + r
+                const int cur = st & 1, nxt = cur ^ 1;
+                const int sn = (st + 1 < 64) ? st + 1 : st;
+                const int kn = 32 * (sn >> 4) + 8 * ((sn & 15) >> 2) + (sn & 3);
+                load_a<4>(gl + ((kn + 4 * khalf) * 32 + col) * 4, gk[nxt]);
+                __builtin_amdgcn_sched_barrier(0);
+                const float x = acc[st >> 4][st & 15];
+                const float bfrag = x * x;
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+                    nrm[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(gk[cur][m], bfrag, nrm[m], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    const f32x4 b4 = *reinterpret_cast<const f32x4 *>(g.beta + 32 * m + 8 * rq + 4 * khalf);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = 4 * rq + e;
+                        const float nv = nrm[m][r] + b4[e];
+                        acc[m][r] *= (g.act == BASIC_ACT_GDN) ? __builtin_amdgcn_rsqf(nv) : __builtin_amdgcn_sqrtf(nv);
+                    }
+                }
+        }
+        // ---- store (HBM-bound: 2 GB of fp32 activations leave this layer at B = 256)
+        int bid = tile;
+        const int tx_i = bid % g.tiles_x; bid /= g.tiles_x;
+        const int ty_i = bid % g.tiles_y; bid /= g.tiles_y;
+        const int my = ty_i * TH + ty, mx = tx_i * TW + tx, b = bid * TB + tb;
+        if (lane_live && my < g.mh && mx < g.mw && b < g.batch && !(g.debug & 32)) {
+            const int oy = my * g.s_out + g.oy0, ox = mx * g.s_out + g.ox0;
+            const int64_t plane = static_cast<int64_t>(g.out_h) * g.out_w;
+            // channels of (m, rq, e) are 32 m + 8 rq + 4 khalf + e: one running pointer instead of 64 address products
+            float *oc = g.out + (static_cast<int64_t>(b) * g.out_ctotal + g.co_base + 4 * khalf) * plane + static_cast<int64_t>(oy) * g.out_w + ox;
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        *oc = apply_act(acc[m][4 * rq + e], g.act);
+                        oc += plane;
+                    }
+                    oc += 4 * plane;
+                }
+        }
+    }
+#undef BASIC_FIRST_ISSUE_PATCH
+}
+
+// ---------------------------------------------------------------------------------------------
 // Last synthesis layer (ConvTranspose2d 5x5, stride 2, pad 2, output_padding 1, Cout <= 4):
 // three output channels would waste 29/32 of every MFMA tile, and on gfx950 the fp32 matrix rate
 // equals the fp32 vector rate anyway, so this layer runs on the VALU.  One lane owns one INPUT
@@ -961,6 +1157,27 @@ extern "C" int basic_conv_forward_dev(const basic_conv_plan *p, const float *d_i
         BASIC_REQUIRE(static_cast<int64_t>(tb) * p->cin * in_h * in_w < (1ll << 29), "conv_forward: input tile too large");
         BASIC_REQUIRE(lds_bytes <= 160 * 1024, "conv_forward: LDS budget exceeded");
         hipStream_t st = as_stream(hip_stream);
+        if (ch.mt == 4 && ch.nsplit == 1 && ph.waves == 8 && ph.kh == 5 && ph.kw == 5 && ph.cin_pad == kCK && kCK == 4 &&
+            ch.cout == 128 && p->d_gammaT && !(dbg & 64)) {
+            // single-stage GDN layer (the first analysis layer): persistent workgroups with resident weights and gamma
+            const int patch_pad1 = (tb * kCK * g.ph * g.pwp + 511) / 512 * 512;
+            const size_t lds1 = sizeof(float) * (12800 + 16384 + 2 * static_cast<size_t>(patch_pad1));
+            if (lds1 <= 160 * 1024 && patch_pad1 <= kFirstSlots * 512) {
+                static bool attr1 = false;
+                if (!attr1) {
+                    BASIC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(conv5x5_cin4_gdn_persistent_kernel),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                    attr1 = true;
+                }
+                int dev = 0, cus = 256;
+                (void)hipGetDevice(&dev);
+                (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+                const int grid = blocks < cus ? blocks : cus;
+                hipLaunchKernelGGL(conv5x5_cin4_gdn_persistent_kernel, dim3(grid), dim3(512), lds1, st, g, blocks);
+                BASIC_HIP_TRY(hipGetLastError());
+                continue;
+            }
+        }
         switch (ch.mt) {
             case 1: rc = launch_mt<1>(g, ph.kh, ph.kw, blocks, ch.nsplit, lds_bytes, st); break;
             case 2: rc = launch_mt<2>(g, ph.kh, ph.kw, blocks, ch.nsplit, lds_bytes, st); break;
