@@ -183,7 +183,7 @@ def main():
                         parallelism=f"image-sharded x{world}, RCCL all-reduce of metric sums only"),
             roofline=dict(bound="mfma", achieved=achieved, peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
                           frac=achieved / PEAK_FP32_MFMA_TFLOPS, traffic=traffic,
-                          kernel="conv_tap_mfma_kernel<MT> (all transform launches of one encode+decode pass)",
+                          kernel="conv_tap_mfma_kernel<MT,CK,KH,KW,WAVES> + first/last-layer kernels (the 38 transform launches of one encode+decode pass)",
                           flops_per_launch=flops_pass / launches, launches_per_pass=launches,
                           avg_launch_ms=conv_s / launches * 1e3, pass_ms=conv_s * 1e3),
         )

@@ -19,4 +19,4 @@ if n_last:
     convs = [r for r in rows if "conv" in r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]]
     for r in convs[-n_last:]:
         dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
-        print(r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][-34:], r["Grid_Size_X"], "lds", r["LDS_Block_Size"], "vgpr", r["VGPR_Count"], r["Accum_VGPR_Count"], f"{dur:.0f} us")
+        print(r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][-44:], r["Grid_Size_X"], "lds", r["LDS_Block_Size"], "vgpr", r["VGPR_Count"], r["Accum_VGPR_Count"], f"{dur:.0f} us")
