@@ -134,6 +134,7 @@ int upload_tables(basic_rans_tables *t)
             for (int j = 0; j < size; ++j) t->image.push_back(static_cast<uint32_t>(row[j]));
         }
     }
+    t->image.push_back(0x7FFFFFFFu);  // lane 63 of the last row reads one entry past it
     if (t->image.size() * 4 > 144 * 1024 || t->image.size() >= (1u << 18)) t->fast_ok = false;
     if (t->fast_ok) {
         BASIC_HIP_TRY(hipMalloc(&t->d_image, t->image.size() * sizeof(uint32_t)));
@@ -876,37 +877,49 @@ __global__ __launch_bounds__(64) void rans_decode_fast_kernel(TablesDev T, const
         int32_t result = 0;
         const int cnt = (n - c0) < 64 ? (n - c0) : 64;
 
-        // (row word, first-level probe) of a symbol, fetched two symbols ahead of its use
-        auto fetch = [&](int jj, uint32_t &m, uint32_t &p) {
+        // Per symbol, fetched two symbols ahead of its use: the row word and, per lane l, the row entries l and
+        // l + 1 (one ds_read2_b32) with their difference.  For rows of <= 64 entries lane l is then "symbol l":
+        // it knows its start and frequency, so EVERY lane advances the state for its own symbol in parallel
+        // (two VALU multiply-adds) while the ballot finds which lane is right; the serial chain per symbol is
+        // mask -> compare -> ballot -> two lane broadcasts.
+        auto fetch = [&](int jj, uint32_t &m, uint32_t &pv, uint32_t &pu, uint32_t &fr) {
             m = bcast_u32(meta_l, jj);
-            p = img[(m & 0x3FFFFu) + lane];
+            const uint32_t *row = img + (m & 0x3FFFFu) + lane;
+            pv = row[0];
+            pu = row[1];
+            fr = pu - pv;
         };
-        auto decode_one = [&](int j, uint32_t meta, uint32_t p) {
+        auto decode_one = [&](int j, uint32_t meta, uint32_t pv, uint32_t pu, uint32_t fr) {
             const int32_t size = static_cast<int32_t>(meta >> 18);
             const uint32_t cf = xl & mask;
-            const int first = __builtin_ctzll(__ballot(p > cf));
-            // rows of <= 64 entries: the probe vector is the row (first >= 1 because entry 0 is 0 <= cf)
-            uint32_t c_t = bcast_u32(p, first);
-            uint32_t c_s = bcast_u32(p, first - 1);  // lane select is taken mod 64; unused when first == 0 (wide rows only)
-            int32_t s = first - 1;
+            // x = freq * (x >> prec) + (cf - start)   (rans64.h:128-142)
+            const uint32_t t_lo = (xl >> prec) | (xh << (32u - prec));
+            const uint32_t t_hi = xh >> prec;
+            const uint64_t cand = static_cast<uint64_t>(fr) * t_lo + static_cast<uint32_t>(cf - pv);  // v_mad_u64_u32
+            const uint32_t cand_lo = static_cast<uint32_t>(cand);
+            const uint32_t cand_hi = static_cast<uint32_t>(cand >> 32) + __umul24(fr, t_hi);          // fr <= 2^16, t_hi < 2^15
+            int32_t s = __builtin_ctzll(__ballot(pu > cf));  // entry s <= cf < entry s + 1
+            uint32_t nxl = bcast_u32(cand_lo, s);            // lane select is taken mod 64 (garbage only for wide rows)
+            uint32_t nxh = bcast_u32(cand_hi, s);
             if (__builtin_expect(size > 64, 0)) {
+                // wide row: pv holds the last entry of each of 64 blocks; second level on the scalar unit
+                const int first = __builtin_ctzll(__ballot(pv > cf));
                 const int32_t step = (size + 63) >> 6;
                 const int32_t lo = first * step;
                 const int32_t span = (lo + step <= size) ? step : (size - lo);
                 const uint32_t va = (lane < span) ? img[(meta & 0x3FFFFu) + 64 + lo + lane] : 0x7FFFFFFFu;
                 const int tl = __builtin_ctzll(__ballot(va > cf));
-                c_t = bcast_u32(va, tl);
+                const uint32_t c_t = bcast_u32(va, tl);
                 // entry lo-1 is the last entry of the previous block = that block's probe value
-                if (tl > 0) c_s = bcast_u32(va, tl - 1);
+                const uint32_t c_s = tl > 0 ? bcast_u32(va, tl - 1) : bcast_u32(pv, first - 1);
                 s = lo + tl - 1;
+                const uint32_t freq = c_t - c_s;
+                const uint64_t prod = static_cast<uint64_t>(freq) * t_lo + (cf - c_s);
+                nxl = static_cast<uint32_t>(prod);
+                nxh = static_cast<uint32_t>(prod >> 32) + freq * t_hi;
             }
-            // x = freq * (x >> prec) + (cf - c_s)   (rans64.h:128-142), on 32-bit halves
-            const uint32_t freq = c_t - c_s;
-            const uint32_t t_lo = (xl >> prec) | (xh << (32u - prec));
-            const uint32_t t_hi = xh >> prec;
-            const uint64_t prod = static_cast<uint64_t>(freq) * t_lo + (cf - c_s);
-            xl = static_cast<uint32_t>(prod);
-            xh = static_cast<uint32_t>(prod >> 32) + freq * t_hi;
+            xl = nxl;
+            xh = nxh;
             if (__builtin_expect((xh | (xl >> 31)) == 0u, 0)) { xh = xl; xl = next_word(); }
             int32_t value = s;
             if (__builtin_expect(value == size - bsub, 0)) {  // the bypass sentinel (never matches without bypass coding)
@@ -924,17 +937,17 @@ __global__ __launch_bounds__(64) void rans_decode_fast_kernel(TablesDev T, const
             result = (lane == j) ? value : result;
         };
 
-        uint32_t ma, pa, mb, pb;
-        fetch(0, ma, pa);
-        fetch(cnt > 1 ? 1 : 0, mb, pb);
+        uint32_t ma, va_, ua, fa, mb, vb_, ub, fb;
+        fetch(0, ma, va_, ua, fa);
+        fetch(cnt > 1 ? 1 : 0, mb, vb_, ub, fb);
         int j = 0;
         for (; j + 1 < cnt; j += 2) {
-            decode_one(j, ma, pa);
-            fetch(j + 2 < cnt ? j + 2 : cnt - 1, ma, pa);  // two symbols ahead
-            decode_one(j + 1, mb, pb);
-            fetch(j + 3 < cnt ? j + 3 : cnt - 1, mb, pb);
+            decode_one(j, ma, va_, ua, fa);
+            fetch(j + 2 < cnt ? j + 2 : cnt - 1, ma, va_, ua, fa);  // two symbols ahead
+            decode_one(j + 1, mb, vb_, ub, fb);
+            fetch(j + 3 < cnt ? j + 3 : cnt - 1, mb, vb_, ub, fb);
         }
-        if (j < cnt) decode_one(j, ma, pa);
+        if (j < cnt) decode_one(j, ma, va_, ua, fa);
         if (i < n) out[i] = result + off_l;
     }
     if (lane == 0) {
