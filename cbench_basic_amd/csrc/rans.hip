@@ -38,10 +38,11 @@ struct basic_rans_tables {
     std::vector<int32_t> base;
     uint16_t *d_cdf16 = nullptr;
     int32_t *d_base = nullptr;
-    // Search image of the fast decoder (uint32, copied to LDS by every workgroup): per row a 64-entry
-    // first-level probe vector -- rows of <= 64 entries: the row itself padded with INT_MAX; wider rows:
-    // the last entry of each of 64 blocks -- followed, for wide rows, by the full row.
-    // meta[r] = image offset (dwords) | size << 18   (size <= 4096, image <= 2^18 dwords)
+    // Search image of the fast decoder (uint32, copied to LDS by every workgroup), 16 bytes per lane.
+    // Rows of <= 64 entries: lane l = { entry l, start of symbol l-1, frequency of symbol l-1, 0 } (INT_MAX keys
+    // past the row; frequency 0 for the bypass sentinel, so that its candidate state always looks "rare").
+    // Wider rows: one lane { INT_MAX, 0, 0, 0 }, the last entry of each of 64 blocks, the full row.
+    // meta[r] = byte offset of the row in the image.
     std::vector<uint32_t> image, meta;
     uint32_t *d_image = nullptr, *d_meta = nullptr;
     bool fast_ok = false;
@@ -121,10 +122,23 @@ int upload_tables(basic_rans_tables *t)
         const int size = t->sizes[r];
         const int32_t *row = &t->cdfs[static_cast<size_t>(r) * t->stride];
         if (size > 4096) { t->fast_ok = false; break; }
-        t->meta[r] = static_cast<uint32_t>(t->image.size()) | (static_cast<uint32_t>(size) << 18);
+        t->meta[r] = static_cast<uint32_t>(t->image.size() * 4);  // byte offset
         if (size <= 64) {
-            for (int l = 0; l < 64; ++l) t->image.push_back(l < size ? static_cast<uint32_t>(row[l]) : 0x7FFFFFFFu);
+            // lane l: { entry l (search key), start and frequency of symbol l - 1, pad }
+            for (int l = 0; l < 64; ++l) {
+                uint32_t key = 0x7FFFFFFFu, st = 0, fq = 0;
+                if (l < size) key = static_cast<uint32_t>(row[l]);
+                if (l >= 1 && l < size) {
+                    st = static_cast<uint32_t>(row[l - 1]);
+                    fq = key - st;
+                    if (t->bypass && l - 1 == size - 2) fq = 0;  // the sentinel symbol always takes the rare path
+                }
+                t->image.push_back(key); t->image.push_back(st); t->image.push_back(fq); t->image.push_back(0);
+            }
         } else {
+            // lane 0 = { INT_MAX, 0, 0 }: every lookup selects it and lands on the rare path; then the 64
+            // block-end probes and the row (lanes 1..63 of the fast path read into them, harmlessly)
+            t->image.push_back(0x7FFFFFFFu); t->image.push_back(0); t->image.push_back(0); t->image.push_back(0);
             const int step = (size + 63) >> 6;
             for (int l = 0; l < 64; ++l) {
                 int e = (l + 1) * step - 1;
@@ -132,10 +146,11 @@ int upload_tables(basic_rans_tables *t)
                 t->image.push_back(static_cast<uint32_t>(row[e]));
             }
             for (int j = 0; j < size; ++j) t->image.push_back(static_cast<uint32_t>(row[j]));
+            while (t->image.size() & 3) t->image.push_back(0);  // rows start 16-byte aligned
         }
     }
-    t->image.push_back(0x7FFFFFFFu);  // lane 63 of the last row reads one entry past it
-    if (t->image.size() * 4 > 144 * 1024 || t->image.size() >= (1u << 18)) t->fast_ok = false;
+    for (int l = 0; l < 256; ++l) t->image.push_back(0x7FFFFFFFu);  // lanes 1..63 of a trailing wide row stay inside
+    if (t->image.size() * 4 > 156 * 1024) t->fast_ok = false;
     if (t->fast_ok) {
         BASIC_HIP_TRY(hipMalloc(&t->d_image, t->image.size() * sizeof(uint32_t)));
         BASIC_HIP_TRY(hipMalloc(&t->d_meta, t->meta.size() * sizeof(uint32_t)));
@@ -330,6 +345,7 @@ extern "C" void basic_rans_tables_destroy(basic_rans_tables *t)
 namespace {
 
 constexpr uint64_t kRansL = 1ull << 31;
+typedef uint32_t f32x4u __attribute__((ext_vector_type(4)));  // one 16-byte entry of the decoder image
 
 struct TablesDev {
     const int32_t *cdfs, *sizes, *offsets;
@@ -826,7 +842,7 @@ __global__ __launch_bounds__(64) void rans_decode_fast_kernel(TablesDev T, const
     const int limit = static_cast<int>(word_off[stream + 1] - word_off[stream]);
     int pos, wbase;          // next word / first cached word (uniform)
     uint32_t cache;          // lane k holds word wbase + k
-    uint32_t xl, xh;         // coder state, uniform
+    uint64_t x;              // coder state, uniform
     {
         const int64_t p0 = pos_io[stream];
         pos = p0 < 0 ? 2 : static_cast<int>(p0);
@@ -834,19 +850,16 @@ __global__ __launch_bounds__(64) void rans_decode_fast_kernel(TablesDev T, const
         cache = (wbase + lane < limit) ? words[wbase + lane] : 0u;
         if (p0 < 0) {
             // the head words may sit in an earlier cache line only when pos >= 64, which cannot happen for pos = 2
-            xl = bcast_u32(cache, 0);
-            xh = bcast_u32(cache, 1);
+            x = static_cast<uint64_t>(bcast_u32(cache, 0)) | (static_cast<uint64_t>(bcast_u32(cache, 1)) << 32);
         } else {
-            const uint64_t x0 = state[stream];
-            xl = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(x0));
-            xh = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(x0 >> 32));
+            x = uniform_u64(state[stream]);
         }
     }
     const uint32_t prec = static_cast<uint32_t>(T.precision);
     const uint32_t mask = (1u << prec) - 1u;
     const uint32_t bprec = static_cast<uint32_t>(T.bypass_precision);
     const uint32_t maxbv = (1u << bprec) - 1u;
-    const int32_t bsub = T.bypass ? 2 : static_cast<int32_t>(0x80000000u);  // size - bsub = sentinel symbol
+    const bool bypass = T.bypass != 0;
 
     auto next_word = [&]() -> uint32_t {
         if (pos - wbase >= 64) {
@@ -858,100 +871,103 @@ __global__ __launch_bounds__(64) void rans_decode_fast_kernel(TablesDev T, const
         return w;
     };
     auto get_bits = [&](uint32_t nbits) -> uint32_t {  // Rans64DecGetBits, rans64.cpp:49-65
-        const uint32_t v = xl & ((1u << nbits) - 1u);
-        xl = (xl >> nbits) | (xh << (32u - nbits));
-        xh >>= nbits;
-        if (xh == 0u && xl < 0x80000000u) { xh = xl; xl = next_word(); }
+        const uint32_t v = static_cast<uint32_t>(x) & ((1u << nbits) - 1u);
+        x >>= nbits;
+        if (x < kRansL) x = (x << 32) | next_word();
         return v;
     };
 
     for (int c0 = 0; c0 < n; c0 += 64) {
         const int i = c0 + lane;
-        uint32_t meta_l = 2u << 18;
-        int32_t off_l = 0;
+        uint32_t meta_l = 0;
+        int32_t off_l = 0, size_l = 2;
         if (i < n) {
             const int32_t row = clampi(idx[i], 0, T.rows - 1);
             meta_l = T.meta[row];
             off_l = T.offsets[row];
+            size_l = T.sizes[row];
         }
-        int32_t result = 0;
+        int32_t result = 1;  // holds symbol + 1 (the selecting lane); the -1 is folded into the final store
         const int cnt = (n - c0) < 64 ? (n - c0) : 64;
 
-        // Per symbol, fetched two symbols ahead of its use: the row word and, per lane l, the row entries l and
-        // l + 1 (one ds_read2_b32) with their difference.  For rows of <= 64 entries lane l is then "symbol l":
-        // it knows its start and frequency, so EVERY lane advances the state for its own symbol in parallel
-        // (two VALU multiply-adds) while the ballot finds which lane is right; the serial chain per symbol is
-        // mask -> compare -> ballot -> two lane broadcasts.
-        auto fetch = [&](int jj, uint32_t &m, uint32_t &pv, uint32_t &pu, uint32_t &fr) {
-            m = bcast_u32(meta_l, jj);
-            const uint32_t *row = img + (m & 0x3FFFFu) + lane;
-            pv = row[0];
-            pu = row[1];
-            fr = pu - pv;
+        // Per symbol, fetched two symbols ahead of its use: lane l's 16-byte image entry of the symbol's row
+        // (one ds_read_b128).  Lane l holds the start and frequency of symbol l - 1 and the search key entry l,
+        // so EVERY lane advances the state for its own symbol (three VALU ops) while one compare + ballot finds
+        // the first lane whose key exceeds the coded value -- the lane that is right.  A lone wave issues one
+        // instruction per ~8-11 cycles whatever it is (scripts/micro/lone_wave_latency.hip), so the common path
+        // is built for instruction count: the only test is "new state < 2^31", which covers renormalisation
+        // and, because their image frequency is 0, the bypass sentinel and wide rows as well.
+        auto fetch = [&](int jj, f32x4u &e) {
+            const uint32_t m = bcast_u32(meta_l, jj);
+            e = *reinterpret_cast<const f32x4u *>(reinterpret_cast<const char *>(img) + m + lane * 16);
         };
-        auto decode_one = [&](int j, uint32_t meta, uint32_t pv, uint32_t pu, uint32_t fr) {
-            const int32_t size = static_cast<int32_t>(meta >> 18);
-            const uint32_t cf = xl & mask;
-            // x = freq * (x >> prec) + (cf - start)   (rans64.h:128-142)
-            const uint32_t t_lo = (xl >> prec) | (xh << (32u - prec));
-            const uint32_t t_hi = xh >> prec;
-            const uint64_t cand = static_cast<uint64_t>(fr) * t_lo + static_cast<uint32_t>(cf - pv);  // v_mad_u64_u32
-            const uint32_t cand_lo = static_cast<uint32_t>(cand);
-            const uint32_t cand_hi = static_cast<uint32_t>(cand >> 32) + __umul24(fr, t_hi);          // fr <= 2^16, t_hi < 2^15
-            int32_t s = __builtin_ctzll(__ballot(pu > cf));  // entry s <= cf < entry s + 1
-            uint32_t nxl = bcast_u32(cand_lo, s);            // lane select is taken mod 64 (garbage only for wide rows)
-            uint32_t nxh = bcast_u32(cand_hi, s);
-            if (__builtin_expect(size > 64, 0)) {
-                // wide row: pv holds the last entry of each of 64 blocks; second level on the scalar unit
-                const int first = __builtin_ctzll(__ballot(pv > cf));
-                const int32_t step = (size + 63) >> 6;
-                const int32_t lo = first * step;
-                const int32_t span = (lo + step <= size) ? step : (size - lo);
-                const uint32_t va = (lane < span) ? img[(meta & 0x3FFFFu) + 64 + lo + lane] : 0x7FFFFFFFu;
-                const int tl = __builtin_ctzll(__ballot(va > cf));
-                const uint32_t c_t = bcast_u32(va, tl);
-                // entry lo-1 is the last entry of the previous block = that block's probe value
-                const uint32_t c_s = tl > 0 ? bcast_u32(va, tl - 1) : bcast_u32(pv, first - 1);
-                s = lo + tl - 1;
-                const uint32_t freq = c_t - c_s;
-                const uint64_t prod = static_cast<uint64_t>(freq) * t_lo + (cf - c_s);
-                nxl = static_cast<uint32_t>(prod);
-                nxh = static_cast<uint32_t>(prod >> 32) + freq * t_hi;
-            }
-            xl = nxl;
-            xh = nxh;
-            if (__builtin_expect((xh | (xl >> 31)) == 0u, 0)) { xh = xl; xl = next_word(); }
-            int32_t value = s;
-            if (__builtin_expect(value == size - bsub, 0)) {  // the bypass sentinel (never matches without bypass coding)
-                uint32_t v = get_bits(bprec);
-                uint32_t nb = v;
-                while (v == maxbv) { v = get_bits(bprec); nb += v; }
-                uint32_t raw = 0;
-                for (uint32_t k = 0; k < nb; ++k) {
-                    const uint32_t nib = get_bits(bprec);
-                    if (k * bprec < 32u) raw |= nib << (k * bprec);
+        auto decode_one = [&](int j, const f32x4u &e) {
+            const uint32_t cf = static_cast<uint32_t>(x) & mask;
+            const uint64_t t = x >> prec;
+            // x = freq * (x >> prec) + (cf - start)   (rans64.h:128-142), per lane for its own symbol
+            const uint64_t addend = static_cast<uint64_t>(cf - e[1]) |
+                                    (static_cast<uint64_t>(__umul24(e[2], static_cast<uint32_t>(t >> 32))) << 32);  // freq <= 2^16, t_hi < 2^15
+            uint64_t cand;  // = freq * t_lo + addend; spelled out so that the addend's halves are written in place
+            asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(cand) : "v"(e[2]), "s"(static_cast<uint32_t>(t)), "v"(addend) : "vcc");
+            int32_t first = __builtin_ctzll(__ballot(e[0] > cf));  // symbol + 1
+            x = bcast_u64(cand, first);
+            if (__builtin_expect(x < kRansL, 0)) {
+                const int32_t size = bcast_u32(static_cast<uint32_t>(size_l), j);
+                const uint32_t base = bcast_u32(meta_l, j) >> 2;
+                int32_t sym = first - 1;
+                if (size > 64) {
+                    // wide row: 64 block-end probes after the dummy lane, then the row; two-level search
+                    const uint32_t pr = img[base + 4 + lane];
+                    const int blk = __builtin_ctzll(__ballot(pr > cf));
+                    const int32_t step = (size + 63) >> 6;
+                    const int32_t lo = blk * step;
+                    const int32_t span = (lo + step <= size) ? step : (size - lo);
+                    const uint32_t va = (lane < span) ? img[base + 68 + lo + lane] : 0x7FFFFFFFu;
+                    const int tl = __builtin_ctzll(__ballot(va > cf));
+                    const uint32_t c_t = bcast_u32(va, tl);
+                    // entry lo-1 is the last entry of the previous block = that block's probe value
+                    const uint32_t c_s = tl > 0 ? bcast_u32(va, tl - 1) : bcast_u32(pr, blk - 1);
+                    sym = lo + tl - 1;
+                    x = static_cast<uint64_t>(c_t - c_s) * t + (cf - c_s);
+                } else if (bypass && sym == size - 2) {
+                    // the sentinel's image frequency is 0: redo its update with the true one
+                    const uint32_t c_t = bcast_u32(e[0], first), c_s = bcast_u32(e[1], first);
+                    x = static_cast<uint64_t>(c_t - c_s) * t + (cf - c_s);
                 }
-                value = static_cast<int32_t>(raw >> 1);
-                if (raw & 1u) value = -value - 1; else value += size - 2;
+                if (x < kRansL) x = (x << 32) | next_word();
+                if (bypass && sym == size - 2) {
+                    uint32_t v = get_bits(bprec);
+                    uint32_t nb = v;
+                    while (v == maxbv) { v = get_bits(bprec); nb += v; }
+                    uint32_t raw = 0;
+                    for (uint32_t k = 0; k < nb; ++k) {
+                        const uint32_t nib = get_bits(bprec);
+                        if (k * bprec < 32u) raw |= nib << (k * bprec);
+                    }
+                    sym = static_cast<int32_t>(raw >> 1);
+                    if (raw & 1u) sym = -sym - 1; else sym += size - 2;
+                }
+                first = sym + 1;
             }
-            result = (lane == j) ? value : result;
+            // result[lane j] = first (one scalar operand per VALU instruction on gfx9: the lane select goes through m0)
+            asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(result) : "s"(first), "s"(j) : "m0");
         };
 
-        uint32_t ma, va_, ua, fa, mb, vb_, ub, fb;
-        fetch(0, ma, va_, ua, fa);
-        fetch(cnt > 1 ? 1 : 0, mb, vb_, ub, fb);
+        f32x4u ea, eb;
+        fetch(0, ea);
+        fetch(cnt > 1 ? 1 : 0, eb);
         int j = 0;
         for (; j + 1 < cnt; j += 2) {
-            decode_one(j, ma, va_, ua, fa);
-            fetch(j + 2 < cnt ? j + 2 : cnt - 1, ma, va_, ua, fa);  // two symbols ahead
-            decode_one(j + 1, mb, vb_, ub, fb);
-            fetch(j + 3 < cnt ? j + 3 : cnt - 1, mb, vb_, ub, fb);
+            decode_one(j, ea);
+            fetch(j + 2 < cnt ? j + 2 : cnt - 1, ea);  // two symbols ahead
+            decode_one(j + 1, eb);
+            fetch(j + 3 < cnt ? j + 3 : cnt - 1, eb);
         }
-        if (j < cnt) decode_one(j, ma, va_, ua, fa);
-        if (i < n) out[i] = result + off_l;
+        if (j < cnt) decode_one(j, ea);
+        if (i < n) out[i] = result - 1 + off_l;
     }
     if (lane == 0) {
-        state[stream] = static_cast<uint64_t>(xl) | (static_cast<uint64_t>(xh) << 32);
+        state[stream] = x;
         pos_io[stream] = pos;
     }
 }
