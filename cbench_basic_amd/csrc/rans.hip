@@ -590,47 +590,59 @@ __global__ __launch_bounds__(64) void rans_encode_fast_kernel(TablesDev T, const
         int32_t row3 = 0, s3 = 0;
         if (i3 >= 0) { row3 = idx[i3]; s3 = sym[i3]; }
 
-        // The broadcasts of symbol j-1 are issued before the arithmetic of symbol j (two alternating
-        // scalar register sets): a lone wave issues in order, so a readlane consumed right away would
-        // stall the whole chain for its latency.
-#define BASIC_ENC_LOAD(SET, J)                                                                                  \
+        // Lane j owns symbol j of the chunk and already holds its frequency, start and exact-division
+        // constants, so C(s, x) is evaluated by ALL lanes for their own symbol against the current uniform
+        // state (11 VALU ops) and only the new state of lane j is broadcast back: no per-symbol operand
+        // broadcasts, no scalar 64x64 multiply.  A lone wave issues one instruction per ~8-11 cycles whatever
+        // it is (scripts/micro/lone_wave_latency.hip), so what counts is the instruction count per symbol.
+        // Renormalisation and bypass symbols (x_max forced to 0) hide behind one ballot-bit test.
+        const uint32_t fq = cur.a & 0xFFFFu, cm = cur.a >> 16, sh = cur.b & 63u, st = cur.b >> 8;
+        const uint32_t xm = (cur.b & 0x80u) ? 0u : (fq << xs);  // renormalise when (x >> 32) >= xm
+#define BASIC_ENC_STEP(J)                                                                                       \
         do {                                                                                                   \
-            const int j_ = (J) < 0 ? 0 : (J);                                                                  \
-            SET##a = bcast_u32(cur.a, j_); SET##b = bcast_u32(cur.b, j_);                                      \
-            SET##l = bcast_u32(cur.rl, j_); SET##h = bcast_u32(cur.rh, j_);                                    \
-        } while (0)
-#define BASIC_ENC_STEP(SET, J)                                                                                  \
-        do {                                                                                                   \
-            if (__builtin_expect((SET##b & 0x80u) != 0u, 0)) {                                                 \
-                /* decode order: sentinel, count nibbles, payload low-first  =>  written reversed */          \
-                const uint32_t r = bcast_u32(cur.raw, (J));                                                    \
-                int nb = 0;                                                                                    \
-                while (nb * bprec < 32u && (r >> (nb * bprec)) != 0u) ++nb;                                    \
-                for (int k = nb - 1; k >= 0; --k) put_raw(x, em, lane, (r >> (k * bprec)) & maxbv, bprec);     \
-                put_raw(x, em, lane, static_cast<uint32_t>(nb) % maxbv, bprec);                                \
-                for (uint32_t k = 0; k < static_cast<uint32_t>(nb) / maxbv; ++k) put_raw(x, em, lane, maxbv, bprec); \
+            if (__builtin_expect(static_cast<uint32_t>(x >> 32) >= bcast_u32(xm, (J)), 0)) {                   \
+                const uint32_t b_ = bcast_u32(cur.b, (J));                                                     \
+                if (b_ & 0x80u) {                                                                              \
+                    /* decode order: sentinel, count nibbles, payload low-first  =>  written reversed */      \
+                    const uint32_t r = bcast_u32(cur.raw, (J));                                                \
+                    int nb = 0;                                                                                \
+                    while (nb * bprec < 32u && (r >> (nb * bprec)) != 0u) ++nb;                                \
+                    for (int k = nb - 1; k >= 0; --k) put_raw(x, em, lane, (r >> (k * bprec)) & maxbv, bprec); \
+                    put_raw(x, em, lane, static_cast<uint32_t>(nb) % maxbv, bprec);                            \
+                    for (uint32_t k = 0; k < static_cast<uint32_t>(nb) / maxbv; ++k) put_raw(x, em, lane, maxbv, bprec); \
+                }                                                                                              \
+                if (static_cast<uint32_t>(x >> 32) >= (bcast_u32(fq, (J)) << xs)) {                            \
+                    em.push(static_cast<uint32_t>(x), lane);                                                   \
+                    x >>= 32;                                                                                  \
+                }                                                                                              \
             }                                                                                                  \
-            if (__builtin_expect(static_cast<uint32_t>(x >> 32) >= ((SET##a & 0xFFFFu) << xs), 0)) {           \
-                em.push(static_cast<uint32_t>(x), lane);                                                       \
-                x >>= 32;                                                                                      \
-            }                                                                                                  \
-            const uint64_t rcp_ = static_cast<uint64_t>(SET##l) | (static_cast<uint64_t>(SET##h) << 32);       \
-            const uint64_t q_ = __umul64hi(x, rcp_) >> (SET##b & 63u);                                         \
-            x = x + (SET##b >> 8) + q_ * (SET##a >> 16); /* (q << p) + (x - q*freq) + start */                 \
+            const uint32_t xl_ = static_cast<uint32_t>(x), xh_ = static_cast<uint32_t>(x >> 32);              \
+            /* q = mulhi64(x, rcp) >> shift  (== x / freq, Alverson; q = x - 1 for freq 1, see the encoder image): */ \
+            /* mid = xh*rl + hi32(xl*rl) + xl*rh as a 64-bit value + carry, high = xh*rh + (mid >> 32)              */ \
+            const uint64_t t_ = static_cast<uint64_t>(xh_) * cur.rl + __umulhi(xl_, cur.rl);                   \
+            uint64_t mid_, cy_;                                                                                \
+            asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(mid_), "=s"(cy_) : "s"(xl_), "v"(cur.rh), "v"(t_));  \
+            uint32_t ch_;                                                                                      \
+            asm("v_addc_co_u32 %0, vcc, 0, 0, %1" : "=v"(ch_) : "s"(cy_) : "vcc");                             \
+            const uint64_t hadd_ = (mid_ >> 32) | (static_cast<uint64_t>(ch_) << 32);                          \
+            uint64_t h_;                                                                                       \
+            asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(h_) : "s"(xh_), "v"(cur.rh), "v"(hadd_) : "vcc");   \
+            const uint64_t q_ = h_ >> sh;                                                                      \
+            /* x' = (q << p) + (x - q*freq) + start = x + start' + q * (2^p - freq) */                         \
+            const uint64_t base_ = x + st;                                                                     \
+            const uint64_t nadd_ = static_cast<uint32_t>(base_) |                                              \
+                (static_cast<uint64_t>(static_cast<uint32_t>(base_ >> 32) + __umul24(static_cast<uint32_t>(q_ >> 32), cm)) << 32); \
+            uint64_t nx_;                                                                                      \
+            asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(nx_) : "v"(static_cast<uint32_t>(q_)), "v"(cm), "v"(nadd_) : "vcc"); \
+            x = bcast_u64(nx_, (J));                                                                           \
         } while (0)
         const int j_lo = hi >= 64 ? 0 : static_cast<int>(64 - hi);
-        uint32_t e0a, e0b, e0l, e0h, e1a, e1b, e1l, e1h;
         int j = 63;
-        BASIC_ENC_LOAD(e0, j);
-        while (j - 1 >= j_lo) {
-            BASIC_ENC_LOAD(e1, j - 1);
-            BASIC_ENC_STEP(e0, j);
-            BASIC_ENC_LOAD(e0, j - 2);
-            BASIC_ENC_STEP(e1, j - 1);
-            j -= 2;
+        for (; j - 1 >= j_lo; j -= 2) {
+            BASIC_ENC_STEP(j);
+            BASIC_ENC_STEP(j - 1);
         }
-        if (j >= j_lo) BASIC_ENC_STEP(e0, j);
-#undef BASIC_ENC_LOAD
+        if (j >= j_lo) BASIC_ENC_STEP(j);
 #undef BASIC_ENC_STEP
         cur = nxt;
         i2 = i3; row2 = row3; s2 = s3;
