@@ -35,6 +35,8 @@ _SIGNATURES = {
     "basic_rans_tables_destroy": (None, [_P]),
     "basic_rans_encode_host": (_I, [_P, _P, _P, _L, _P, _P, _P, _P, _L, _P]),
     "basic_rans_encode_bound": (_L, [_L]),
+    "basic_frame_streams": (_I, [_P, _P, _I, ctypes.c_uint32, ctypes.c_uint32, _P, _L, _P]),
+    "basic_unframe_streams": (_I, [_P, _L, _P, _P, _P, _P, _I, _P]),
     "basic_rans_decode_host": (_I, [_P, _P, _L, _P, _L, _P, _P, _P, _P]),
     "basic_rans_stream_open": (_I, [_P, _P, _L, _P]),
     "basic_rans_stream_decode": (_I, [_P, _P, _L, _P]),

@@ -1068,6 +1068,57 @@ int launch_decode(const basic_rans_tables *t, const ArDev &ar, int nstreams, hip
 
 }  // namespace
 
+namespace {
+inline void put_be32(uint8_t *p, uint32_t v) { p[0] = v >> 24; p[1] = (v >> 16) & 0xFF; p[2] = (v >> 8) & 0xFF; p[3] = v & 0xFF; }
+inline uint32_t get_be32(const uint8_t *p) { return (uint32_t(p[0]) << 24) | (uint32_t(p[1]) << 16) | (uint32_t(p[2]) << 8) | p[3]; }
+}  // namespace
+
+extern "C" int basic_frame_streams(const uint32_t *words, const int64_t *word_off, int n, uint32_t h, uint32_t w,
+                                   uint8_t *out, int64_t out_capacity, int64_t *out_len)
+{
+    BASIC_REQUIRE(word_off && out_len && n >= 0 && (words || n == 0 || word_off[n] == word_off[0]), "frame_streams: bad argument");
+    const int64_t total = 12 + 4ll * n + 4 * (word_off[n] - word_off[0]);
+    *out_len = total;
+    if (!out || out_capacity < total) { set_error("frame_streams: output buffer too small"); return BASIC_ERR_OVERFLOW; }
+    put_be32(out, h); put_be32(out + 4, w); put_be32(out + 8, static_cast<uint32_t>(n));
+    uint8_t *p = out + 12;
+    for (int i = 0; i < n; ++i) {
+        const int64_t bytes = 4 * (word_off[i + 1] - word_off[i]);
+        BASIC_REQUIRE(bytes >= 0 && bytes <= 0xFFFFFFFFll, "frame_streams: offsets must ascend");
+        put_be32(p, static_cast<uint32_t>(bytes));
+        std::memcpy(p + 4, words + word_off[i], static_cast<size_t>(bytes));
+        p += 4 + bytes;
+    }
+    return BASIC_OK;
+}
+
+extern "C" int basic_unframe_streams(const uint8_t *data, int64_t len, uint32_t *h, uint32_t *w, int *n,
+                                     int64_t *word_off, int n_capacity, uint32_t *words_out)
+{
+    BASIC_REQUIRE(data && len >= 12 && n, "unframe_streams: truncated header");
+    if (h) *h = get_be32(data);
+    if (w) *w = get_be32(data + 4);
+    const uint32_t cnt = get_be32(data + 8);
+    BASIC_REQUIRE(cnt <= 0x7FFFFFFFu && 12 + 4ll * cnt <= len, "unframe_streams: truncated body");
+    *n = static_cast<int>(cnt);
+    if (!words_out) return BASIC_OK;
+    BASIC_REQUIRE(word_off && n_capacity >= static_cast<int>(cnt), "unframe_streams: offset array too small");
+    int64_t cur = 12, wpos = 0;
+    word_off[0] = 0;
+    for (uint32_t i = 0; i < cnt; ++i) {
+        BASIC_REQUIRE(cur + 4 <= len, "unframe_streams: truncated body");
+        const int64_t bytes = get_be32(data + cur);
+        cur += 4;
+        BASIC_REQUIRE(cur + bytes <= len, "unframe_streams: truncated body");
+        BASIC_REQUIRE(bytes >= 8 && bytes % 4 == 0, "rANS stream must hold >= 2 whole 32-bit words");
+        std::memcpy(words_out + wpos, data + cur, static_cast<size_t>(bytes));
+        cur += bytes;
+        wpos += bytes / 4;
+        word_off[i + 1] = wpos;
+    }
+    return BASIC_OK;
+}
+
 extern "C" int64_t basic_rans_encode_bound(int64_t n)
 {
     // worst case per symbol: one 16-bit symbol + <= 13 raw groups of bypass_precision bits, well under

@@ -222,7 +222,11 @@ class LatentGraphicalANSEntropyCoder(HotPathModule, VariableRateCodecInterface, 
                     else:
                         raw = node_data
                         node_data = coder(raw, **pk)            # forward: quantised latent (:836)
-                        data[node] = coder.encode(raw, **pk) if do_encode else node_data  # (:838)
+                        if do_encode:  # (:838); coders that can, only enqueue their GPU work here (resolved in encode())
+                            data[node] = coder.encode(raw, lazy=True, **pk) if getattr(coder, "supports_lazy_encode", False) \
+                                else coder.encode(raw, **pk)
+                        else:
+                            data[node] = node_data
                     kw_all[node] = node_data
             for edge in self._generative_edges_from[node]:
                 ek = {ik: kw_all[k] for k, ik in self.latent_generative_input_mapping.get(edge, {}).items()}
@@ -253,7 +257,8 @@ class LatentGraphicalANSEntropyCoder(HotPathModule, VariableRateCodecInterface, 
             with self.profiler.start_time_profile("encode_generative"):
                 data_dict, _ = self._generative_process(latent_dict, prior_dict=prior_dict, do_encode=True)
             nodes = self._coded_nodes()
-            return merge_bytes([data_dict[n] for n in nodes], num_segments=len(nodes))
+            bodies = [data_dict[n].result() if hasattr(data_dict[n], "result") else data_dict[n] for n in nodes]
+            return merge_bytes(bodies, num_segments=len(nodes))
 
     def decode(self, data, *args, prior=None, **kwargs):
         with torch.no_grad():

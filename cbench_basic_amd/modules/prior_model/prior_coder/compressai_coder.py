@@ -43,6 +43,18 @@ def write_body(shape, out_strings: List[List[bytes]], segments=1) -> bytes:
     return b"".join(parts)
 
 
+class PendingBody:
+    """A coder's byte string whose GPU work is enqueued but not yet synchronised (``encode(..., lazy=True)``):
+    the caller keeps launching kernels and calls ``result()`` when it needs the bytes."""
+
+    def __init__(self, tables, handle, shape_hw):
+        self._tables, self._handle, self._shape = tables, handle, tuple(int(v) for v in shape_hw)
+
+    def result(self) -> bytes:
+        host, off = self._tables.encode_batch_end(self._handle)
+        return K.frame_streams(host, off, self._shape)
+
+
 def read_body(data: bytes, segments=1):
     """compressai_coder.py:63-72."""
     h, w, n = struct.unpack(">3I", data[:12])
@@ -177,21 +189,23 @@ class CompressAIEntropyBottleneckPriorCoder(HotPathModule):
             zhat = zhat * channel_gains_inv.reshape(1, -1, 1, 1)
         return zhat
 
-    def encode(self, input, *args, channel_gains=None, channel_gains_inv=None, **kwargs) -> bytes:  # :230-236
+    supports_lazy_encode = True
+
+    def encode(self, input, *args, channel_gains=None, channel_gains_inv=None, lazy=False, **kwargs) -> bytes:  # :230-236
         self._ready()
         if channel_gains is not None:
             input = input * channel_gains.reshape(1, -1, 1, 1)
         sym, idx, _ = K.eb_quantize_index(input, self._medians_dev)
         n = sym[0].numel()
-        strings = self._tables.encode_batch_to_bytes(sym.reshape(-1), idx.reshape(-1), n)
-        return write_body(input.shape[-2:], [[s] for s in strings])
+        body = PendingBody(self._tables, self._tables.encode_batch_begin(sym.reshape(-1), idx.reshape(-1), n), input.shape[-2:])
+        return body if lazy else body.result()
 
     def decode(self, byte_string, *args, channel_gains=None, channel_gains_inv=None, **kwargs):  # :238-245
         self._ready()
-        strings, shape = read_body(byte_string)
-        B, C = len(strings), self.entropy_bottleneck.channels
+        words, woff, shape = K.unframe_streams(byte_string)
+        B, C = len(woff) - 1, self.entropy_bottleneck.channels
         idx = torch.arange(C, device=self.device, dtype=torch.int32).reshape(1, C, 1, 1).expand(B, C, *shape).contiguous()
-        sym = self._tables.decode_batch_from_bytes([s[0] for s in strings], idx.reshape(-1), C * shape[0] * shape[1])
+        sym = self._tables.decode_batch_from_words(words, woff, idx.reshape(-1), C * shape[0] * shape[1])
         zhat = K.eb_dequantize(sym.reshape(B, C, *shape), self._medians_dev)
         if channel_gains_inv is not None:
             zhat = zhat * channel_gains_inv.reshape(1, -1, 1, 1)
@@ -287,21 +301,23 @@ class CompressAIGaussianConditionalCoder(HotPathModule):
             yhat = yhat * channel_gains_inv.reshape(1, -1, 1, 1)
         return yhat
 
-    def encode(self, y, *args, prior=None, channel_gains=None, channel_gains_inv=None, **kwargs):  # :377-385
+    supports_lazy_encode = True
+
+    def encode(self, y, *args, prior=None, channel_gains=None, channel_gains_inv=None, lazy=False, **kwargs):  # :377-385
         self._ready()
         if channel_gains is not None:
             y = y * channel_gains.reshape(1, -1, 1, 1)
         sym, idx, _ = K.gc_quantize_index(y, self._crop(prior, *y.shape[-2:]), self._scale_table_dev, self.scale_bound,
                                           want_yhat=False)
-        strings = self._tables.encode_batch_to_bytes(sym.reshape(-1), idx.reshape(-1), sym[0].numel())
-        return write_body(y.shape[-2:], [[s] for s in strings])
+        body = PendingBody(self._tables, self._tables.encode_batch_begin(sym.reshape(-1), idx.reshape(-1), sym[0].numel()), y.shape[-2:])
+        return body if lazy else body.result()
 
     def decode(self, byte_string, *args, prior=None, channel_gains=None, channel_gains_inv=None, **kwargs):  # :387-393
         self._ready()
-        strings, shape = read_body(byte_string)
+        words, woff, shape = K.unframe_streams(byte_string)
         scales = self._crop(prior, *shape)
         _, idx, _ = K.gc_quantize_index(scales, scales, self._scale_table_dev, self.scale_bound, want_yhat=False)
-        sym = self._tables.decode_batch_from_bytes([s[0] for s in strings], idx.reshape(-1), idx[0].numel())
+        sym = self._tables.decode_batch_from_words(words, woff, idx.reshape(-1), idx[0].numel())
         yhat = K.i32_to_f32(sym.reshape(idx.shape))
         if channel_gains_inv is not None:
             yhat = yhat * channel_gains_inv.reshape(1, -1, 1, 1)

@@ -162,41 +162,56 @@ class RansTables:
                                                           words.data_ptr(), slot_words, nwords.data_ptr(), _stream()))
         return words, nwords
 
-    def encode_batch_to_bytes(self, symbols, indexes, n_per_stream):
-        """Equal-length streams (one per image): returns a list of ``bytes`` (reference py::bytes)."""
+    # ---- batched streams <-> host bytes.  begin() only enqueues GPU work (encode, device-side offsets, compaction);
+    # end() is the single host synchronisation, so a caller can launch more kernels in between.
+    def encode_batch_begin(self, symbols, indexes, n_per_stream, slot=None):
         symbols, indexes = _dev(symbols, torch.int32), _dev(indexes, torch.int32)
         ns = symbols.numel() // n_per_stream
         seg = torch.arange(ns + 1, device=symbols.device, dtype=torch.int64) * n_per_stream
-        slot = n_per_stream + 2  # the reference's own buffer size (rans64.cpp:240)
+        slot = slot or n_per_stream + 2  # the reference's own buffer size (rans64.cpp:240)
         words, nwords = self.encode_batch(symbols, indexes, seg, slot)
-        nw = nwords.cpu().numpy()
-        if (nw < 0).any():  # bypass-heavy data: retry with the guaranteed bound
-            slot = 3 * n_per_stream + 4
-            words, nwords = self.encode_batch(symbols, indexes, seg, slot)
-            nw = nwords.cpu().numpy()
-        off = np.concatenate([[0], np.cumsum(nw)]).astype(np.int64)
-        d_off = torch.from_numpy(off).to(symbols.device)
-        packed = torch.empty((int(off[-1]),), device=symbols.device, dtype=torch.int32)
+        d_off = torch.zeros((ns + 1,), device=symbols.device, dtype=torch.int64)
+        torch.cumsum(nwords.clamp(min=0), 0, out=d_off[1:])
+        packed = torch.empty((ns * slot,), device=symbols.device, dtype=torch.int32)
         _lib.check(_lib.lib().basic_rans_compact_streams_dev(words.data_ptr(), slot, nwords.data_ptr(), d_off.data_ptr(), ns,
                                                              packed.data_ptr(), _stream()))
-        host = packed.cpu().numpy()
-        return [host[off[i]:off[i + 1]].tobytes() for i in range(ns)]
+        return dict(symbols=symbols, indexes=indexes, n=n_per_stream, ns=ns, slot=slot, nwords=nwords, packed=packed, keep=words)
+
+    def encode_batch_end(self, h):
+        """-> (uint32 words of all streams back to back (numpy), int64 word offsets [ns + 1])."""
+        nw = h["nwords"].cpu().numpy()
+        if (nw < 0).any():  # bypass-heavy data overflowed the reference's bound: redo with the guaranteed one
+            h = self.encode_batch_begin(h["symbols"], h["indexes"], h["n"], slot=3 * h["n"] + 4)
+            nw = h["nwords"].cpu().numpy()
+        off = np.zeros(h["ns"] + 1, dtype=np.int64)
+        np.cumsum(nw, out=off[1:])
+        host = h["packed"][: int(off[-1])].cpu().numpy().view(np.uint32)
+        return host, off
+
+    def encode_batch_to_bytes(self, symbols, indexes, n_per_stream):
+        """Equal-length streams (one per image): returns a list of ``bytes`` (reference py::bytes)."""
+        host, off = self.encode_batch_end(self.encode_batch_begin(symbols, indexes, n_per_stream))
+        return [host[off[i]:off[i + 1]].tobytes() for i in range(len(off) - 1)]
+
+    def decode_batch_from_words(self, host_words, word_off, indexes, n_per_stream):
+        """Streams given as one uint32 array + word offsets (see unframe_streams): int32 symbols like ``indexes``."""
+        indexes = _dev(indexes, torch.int32)
+        ns = len(word_off) - 1
+        d_words = torch.from_numpy(host_words.view(np.int32)).to(indexes.device)
+        d_woff = torch.from_numpy(np.ascontiguousarray(word_off, dtype=np.int64)).to(indexes.device)
+        seg = torch.arange(ns + 1, device=indexes.device, dtype=torch.int64) * n_per_stream
+        out, _, _ = self.decode_batch(d_words, d_woff, indexes, seg)
+        return out
 
     def decode_batch_from_bytes(self, strings, indexes, n_per_stream):
         """Inverse of encode_batch_to_bytes: int32 symbols shaped like ``indexes`` (device)."""
-        indexes = _dev(indexes, torch.int32)
-        ns = len(strings)
         for s in strings:
             if len(s) < 8 or len(s) % 4:
                 raise ValueError("rANS stream must hold >= 2 whole 32-bit words")
         lens = np.array([len(s) // 4 for s in strings], dtype=np.int64)
         woff = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
-        host = np.frombuffer(b"".join(strings), dtype=np.int32)
-        d_words = torch.from_numpy(host.copy()).to(indexes.device)
-        d_woff = torch.from_numpy(woff).to(indexes.device)
-        seg = torch.arange(ns + 1, device=indexes.device, dtype=torch.int64) * n_per_stream
-        out, _, _ = self.decode_batch(d_words, d_woff, indexes, seg)
-        return out
+        host = np.frombuffer(b"".join(strings), dtype=np.uint32).copy()
+        return self.decode_batch_from_words(host, woff, indexes, n_per_stream)
 
     def decode_batch(self, words, word_off, indexes, seg, out=None, state=None, pos=None):
         words, word_off = _dev(words, torch.int32), _dev(word_off, torch.int64)
@@ -276,3 +291,29 @@ def eb_nll_per_image(zq, coef, likelihood_bound=1e-9):
     out = torch.empty((B,), device=zq.device, dtype=torch.float32)
     _lib.check(_lib.lib().basic_eb_nll_per_image_dev(zq.data_ptr(), coef.data_ptr(), B, C, hw, float(likelihood_bound), out.data_ptr(), _stream()))
     return out
+
+
+def frame_streams(host_words, word_off, shape_hw) -> bytes:
+    """write_body (compressai_coder.py:75-84) for one stream per image, done by the C helper."""
+    host_words = np.ascontiguousarray(host_words, dtype=np.uint32)
+    word_off = np.ascontiguousarray(word_off, dtype=np.int64)
+    n = len(word_off) - 1
+    cap = 12 + 4 * n + 4 * int(word_off[-1] - word_off[0])
+    out = np.empty(cap, dtype=np.uint8)
+    out_len = ctypes.c_int64()
+    _lib.check(_lib.lib().basic_frame_streams(host_words.ctypes.data, word_off.ctypes.data, n, int(shape_hw[0]), int(shape_hw[1]),
+                                              out.ctypes.data, cap, ctypes.byref(out_len)))
+    return out[: out_len.value].tobytes()
+
+
+def unframe_streams(data: bytes):
+    """read_body (compressai_coder.py:63-72) for one stream per image: (uint32 words, word offsets, (h, w))."""
+    buf = np.frombuffer(data, dtype=np.uint8)
+    h, w, n = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_int()
+    _lib.check(_lib.lib().basic_unframe_streams(buf.ctypes.data, len(data), ctypes.byref(h), ctypes.byref(w), ctypes.byref(n),
+                                                None, 0, None))
+    word_off = np.empty(n.value + 1, dtype=np.int64)
+    words = np.empty(max((len(data) - 12 - 4 * n.value) // 4, 1), dtype=np.uint32)
+    _lib.check(_lib.lib().basic_unframe_streams(buf.ctypes.data, len(data), ctypes.byref(h), ctypes.byref(w), ctypes.byref(n),
+                                                word_off.ctypes.data, n.value, words.ctypes.data))
+    return words[: int(word_off[-1])], word_off, (h.value, w.value)

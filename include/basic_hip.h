@@ -76,6 +76,17 @@ int basic_rans_decode_host(const basic_rans_tables *t, const uint8_t *stream, in
                            const int32_t *indexes, int64_t n, const int32_t *ar_indexes,
                            const int32_t *ar_off0, const int32_t *ar_off1, int32_t *out_symbols);
 
+/* Host framing of a batch of per-image streams, the wire format of CompressAI-style coders
+ * (reference: write_body / read_body, cbench/modules/prior_model/prior_coder/compressai_coder.py:63-84):
+ * ">III" (h, w, n) then per stream ">I" byte length + payload.  `words` holds the n streams back to
+ * back, stream i = words[word_off[i] .. word_off[i+1]).  frame: returns BASIC_ERR_OVERFLOW if
+ * out_capacity is too small (needed size in *out_len).  unframe: word_off needs n+1 entries and
+ * words_out (len - 12 - 4n) / 4 words; pass words_out = NULL to query h, w, n only. */
+int basic_frame_streams(const uint32_t *words, const int64_t *word_off, int n, uint32_t h, uint32_t w,
+                        uint8_t *out, int64_t out_capacity, int64_t *out_len);
+int basic_unframe_streams(const uint8_t *data, int64_t len, uint32_t *h, uint32_t *w, int *n,
+                          int64_t *word_off, int n_capacity, uint32_t *words_out);
+
 typedef struct basic_rans_stream basic_rans_stream;
 int basic_rans_stream_open(const basic_rans_tables *t, const uint8_t *stream, int64_t stream_len,
                            basic_rans_stream **out);

@@ -177,3 +177,25 @@ def test_shard_indices_cover_everything():
     for n, w in [(256, 8), (24, 8), (5, 8), (0, 2), (7, 1)]:
         allidx = sorted(i for r in range(w) for i in shard_indices(n, r, w))
         assert allidx == list(range(n))
+
+
+def test_c_framing_matches_write_body():
+    """basic_frame_streams / basic_unframe_streams == write_body / read_body (compressai_coder.py:63-84)."""
+    from cbench_basic_amd.nn import kernels as K
+    from cbench_basic_amd.modules.prior_model.prior_coder.compressai_coder import write_body, read_body
+    rng = np.random.default_rng(3)
+    lens = [2, 7, 2, 31, 5]
+    words = rng.integers(0, 2**32, size=sum(lens), dtype=np.uint32)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    strings = [[words[off[i]:off[i + 1]].tobytes()] for i in range(len(lens))]
+    ref = write_body((4, 6), strings)
+    got = K.frame_streams(words, off, (4, 6))
+    assert got == ref
+    w2, off2, shape = K.unframe_streams(ref)
+    assert shape == (4, 6) and np.array_equal(off2, off) and np.array_equal(w2, words)
+    back, shape2 = read_body(got)
+    assert shape2 == (4, 6) and [b[0] for b in back] == [s[0] for s in strings]
+    with pytest.raises(ValueError):
+        K.unframe_streams(ref[:-3])            # truncated body
+    with pytest.raises(ValueError):
+        K.unframe_streams(ref[:8])             # truncated header
