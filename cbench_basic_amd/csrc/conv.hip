@@ -138,7 +138,8 @@ __global__ __launch_bounds__(64 * WAVES, (MT <= 4 && WAVES == 4 ? 2 : 1)) void c
     const int wl_pad = ((wl_floats > gam_floats ? wl_floats : gam_floats) + kWPiece - 1) / kWPiece * kWPiece;
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform by construction: keeps LDS-DMA bases on the scalar unit
     const int khalf = lane >> 5, col = lane & 31;
 
     // tile origin
@@ -331,15 +332,20 @@ __global__ __launch_bounds__(64 * WAVES, (MT <= 4 && WAVES == 4 ? 2 : 1)) void c
             __syncthreads();  // chunk mk landed; every wave is done with the buffer the next chunk overwrites
             if (mk + 1 < MT) BASIC_ISSUE_GAMMA(mk + 1);
             const float *wl = lds + ((nstages + mk) & 1) * stage_floats;
+            float gk[2][MTP];  // A fragments one step ahead of their MFMAs, as in the main loop
+            load_a<MTP>(wl + ((4 * khalf) * 32 + col) * MTP, gk[0]);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
+                const int cur = r & 1, nxt = cur ^ 1;
+                const int rn = (r + 1 < 16) ? r + 1 : r;
+                load_a<MTP>(wl + ((8 * (rn >> 2) + (rn & 3) + 4 * khalf) * 32 + col) * MTP, gk[nxt]);
                 const float x = acc[mk][r];
                 const float bfrag = x * x;  // k = 32mk + 8(r>>2) + (r&3) [+4 for lanes 32..63]
-                float gk[MTP];
-                load_a<MTP>(wl + ((8 * (r >> 2) + (r & 3) + 4 * khalf) * 32 + col) * MTP, gk);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
-                    nrm[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(gk[m], bfrag, nrm[m], 0, 0, 0);
+                    nrm[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(gk[cur][m], bfrag, nrm[m], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
 #pragma unroll
@@ -393,7 +399,8 @@ __global__ __launch_bounds__(512, 1) void conv5x5_cin4_gdn_persistent_kernel(con
     float *wl = lds;
     float *gl = lds + kWFloats;
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform by construction: keeps LDS-DMA bases on the scalar unit
     const int khalf = lane >> 5, col = lane & 31;
     const int TB = 1 << g.tb_log, TH = 1 << g.th_log, TW = 1 << g.tw_log;
     const int chan_stride = g.ph * g.pwp;
@@ -706,7 +713,8 @@ constexpr int kSmDStage = kSmDSlots * 256 * 4;              // floats per stage 
 __global__ __launch_bounds__(256) void deconv5s2_cout3_dma_kernel(const SmallLaunch g)
 {
     __shared__ __attribute__((aligned(16))) float buf[2 * kSmDStage];
-    const int tid = threadIdx.x, wave = tid >> 6;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: LDS-DMA bases stay scalar
     int bid = blockIdx.x;
     const int tx_i = bid % g.tiles_x; bid /= g.tiles_x;
     const int ty_i = bid % g.tiles_y; bid /= g.tiles_y;
