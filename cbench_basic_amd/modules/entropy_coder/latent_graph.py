@@ -221,7 +221,15 @@ class LatentGraphicalANSEntropyCoder(HotPathModule, VariableRateCodecInterface, 
                         data[node] = node_data
                     else:
                         raw = node_data
-                        node_data = coder(raw, **pk)            # forward: quantised latent (:836)
+                        # forward: quantised latent (:836).  When encoding, a node whose quantised value feeds no
+                        # further module (the last latent: its only edge is the synthesis transform, skipped
+                        # below) does not need it, and nobody reads the rate estimate either.
+                        feeds = [e for e in self._generative_edges_from[node]
+                                 if not (do_encode and self.use_lossy_compression and e.split(sym)[1] == self.DEFAULT_INPUT_NODE_NAME)]
+                        if do_encode and not feeds:
+                            node_data = None
+                        else:
+                            node_data = coder(raw, **pk)
                         if do_encode:  # (:838); coders that can, only enqueue their GPU work here (resolved in encode())
                             data[node] = coder.encode(raw, lazy=True, **pk) if getattr(coder, "supports_lazy_encode", False) \
                                 else coder.encode(raw, **pk)
