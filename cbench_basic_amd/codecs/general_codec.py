@@ -30,6 +30,20 @@ class GeneralCodec(HotPathModule, CodecInterface, VariableRateCodecInterface, Va
     def forward(self, data, *args, **kwargs):
         return self.entropy_coder(data, *args, **kwargs)
 
+    def forward_estimate_bitlen(self, data, *args, **kwargs):
+        """general_codec.py:190-209: (reconstruction, estimated compressed size in BYTES) from the entropy
+        coder's cached rate estimate (prior_entropy is in nats per image)."""
+        import math
+        import torch
+        with torch.no_grad():
+            result = self.forward(data, *args, **kwargs)
+            estimated_bitlen = 0
+            pe = self.entropy_coder.get_raw_cache("metric_dict").get("prior_entropy") \
+                if hasattr(self.entropy_coder, "get_raw_cache") else None
+            if pe is not None:
+                estimated_bitlen = estimated_bitlen + pe * data.size(0) / math.log(2)
+            return result, estimated_bitlen / 8
+
     def update_state(self, *args, **kwargs) -> None:  # general_codec.py:320-326
         for m in self.children():
             if hasattr(m, "update_state"):

@@ -17,6 +17,7 @@ SURVEY 8f -- its RESULT (per-level node parameters) can be installed with
 import copy
 from typing import Any, Dict, List, Optional
 
+import math
 import torch
 import torch.nn as nn
 
@@ -287,6 +288,14 @@ class LatentGraphicalANSEntropyCoder(HotPathModule, VariableRateCodecInterface, 
             node_dict = self._node_generate_process(**self._get_default_node_dict(force_add_default_dynamic_nodes=True, **kwargs))
             latent = self._inference_process({self.DEFAULT_INPUT_NODE_NAME: data.to(self.device), **node_dict})
             data_dict, prior_dict = self._generative_process(latent)
+            # rate metrics (latent_graph.py:1168-1178): nats per image summed over the coded nodes, bits per dimension
+            total_prior_entropy, estimated_bpd = 0, 0
+            for name, module in self.latent_node_entropy_coders.items():
+                pe = module.get_raw_cache("metric_dict").get("prior_entropy") if hasattr(module, "get_raw_cache") else None
+                if pe is not None:
+                    total_prior_entropy = total_prior_entropy + pe
+                    estimated_bpd = estimated_bpd + pe / math.log(2) / (data.numel() / data.size(0))
+            self.update_cache("metric_dict", prior_entropy=total_prior_entropy, estimated_bpd=estimated_bpd)
             return data_dict[self.DEFAULT_INPUT_NODE_NAME]
 
     def update_state(self, *args, **kwargs) -> None:  # latent_graph.py:1297-1301

@@ -141,6 +141,15 @@ def test_rate_estimates_prior_entropy(setup):
     data = codec.compress(x)
     est_bits = (got_z + got_y) * 2 / 0.6931471805599453
     assert abs(est_bits - len(data) * 8) < 0.1 * len(data) * 8
+    # codec level (general_codec.py:190-209, latent_graph.py:1168-1178): forward_estimate_bitlen returns BYTES for
+    # the batch; the entropy coder caches prior_entropy (nats / image) and estimated_bpd (bits / input dimension)
+    xhat, est_bytes = codec.forward_estimate_bitlen(x.cuda())
+    assert xhat.shape == x.shape
+    assert abs(float(est_bytes) - len(data)) < 0.1 * len(data)
+    md = ec.get_raw_cache("metric_dict")
+    pe = float(md["prior_entropy"])
+    assert abs(pe * 2 / 0.6931471805599453 / 8 - float(est_bytes)) < 1e-3 * float(est_bytes)
+    assert abs(float(md["estimated_bpd"]) - pe / 0.6931471805599453 / (3 * 128 * 128)) < 1e-6
 
 
 def test_full_batch_properties(setup):
