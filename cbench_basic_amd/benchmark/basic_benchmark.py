@@ -1,0 +1,217 @@
+"""The testing half of ``BasicLosslessCompressionBenchmark`` (cbench/benchmark/basic_benchmark.py:105-326,640-1060) and
+``BaseBenchmark.save_metrics`` (cbench/benchmark/base.py:54-112): run codec.compress / decompress over a dataset for
+every (complexity level, rate level), collect the reference's metric names, write ``metrics.csv`` and ``metrics_2d.csv``.
+
+Step metrics (basic_benchmark.py:121-260): ``original_length`` (bytes of the input tensor), ``compression_ratio``,
+``compressed_length``, ``time_compress`` / ``time_decompress`` / ``time_total`` (ms), ``speed_*`` (MiB/s of original
+data), the distortion metric (``psnr``), and with ``nn_codec_use_forward_pass`` the ``*_nn_forward`` pair from
+``codec.forward_estimate_bitlen``.  Level loop and key prefixes (``sclevel{c}_vrlevel{r}_<metric>``) follow
+:913-1026, including BD-rate over the rate levels when there are more than three of them.
+"""
+import csv
+import os
+import pickle
+import time
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from .metrics import MetricLogger
+
+
+class BasicLosslessCompressionBenchmark:
+    def __init__(self, codec, dataloader, *args, distortion_metric=None, skip_decompress=False,
+                 nn_codec_use_forward_pass=False, nn_codec_forward_pass_skip_compression=False,
+                 testing_variable_rate_levels=None, testing_variable_rate_bj_delta_metric=None,
+                 testing_complexity_levels=None, force_testing_device="cuda", output_dir=None, num_repeats=1, **kwargs):
+        self.codec = codec
+        self.dataloader = dataloader
+        self.distortion_metric = distortion_metric
+        self.skip_decompress = skip_decompress
+        self.nn_codec_use_forward_pass = nn_codec_use_forward_pass
+        self.nn_codec_forward_pass_skip_compression = nn_codec_forward_pass_skip_compression
+        self.testing_variable_rate_levels = list(testing_variable_rate_levels or [])
+        self.testing_variable_rate_bj_delta_metric = testing_variable_rate_bj_delta_metric
+        self.testing_complexity_levels = list(testing_complexity_levels or [])
+        self.force_testing_device = force_testing_device
+        self.output_dir = output_dir
+        self.num_repeats = num_repeats
+        self.metric_logger = MetricLogger()
+
+    # ---- files (base.py:41-52)
+    @property
+    def metric_file(self):
+        return os.path.join(self.output_dir, "metrics.csv")
+
+    @property
+    def metric_raw_file(self):
+        return os.path.join(self.output_dir, "metrics.pkl")
+
+    # ---- one step (basic_benchmark.py:105-260)
+    @staticmethod
+    def _estimate_byte_length(data):
+        if isinstance(data, bytes):
+            return len(data)
+        if isinstance(data, str):
+            return len(data.encode("utf-8"))
+        if isinstance(data, torch.Tensor):
+            return int(np.prod(data.shape)) * data.element_size()
+        if isinstance(data, np.ndarray):
+            return int(data.size * data.itemsize)
+        raise ValueError("Bitstream of data {} in type {} cannot be estimated!".format(data, type(data)))
+
+    def _sync(self):
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()  # the device queue is empty before and after every timed region
+
+    def _run_step(self, step, data, metric_logger):
+        data_input = data_target = data.to(self.force_testing_device) if self.force_testing_device else data
+        original_length = self._estimate_byte_length(data_input)
+        metric_logger.update(original_length=original_length)
+        dm = self.distortion_metric
+        if self.nn_codec_use_forward_pass and hasattr(self.codec, "forward_estimate_bitlen"):
+            decompressed, compressed_length = self.codec.forward_estimate_bitlen(data_input)
+            compressed_length = float(compressed_length)
+            metric_logger.update(compression_ratio_nn_forward=compressed_length / original_length,
+                                 compressed_length_nn_forward=compressed_length)
+            if dm is not None:
+                dm(decompressed, data_target)
+            if self.nn_codec_forward_pass_skip_compression:
+                return
+        self._sync()
+        t0 = time.time()
+        compressed = self.codec.compress(data_input)
+        self._sync()
+        time_compress = time.time() - t0
+        compressed_length = self._estimate_byte_length(compressed)
+        metric_logger.update(compression_ratio=compressed_length / original_length, compressed_length=compressed_length,
+                             time_compress=time_compress * 1000,
+                             speed_compress=original_length / time_compress / 1024 / 1024)
+        if not self.skip_decompress:
+            t0 = time.time()
+            decompressed = self.codec.decompress(compressed)
+            self._sync()
+            time_decompress = time.time() - t0
+            metric_logger.update(time_decompress=time_decompress * 1000,
+                                 speed_decompress=original_length / time_decompress / 1024 / 1024,
+                                 time_total=(time_compress + time_decompress) * 1000,
+                                 speed_total=original_length / (time_compress + time_decompress) / 1024 / 1024)
+            if dm is not None:
+                dm(decompressed, data_target)
+
+    def _run_dataset(self):
+        logger = MetricLogger()
+        for step, data in enumerate(self.dataloader):
+            self._run_step(step, data, logger)
+        return logger.get_global_average()
+
+    # ---- level loop (basic_benchmark.py:640-1030): rate levels innermost, then complexity levels
+    def run_testing(self, *args, **kwargs):
+        metrics, metrics_2d = OrderedDict(), OrderedDict()
+        vr, vc = self.testing_variable_rate_levels, self.testing_complexity_levels
+        if hasattr(self.codec, "eval"):
+            self.codec.eval()
+        if self.force_testing_device and hasattr(self.codec, "to"):
+            self.codec.to(self.force_testing_device)
+        for _ in range(self.num_repeats):
+            for ci, clevel in enumerate(vc if vc else [None]):
+                rate_pts, distortion_pts = [], []
+                for ri, rlevel in enumerate(vr if vr else [None]):
+                    if clevel is not None:
+                        self.codec.set_complex_level(clevel)
+                    if rlevel is not None:
+                        self.codec.set_rate_level(rlevel)
+                    if hasattr(self.codec, "post_training_process"):
+                        self.codec.post_training_process()
+                    self.codec.update_state()
+                    if self.distortion_metric is not None:
+                        self.distortion_metric.reset()
+                    current = self._run_dataset()
+                    if self.distortion_metric is not None:
+                        current.update(**self.distortion_metric.collect_metrics())
+                    prefixes = []
+                    if clevel is not None:
+                        prefixes.append(f"sclevel{clevel}")
+                    if rlevel is not None:
+                        prefixes.append(f"vrlevel{rlevel}")
+                        bj = self.testing_variable_rate_bj_delta_metric
+                        if bj is not None:
+                            rn, dn = bj.collect_metric_names
+                            if rn in current and dn in current:
+                                rate_pts.append(current[rn])
+                                distortion_pts.append(current[dn])
+                    prefix = "_".join(prefixes)
+                    if prefixes:
+                        metrics_2d.setdefault(prefix, OrderedDict())
+                    for key, value in current.items():
+                        metrics[f"{prefix}_{key}"] = value  # (sic: the reference keeps the underscore without a prefix)
+                        if prefixes:
+                            metrics_2d[prefix][key] = value
+                    if len(vc) > 1 and hasattr(self.codec, "get_current_complex_metrics"):
+                        for key, value in self.codec.get_current_complex_metrics().items():
+                            metrics[f"{prefix}_{key}"] = value
+                            if prefixes:
+                                metrics_2d[prefix][key] = value
+                # BD metric over this complexity level's rate points (needs at least 4 points, :979-992)
+                bj = self.testing_variable_rate_bj_delta_metric
+                if bj is not None and len(vr) > 3 and len(rate_pts) == len(vr):
+                    bj_prefix = f"sclevel{ci}_" if vc else ""
+                    value = bj((rate_pts, distortion_pts))[bj.name]
+                    metrics[bj_prefix + bj.name] = value
+                    metrics_2d[prefix][bj.name] = value
+        if metrics_2d and self.output_dir:
+            self.save_metrics(metric_file=os.path.join(self.output_dir, "metrics_2d.csv"),
+                              metric_data=list(metrics_2d.values()), names=list(metrics_2d.keys()), raw=False)
+        return metrics
+
+    def run_benchmark(self, *args, run_testing=True, ignore_exist_metrics=False, **kwargs):
+        if self.codec is None:
+            raise ValueError("No codec to benchmark!")
+        if self.output_dir:
+            os.makedirs(self.output_dir, exist_ok=True)
+            if not ignore_exist_metrics and os.path.exists(self.metric_raw_file):
+                with open(self.metric_raw_file, "rb") as f:  # the benchmark has been run: its metrics are the result
+                    return pickle.load(f)
+        if run_testing:
+            metric_dict = self.run_testing(*args, **kwargs)
+            if self.output_dir:
+                self.save_metrics(metric_dict)
+            return metric_dict
+
+    # ---- base.py:54-112 (CSV: name column first, then metric columns in first-seen order, then hparams)
+    def save_metrics(self, metric_data=None, hparams=None, names=None, metric_file=None, raw=True):
+        metric_file = metric_file or self.metric_file
+        if metric_data is None:
+            return
+        if raw:
+            with open(self.metric_raw_file, "wb") as f:
+                pickle.dump(metric_data, f)
+        fieldnames, f_metrics, f_hparams, rows = OrderedDict(), OrderedDict(), OrderedDict(), []
+
+        def _append(metric, hparam=None, name=None):
+            row = OrderedDict()
+            if isinstance(metric, dict):
+                if name is not None:
+                    fieldnames["name"] = None
+                    row["name"] = name
+                for k in metric:
+                    f_metrics[k] = None
+                row.update(**metric)
+                if isinstance(hparam, dict):
+                    for k in hparam:
+                        f_hparams[k] = None
+                    row.update(**hparam)
+            rows.append(row)
+
+        if isinstance(metric_data, (list, tuple)):
+            hparams = hparams or [None] * len(metric_data)
+            names = names or [None] * len(metric_data)
+            for m, h, n in zip(metric_data, hparams, names):
+                _append(m, h, n)
+        else:
+            _append(metric_data, hparams, names)
+        with open(metric_file, "w", newline="") as f:
+            writer = csv.DictWriter(f, fieldnames=list(fieldnames) + list(f_metrics) + list(f_hparams))
+            writer.writeheader()
+            writer.writerows(rows)

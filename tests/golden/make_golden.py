@@ -218,8 +218,43 @@ def framing():
     save("framing.npz", **out)
 
 
+# ---------------------------------------------------------------- 7. benchmark harness: BD metrics, metrics.csv
+def harness():
+    import csv, io, tempfile
+    from cbench.benchmark.metrics.bj_delta import bj_delta
+    rng = np.random.default_rng(11)
+    out = {}
+    for case in range(4):
+        n1, n2 = 4 + case, 5 + (case % 2)
+        r1 = np.sort(rng.uniform(0.1, 2.0, n1)); p1 = 28 + 6 * np.log(r1 + 1) + rng.normal(0, 0.05, n1)
+        r2 = np.sort(rng.uniform(0.15, 2.2, n2)); p2 = 27.5 + 6.3 * np.log(r2 + 1) + rng.normal(0, 0.05, n2)
+        out[f"c{case}_r1"], out[f"c{case}_p1"], out[f"c{case}_r2"], out[f"c{case}_p2"] = r1, p1, r2, p2
+        out[f"c{case}_bd_psnr"] = np.float64(bj_delta(r1, p1, r2, p2, mode=0))
+        out[f"c{case}_bd_rate"] = np.float64(bj_delta(r1, p1, r2, p2, mode=1))
+    # save_metrics (cbench/benchmark/base.py:54-112) on a 2-row metric list with names: the CSV text is the fixture
+    from cbench.benchmark.base import BaseBenchmark
+    class _B(BaseBenchmark):
+        def __init__(self, d):
+            self.output_dir = d
+            import logging
+            self.logger = logging.getLogger("golden")
+        def run_benchmark(self, *a, **k):
+            pass
+        def collect_metrics(self, *a, **k):
+            return None
+    with tempfile.TemporaryDirectory() as d:
+        b = _B(d)
+        rows = [dict(compression_ratio=0.0125, compressed_length=9830.5, psnr=31.25), dict(compression_ratio=0.02, compressed_length=15728.0, psnr=33.5, FLOPs=1.5e9)]
+        try:
+            b.save_metrics(metric_file=os.path.join(d, "metrics_2d.csv"), metric_data=rows, names=["sclevel0_vrlevel0", "sclevel1_vrlevel0"])
+            out["csv_2d"] = b2a(open(os.path.join(d, "metrics_2d.csv"), "rb").read())
+        except Exception as e:  # the writer needs helpers this import environment may not provide
+            print("save_metrics not runnable here:", repr(e))
+    save("harness.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["rans", "tables", "topo", "mconv", "ar", "framing"]
-    fn = dict(rans=rans_kats, tables=gauss_tables, topo=topo_maps, mconv=masked_conv, ar=ar_coder, framing=framing)
+    which = sys.argv[1:] or ["rans", "tables", "topo", "mconv", "ar", "framing", "harness"]
+    fn = dict(rans=rans_kats, tables=gauss_tables, topo=topo_maps, mconv=masked_conv, ar=ar_coder, framing=framing, harness=harness)
     for w in which:
         fn[w]()

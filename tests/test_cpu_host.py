@@ -125,7 +125,9 @@ def test_latent_graph_traversal_with_standin_coders():
     xhat = ec.decode(data)
     assert torch.equal(xhat, x)
     names = [l[0] for l in log]
-    assert names == ["y.update", "z.update", "g_a", "h_a", "z.fwd", "z.enc", "h_s", "y.fwd", "y.enc", "z.dec", "h_s", "y.dec", "g_s"]
+    # reference order (latent_graph.py:836-856) minus "y.fwd": the quantised value of the LAST latent feeds only the
+    # synthesis transform, which encoding skips, so its forward is skipped too
+    assert names == ["y.update", "z.update", "g_a", "h_a", "z.fwd", "z.enc", "h_s", "y.enc", "z.dec", "h_s", "y.dec", "g_s"]
     assert ("y.enc", True) in log and ("z.enc", False) in log  # y is coded with the h_s prior, z unconditionally
 
 
@@ -199,3 +201,37 @@ def test_c_framing_matches_write_body():
         K.unframe_streams(ref[:-3])            # truncated body
     with pytest.raises(ValueError):
         K.unframe_streams(ref[:8])             # truncated header
+
+
+def test_benchmark_harness_formats(tmp_path):
+    """BD metrics and the metrics CSV writer against fixtures produced by the reference's own functions
+    (tests/golden/make_golden.py harness: bj_delta.py:48-94, base.py:54-112); image ingest = ToTensor (uint8 / 255)."""
+    from cbench_basic_amd.benchmark import BasicLosslessCompressionBenchmark, BJDeltaMetric, bj_delta
+    from cbench_basic_amd.data import ImageFolderDataset, RandomImageDataset, batched
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "harness.npz"))
+    for c in range(4):
+        r1, p1, r2, p2 = (g[f"c{c}_{k}"] for k in ("r1", "p1", "r2", "p2"))
+        assert abs(bj_delta(r1, p1, r2, p2, mode=0) - float(g[f"c{c}_bd_psnr"])) < 1e-9
+        assert abs(bj_delta(r1, p1, r2, p2, mode=1) - float(g[f"c{c}_bd_rate"])) < 1e-9
+    m = BJDeltaMetric(reference_pts=(g["c0_r2"], g["c0_p2"]), mode=1)
+    assert m.name == "BD-rate" and abs(m((g["c0_r1"], g["c0_p1"]))["BD-rate"] - float(g["c0_bd_rate"])) < 1e-9
+    b = BasicLosslessCompressionBenchmark(None, None, output_dir=str(tmp_path))
+    rows = [dict(compression_ratio=0.0125, compressed_length=9830.5, psnr=31.25),
+            dict(compression_ratio=0.02, compressed_length=15728.0, psnr=33.5, FLOPs=1.5e9)]
+    b.save_metrics(metric_file=str(tmp_path / "metrics_2d.csv"), metric_data=rows,
+                   names=["sclevel0_vrlevel0", "sclevel1_vrlevel0"], raw=False)
+    got = open(tmp_path / "metrics_2d.csv", "rb").read()
+    if "csv_2d" in g:
+        assert got.replace(b"\r\n", b"\n") == bytes(g["csv_2d"]).replace(b"\r\n", b"\n")
+    assert got.splitlines()[0] == b"name,compression_ratio,compressed_length,psnr,FLOPs"
+    # ingest
+    from PIL import Image
+    rng = np.random.default_rng(0)
+    a = rng.integers(0, 256, size=(5, 7, 3), dtype=np.uint8)
+    Image.fromarray(a).save(tmp_path / "a.png")
+    ds = ImageFolderDataset(str(tmp_path))
+    assert len(ds) == 1 and torch.equal(ds[0], torch.from_numpy(a).permute(2, 0, 1).float() / 255)
+    rd = RandomImageDataset(num=3, size=(3, 8, 8))
+    torch.manual_seed(2)
+    want = torch.rand(3, 8, 8)
+    assert torch.equal(rd[2], want) and [x.shape[0] for x in batched(rd, 2)] == [2, 1]
