@@ -18,6 +18,7 @@ import os
 import sys
 import time
 
+import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -171,9 +172,17 @@ def main():
     dt = time.time() - t0
 
     from cbench_basic_amd.nn import kernels as K
-    from cbench_basic_amd.utils.dist_metrics import reduce_metric_sums
+    from cbench_basic_amd.utils.dist_metrics import gather_per_image, reduce_metric_sums
     mse = K.mse_per_image(xhat, x)
-    psnr_sum = float((-10 * torch.log10(mse.double())).sum())
+    psnr_img = -10 * torch.log10(mse.double())
+    psnr_sum = float(psnr_img.sum())
+    # per-image (bytes, PSNR) of the last step, gathered over xGMI into image order (image i lives on rank i mod world):
+    # the analogue of the reference's per-image metric rows; not part of the timed region
+    from cbench_basic_amd.utils.bytes_ops import split_merged_bytes
+    zb, yb = split_merged_bytes(data, num_segments=2)
+    (_, zo, _), (_, yo, _) = K.unframe_streams(zb), K.unframe_streams(yb)
+    img_bytes = torch.from_numpy(4.0 * (np.diff(zo) + np.diff(yo)) + 8.0).to(dev)
+    table = gather_per_image(torch.stack([img_bytes.double(), psnr_img.to(dev)], dim=1), args.batch * world, rank, world)
     # the ONLY collective of the run: metric sums (analogue of cbench/utils/logging_utils.py:458-465)
     red = reduce_metric_sums(dict(time_s=dt, images=float(args.batch * args.steps), bytes=float(nbytes), psnr_sum=psnr_sum,
                                   psnr_n=float(args.batch)), device=dev)
@@ -200,7 +209,10 @@ def main():
             config=dict(workload=f"hyperprior codec N=128 M=192 (lossy_graph_scalable_exp_hp), synthetic 3x{args.size}x{args.size}, "
                                  f"{args.batch} images per GPU per step, compress+decompress incl. bytes D2H/H2D",
                         images_per_gpu=args.batch, bpp=n_bytes * 8 / pix, psnr_db=psnr_tot / n_psnr,
-                        parallelism=f"image-sharded x{world}, RCCL all-reduce of metric sums only"),
+                        gathered_images=int(table.shape[0]),
+                        gathered_bpp=float(table[:, 0].sum()) * 8 / (table.shape[0] * args.size * args.size),
+                        gathered_psnr_db=float(table[:, 1].mean()),
+                        parallelism=f"image-sharded x{world}, RCCL all-reduce of metric sums + all-gather of per-image (bytes, PSNR)"),
             roofline=dict(bound="mfma", achieved=achieved, peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
                           frac=achieved / PEAK_FP32_MFMA_TFLOPS, traffic=traffic,
                           kernel="conv_tap_mfma_kernel<MT,CK,KH,KW,WAVES> + first/last-layer kernels (the 38 transform launches of one encode+decode pass)",
@@ -208,7 +220,7 @@ def main():
                           avg_launch_ms=conv_s / launches * 1e3, pass_ms=conv_s * 1e3,
                           dominant=measure_dominant_kernel(codec, x)),
         )
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only; at N > 1 the other ranks would just wait for it
             out["cpu_baseline"] = cpu_baseline(cpu_state, args.cpu_images, args.size)
         print(json.dumps(out))
     if dist is not None:
