@@ -11,17 +11,20 @@
 //   * ConvTranspose2d(k, s, p):  s*s launches (sub-pixel phases); phase (py,px) keeps the taps
 //                                with ky = (py+p) mod s, s_in = 1, s_out = s, d = (py+p-ky)/s,
 //                                so no multiply-by-zero work is ever issued.
-// GEMM mapping (M = output channels, N = 128 output positions per workgroup, K = taps x Cin):
-//   * workgroup = 4 wavefronts; each wave owns ALL output channels x 32 positions, i.e. MT 32x32
+// GEMM mapping (M = output channels, N = 32 output positions per wavefront, K = taps x Cin):
+//   * workgroup = 4 (or 8) wavefronts; each wave owns ALL output channels x 32 positions, i.e. MT 32x32
 //     accumulator tiles.  Owning every channel of its pixels is what lets the GDN normalisation
 //     norm = beta + gamma . x^2 run as a SECOND MFMA GEMM straight from the accumulators:
 //     the C/D layout (column = lane, rows in registers) of x^2 IS the B-operand layout of the
 //     next 32x32x2 MFMA, with k-pairs (c, c+4) -- no LDS round trip, no lane shuffles.
-//   * K is walked CK input channels at a time: the input patch [TB][CK][PH][PW] and the packed
-//     weight slab [taps][CK][Cout] are staged in LDS; B fragments are patch reads at
-//     (s_in*pos + tap shift), A fragments are 32 consecutive output channels of one (tap, ci).
-//   * fp32 MFMA issues one 32x32x2 per 64 cycles per SIMD and each B fragment feeds MT of them,
-//     so LDS bandwidth is irrelevant here; the kernel is MFMA-issue bound by design.
+//   * K is walked CK input channels at a time through TWO LDS stage buffers {weight slab
+//     [taps][CK][32][MTP], input patch [TB][CK][PH][PW]} filled by LDS-DMA (global_load_lds) one stage
+//     ahead of the MFMAs; B fragments are patch reads at (s_in*pos + tap shift), the A fragments of all
+//     M-tiles of one (tap, ci) step are MTP consecutive floats (one ds_read_b128).
+//   * Measured on gfx950 (scripts/micro/mfma_peak.hip, mfma_lds.hip): back-to-back fp32 MFMAs reach
+//     99 % of the 157.3 TFLOP/s peak, and every OTHER instruction a SIMD issues costs matrix-pipe time.
+//     So for the codec's tap grids the stage is fully unrolled with compile-time LDS offsets (two LDS
+//     reads per MT MFMAs, nothing else); the remaining losses are stage barriers and DMA issue.
 #include "common.h"
 
 #include <cstdlib>

@@ -7,10 +7,14 @@
 //   core     csrc/ans/rans64.h:59-142 (ryg rans64)
 //
 // MI355X mapping: a stream is a strictly serial chain, so parallelism is ACROSS streams:
-// one 64-lane wavefront per stream (one image), hundreds of streams per launch.  Inside a
-// wave the 64 lanes do everything that is NOT serial -- table lookups, exact-division
-// reciprocals, the CDF search (64-ary, one ballot per probe) and coalesced loads/stores --
-// while the serial state update runs on wave-uniform values (scalar ALU).
+// one 64-lane wavefront per stream (one image), hundreds of streams per launch.  A lone wave issues
+// one instruction per ~8-11 cycles whatever it is (scripts/micro/lone_wave_latency.hip), so the
+// kernels are written for INSTRUCTION COUNT per symbol.  The fast paths make the state update itself
+// lane-parallel: every lane evaluates the update for "its" symbol (decoder: candidate symbol l of
+// the row; encoder: symbol j of the 64-symbol chunk) against the current wave-uniform state with a
+// few VALU ops, and only the chosen lane's new state is broadcast back; renormalisation, bypass
+// symbols and wide rows hide behind one rare-path test.  The generic kernels (AR remap, any table)
+// keep the state update on the scalar unit.
 #include "common.h"
 
 #include <algorithm>
