@@ -202,10 +202,10 @@ class CompressAIEntropyBottleneckPriorCoder(HotPathModule):
 
     def decode(self, byte_string, *args, channel_gains=None, channel_gains_inv=None, **kwargs):  # :238-245
         self._ready()
-        words, woff, shape = K.unframe_streams(byte_string)
-        B, C = len(woff) - 1, self.entropy_bottleneck.channels
+        h, w, B = K.frame_header(byte_string)
+        shape, C = (h, w), self.entropy_bottleneck.channels
         idx = torch.arange(C, device=self.device, dtype=torch.int32).reshape(1, C, 1, 1).expand(B, C, *shape).contiguous()
-        sym = self._tables.decode_batch_from_words(words, woff, idx.reshape(-1), C * shape[0] * shape[1])
+        sym = self._tables.decode_batch_from_frame(byte_string, idx.reshape(-1), C * shape[0] * shape[1])
         zhat = K.eb_dequantize(sym.reshape(B, C, *shape), self._medians_dev)
         if channel_gains_inv is not None:
             zhat = zhat * channel_gains_inv.reshape(1, -1, 1, 1)
@@ -314,10 +314,11 @@ class CompressAIGaussianConditionalCoder(HotPathModule):
 
     def decode(self, byte_string, *args, prior=None, channel_gains=None, channel_gains_inv=None, **kwargs):  # :387-393
         self._ready()
-        words, woff, shape = K.unframe_streams(byte_string)
+        h, w, _ = K.frame_header(byte_string)
+        shape = (h, w)
         scales = self._crop(prior, *shape)
         _, idx, _ = K.gc_quantize_index(scales, scales, self._scale_table_dev, self.scale_bound, want_yhat=False)
-        sym = self._tables.decode_batch_from_words(words, woff, idx.reshape(-1), idx[0].numel())
+        sym = self._tables.decode_batch_from_frame(byte_string, idx.reshape(-1), idx[0].numel())
         yhat = K.i32_to_f32(sym.reshape(idx.shape))
         if channel_gains_inv is not None:
             yhat = yhat * channel_gains_inv.reshape(1, -1, 1, 1)

@@ -177,27 +177,62 @@ class RansTables:
                                                              packed.data_ptr(), _stream()))
         return dict(symbols=symbols, indexes=indexes, n=n_per_stream, ns=ns, slot=slot, nwords=nwords, packed=packed, keep=words)
 
+    def _pinned(self, which, nbytes):
+        """Page-locked staging buffer owned by this table set (D2H of encoded words / H2D of words to decode): DMA at
+        full PCIe rate instead of the pageable path's bounce copies.  Grows geometrically, one per direction."""
+        buf = getattr(self, "_pin_" + which, None)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty((max(nbytes, 1 << 16) * 3 // 2,), dtype=torch.uint8, pin_memory=True)
+            setattr(self, "_pin_" + which, buf)
+        return buf
+
     def encode_batch_end(self, h):
-        """-> (uint32 words of all streams back to back (numpy), int64 word offsets [ns + 1])."""
+        """-> (uint32 words of all streams back to back (numpy), int64 word offsets [ns + 1]).  The words live in this
+        table set's pinned staging buffer: valid until its next encode_batch_end()."""
         nw = h["nwords"].cpu().numpy()
         if (nw < 0).any():  # bypass-heavy data overflowed the reference's bound: redo with the guaranteed one
             h = self.encode_batch_begin(h["symbols"], h["indexes"], h["n"], slot=3 * h["n"] + 4)
             nw = h["nwords"].cpu().numpy()
         off = np.zeros(h["ns"] + 1, dtype=np.int64)
         np.cumsum(nw, out=off[1:])
-        host = h["packed"][: int(off[-1])].cpu().numpy().view(np.uint32)
-        return host, off
+        n = int(off[-1])
+        stage = self._pinned("out", 4 * n)[: 4 * n].view(torch.int32)
+        stage.copy_(h["packed"][:n], non_blocking=True)
+        torch.cuda.current_stream(h["packed"].device).synchronize()
+        return stage.numpy().view(np.uint32), off
 
     def encode_batch_to_bytes(self, symbols, indexes, n_per_stream):
         """Equal-length streams (one per image): returns a list of ``bytes`` (reference py::bytes)."""
         host, off = self.encode_batch_end(self.encode_batch_begin(symbols, indexes, n_per_stream))
         return [host[off[i]:off[i + 1]].tobytes() for i in range(len(off) - 1)]
 
+    def _stage_in(self, nwords):
+        """uint32 numpy view of nwords words of the pinned H2D staging buffer (waits for the previous DMA out of it)."""
+        ev = getattr(self, "_pin_in_event", None)
+        if ev is not None:
+            ev.synchronize()
+        return self._pinned("in", 4 * max(nwords, 1))[: 4 * nwords].view(torch.int32)
+
+    def decode_batch_from_frame(self, data, indexes, n_per_stream):
+        """Framed body (frame_streams / write_body) -> int32 symbols like ``indexes``: the payloads are unframed by the C
+        helper straight into the pinned staging buffer and DMA'd from there."""
+        h, w, n = frame_header(data)
+        stage = self._stage_in((len(data) - 12 - 4 * n) // 4)
+        words, word_off, _ = unframe_streams(data, out=stage.numpy().view(np.uint32))
+        return self._decode_staged(stage[: words.size], word_off, indexes, n_per_stream)
+
     def decode_batch_from_words(self, host_words, word_off, indexes, n_per_stream):
         """Streams given as one uint32 array + word offsets (see unframe_streams): int32 symbols like ``indexes``."""
+        stage = self._stage_in(host_words.size)
+        stage.numpy()[:] = host_words.view(np.int32)
+        return self._decode_staged(stage, word_off, indexes, n_per_stream)
+
+    def _decode_staged(self, stage, word_off, indexes, n_per_stream):
         indexes = _dev(indexes, torch.int32)
         ns = len(word_off) - 1
-        d_words = torch.from_numpy(host_words.view(np.int32)).to(indexes.device)
+        d_words = stage.to(indexes.device, non_blocking=True)
+        self._pin_in_event = torch.cuda.Event()
+        self._pin_in_event.record(torch.cuda.current_stream(indexes.device))
         d_woff = torch.from_numpy(np.ascontiguousarray(word_off, dtype=np.int64)).to(indexes.device)
         seg = torch.arange(ns + 1, device=indexes.device, dtype=torch.int64) * n_per_stream
         out, _, _ = self.decode_batch(d_words, d_woff, indexes, seg)
@@ -306,14 +341,25 @@ def frame_streams(host_words, word_off, shape_hw) -> bytes:
     return out[: out_len.value].tobytes()
 
 
-def unframe_streams(data: bytes):
-    """read_body (compressai_coder.py:63-72) for one stream per image: (uint32 words, word offsets, (h, w))."""
+def frame_header(data: bytes):
+    """(h, w, n streams) of a framed body."""
+    buf = np.frombuffer(data, dtype=np.uint8)
+    h, w, n = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_int()
+    _lib.check(_lib.lib().basic_unframe_streams(buf.ctypes.data, len(data), ctypes.byref(h), ctypes.byref(w), ctypes.byref(n),
+                                                None, 0, None))
+    return h.value, w.value, n.value
+
+
+def unframe_streams(data: bytes, out=None):
+    """read_body (compressai_coder.py:63-72) for one stream per image: (uint32 words, word offsets, (h, w)).
+    ``out``: optional uint32 array of at least (len(data) - 12 - 4 n) / 4 words to receive the payloads."""
     buf = np.frombuffer(data, dtype=np.uint8)
     h, w, n = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_int()
     _lib.check(_lib.lib().basic_unframe_streams(buf.ctypes.data, len(data), ctypes.byref(h), ctypes.byref(w), ctypes.byref(n),
                                                 None, 0, None))
     word_off = np.empty(n.value + 1, dtype=np.int64)
-    words = np.empty(max((len(data) - 12 - 4 * n.value) // 4, 1), dtype=np.uint32)
+    payload = max((len(data) - 12 - 4 * n.value) // 4, 0)
+    words = out if out is not None and payload > 0 and out.size >= payload else np.empty(max(payload, 1), dtype=np.uint32)
     _lib.check(_lib.lib().basic_unframe_streams(buf.ctypes.data, len(data), ctypes.byref(h), ctypes.byref(w), ctypes.byref(n),
                                                 word_off.ctypes.data, n.value, words.ctypes.data))
     return words[: int(word_off[-1])], word_off, (h.value, w.value)
