@@ -182,6 +182,14 @@ __global__ __launch_bounds__(64 * WAVES, (MT <= 4 && WAVES == 4 ? 2 : 1)) void c
 
     int *tapoff = reinterpret_cast<int *>(lds + 2 * stage_floats);  // [ntaps] LDS offsets of the taps
     if (KH == 0 && tid < g.ntaps) tapoff[tid] = g.dy[tid] * g.pwp + g.dx[tid];
+    // Per-channel constants of the epilogue (bias, beta) go to LDS NOW, before any DMA is in flight: a global
+    // load next to outstanding LDS-DMAs makes the compiler wait vmcnt(0) per load (16 serial L2 round trips).
+    float *chan_const = lds + 2 * stage_floats + 32;  // [coutp] bias, [coutp] beta
+    if (tid < g.coutp) {
+        chan_const[tid] = bias ? bias[tid] : 0.f;
+        chan_const[g.coutp + tid] = g.beta ? g.beta[tid] : 1.f;
+    }
+    if (nstages == 0) __syncthreads();  // otherwise the first stage barrier publishes them
 
     // Per-thread gather descriptors, computed once: patch element i = tid + 256*s of every stage is DMA'd
     // from pp[s], which then advances by pstride[s] bytes (CK channels); elements outside the image (and the
@@ -306,8 +314,8 @@ __global__ __launch_bounds__(64 * WAVES, (MT <= 4 && WAVES == 4 ? 2 : 1)) void c
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {  // registers 4rq..4rq+3 are 4 consecutive channels: one 16-byte load
-                const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bias + 32 * m + 8 * rq + 4 * khalf);
+            for (int rq = 0; rq < 4; ++rq) {  // registers 4rq..4rq+3 are 4 consecutive channels: one 16-byte LDS read
+                const f32x4 b4 = *reinterpret_cast<const f32x4 *>(chan_const + 32 * m + 8 * rq + 4 * khalf);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[m][4 * rq + e] += b4[e];
             }
@@ -355,7 +363,7 @@ __global__ __launch_bounds__(64 * WAVES, (MT <= 4 && WAVES == 4 ? 2 : 1)) void c
         for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int rq = 0; rq < 4; ++rq) {
-                const f32x4 b4 = *reinterpret_cast<const f32x4 *>(g.beta + 32 * m + 8 * rq + 4 * khalf);
+                const f32x4 b4 = *reinterpret_cast<const f32x4 *>(chan_const + g.coutp + 32 * m + 8 * rq + 4 * khalf);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int r = 4 * rq + e;
@@ -411,6 +419,11 @@ __global__ __launch_bounds__(512, 1) void conv5x5_cin4_gdn_persistent_kernel(con
     const int patch_pad = (patch_elems + 511) / 512 * 512;
     const int n_pslots = patch_pad / 512;
     float *pbuf = gl + kGFloats;  // two patch buffers of patch_pad floats
+    float *chan_const = pbuf + 2 * patch_pad;  // [128] bias, [128] beta: read from LDS in every tile's epilogue
+    if (tid < 128) {
+        chan_const[tid] = g.bias ? g.bias[tid] : 0.f;
+        chan_const[128 + tid] = g.beta ? g.beta[tid] : 1.f;
+    }
 
     // resident operands: weight slab (6 whole 8 KB pieces + 2 KB) and gamma (8 pieces)
     {
@@ -479,8 +492,13 @@ __global__ __launch_bounds__(512, 1) void conv5x5_cin4_gdn_persistent_kernel(con
 
     int tile = blockIdx.x;
     if (tile < ntiles) BASIC_FIRST_ISSUE_PATCH(tile, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // weights, gamma and the first patch: this wave's DMAs have landed
     for (int it = 0; tile < ntiles; tile += gridDim.x, ++it) {
-        __syncthreads();  // this tile's patch (and, the first time, weights and gamma) landed; all waves left the previous tile
+        // Every wave waited for its own DMAs of this tile's patch BEFORE it issued the previous tile's stores (below), so a
+        // bare barrier publishes the patch -- and, unlike __syncthreads(), does not wait for those 64 stores per lane: the
+        // HBM-bound store phase of tile i drains underneath the MFMAs of tile i + 1.
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
         if (tile + static_cast<int>(gridDim.x) < ntiles && !(g.debug & 1)) BASIC_FIRST_ISSUE_PATCH(tile + gridDim.x, (it + 1) & 1);
         const float *patch = pbuf + (it & 1) * patch_pad;
 
@@ -514,7 +532,7 @@ __global__ __launch_bounds__(512, 1) void conv5x5_cin4_gdn_persistent_kernel(con
             for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int rq = 0; rq < 4; ++rq) {
-                    const f32x4 b4 = *reinterpret_cast<const f32x4 *>(g.bias + 32 * m + 8 * rq + 4 * khalf);
+                    const f32x4 b4 = *reinterpret_cast<const f32x4 *>(chan_const + 32 * m + 8 * rq + 4 * khalf);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) acc[m][4 * rq + e] += b4[e];
                 }
@@ -545,7 +563,7 @@ __global__ __launch_bounds__(512, 1) void conv5x5_cin4_gdn_persistent_kernel(con
             for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int rq = 0; rq < 4; ++rq) {
-                    const f32x4 b4 = *reinterpret_cast<const f32x4 *>(g.beta + 32 * m + 8 * rq + 4 * khalf);
+                    const f32x4 b4 = *reinterpret_cast<const f32x4 *>(chan_const + 128 + 32 * m + 8 * rq + 4 * khalf);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int r = 4 * rq + e;
@@ -555,6 +573,7 @@ __global__ __launch_bounds__(512, 1) void conv5x5_cin4_gdn_persistent_kernel(con
                 }
         }
         // ---- store (HBM-bound: 2 GB of fp32 activations leave this layer at B = 256)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next patch's DMAs (issued a whole tile ago) and older stores
         int bid = tile;
         const int tx_i = bid % g.tiles_x; bid /= g.tiles_x;
         const int ty_i = bid % g.tiles_y; bid /= g.tiles_y;
@@ -1155,7 +1174,7 @@ extern "C" int basic_conv_forward_dev(const basic_conv_plan *p, const float *d_i
         const int wl_pad = ((wl_floats > gam_floats ? wl_floats : gam_floats) + 4 * threads - 1) / (4 * threads) * (4 * threads);
         auto lds_need = [&](int tbv) {  // two stage buffers + tap table
             const int patch_pad = (tbv * kCK * g.ph * g.pwp + threads - 1) / threads * threads;
-            return sizeof(float) * (2 * static_cast<size_t>(wl_pad + patch_pad) + kMaxTaps);
+            return sizeof(float) * (2 * static_cast<size_t>(wl_pad + patch_pad) + 32 + 2 * g.coutp);  // + tap table, bias, beta
         };
         // the patch must fit the gather descriptors and both stage buffers the LDS
         while (tb > 1 && (tb * kCK * g.ph * g.pwp > patch_slots(ch.mt) * threads || lds_need(tb) > 160 * 1024)) tb >>= 1;
@@ -1172,7 +1191,7 @@ extern "C" int basic_conv_forward_dev(const basic_conv_plan *p, const float *d_i
             ch.cout == 128 && p->d_gammaT && !(dbg & 64)) {
             // single-stage GDN layer (the first analysis layer): persistent workgroups with resident weights and gamma
             const int patch_pad1 = (tb * kCK * g.ph * g.pwp + 511) / 512 * 512;
-            const size_t lds1 = sizeof(float) * (12800 + 16384 + 2 * static_cast<size_t>(patch_pad1));
+            const size_t lds1 = sizeof(float) * (12800 + 16384 + 2 * static_cast<size_t>(patch_pad1) + 256);
             if (lds1 <= 160 * 1024 && patch_pad1 <= kFirstSlots * 512) {
                 static bool attr1 = false;
                 if (!attr1) {
