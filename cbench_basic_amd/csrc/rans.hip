@@ -1254,8 +1254,13 @@ extern "C" int basic_rans_encode_host(const basic_rans_tables *t, const int32_t 
     ArDev ar;
     int rc = stage_ar(t, n, ar_indexes, ar_off0, ar_off1, b_ai, b_o0, b_o1, ar);
     if (rc) return rc;
-    hipLaunchKernelGGL(rans_encode_kernel, dim3(1), dim3(64), 0, nullptr, dev_view(t), ar, b_sym.as<int32_t>(),
-                       b_idx.as<int32_t>(), b_seg.as<int64_t>(), b_out.as<uint32_t>(), slot_words, b_nw.as<int32_t>());
+    if (!ar.tab && t->fast_enc_ok)  // same kernel choice as the batched device entry point
+        hipLaunchKernelGGL(rans_encode_fast_kernel, dim3(1), dim3(64), static_cast<size_t>(t->rows) * sizeof(int2), nullptr,
+                           dev_view(t), b_sym.as<int32_t>(), b_idx.as<int32_t>(), b_seg.as<int64_t>(), b_out.as<uint32_t>(),
+                           slot_words, b_nw.as<int32_t>());
+    else
+        hipLaunchKernelGGL(rans_encode_kernel, dim3(1), dim3(64), 0, nullptr, dev_view(t), ar, b_sym.as<int32_t>(),
+                           b_idx.as<int32_t>(), b_seg.as<int64_t>(), b_out.as<uint32_t>(), slot_words, b_nw.as<int32_t>());
     BASIC_HIP_TRY(hipGetLastError());
     int32_t nwords = 0;
     BASIC_HIP_TRY(hipMemcpy(&nwords, b_nw.p, sizeof(nwords), hipMemcpyDeviceToHost));

@@ -13,7 +13,7 @@ def _params(rng, nd, ns, ragged=True):
     return freqs, nsym, off
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(24))
 def test_encode_decode_matches_oracle(oracle, seed):
     from cbench_basic_amd import ans
     rng = np.random.default_rng(seed)
