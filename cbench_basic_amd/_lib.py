@@ -74,6 +74,10 @@ def lib():
             raise BasicHipError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(make -C cbench_basic_amd/csrc). cbench_basic_amd has no CPU fallback.")
+        # One HIP runtime per process: PyTorch ships its own libamdhip64 and the host mirror needs torch for device
+        # memory anyway, so torch is loaded FIRST and libbasic_hip.so binds to that copy.  (With the system runtime
+        # loaded first, torch's later initialisation finds "No HIP GPUs".)
+        import torch  # noqa: F401
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(L, name)
