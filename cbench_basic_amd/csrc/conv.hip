@@ -925,6 +925,8 @@ int build_chunks(basic_conv_plan *p, const float *weight, const float *bias, int
                 }
                 if (kys.empty() || kxs.empty()) {  // phase receives only the bias
                     ph.ntaps = 0;
+                    ph.waves = plan_waves(ch.mt, 0);
+                    ph.ck = stage_channels(0, ph.waves);  // must match the instantiation launch_mt picks (LDS layout)
                     ch.phases.push_back(ph);
                     continue;
                 }

@@ -75,6 +75,48 @@ def test_conv_matches_torch(case):
     _close(got, ref)
 
 
+def _random_case(rng):
+    """Random layer geometry, biased towards the kernels' special paths (8-wave 25-tap 128-channel convs, the persistent
+    first layer, the VALU output layer, 32-channel slices on tiny grids, runtime tap tables for k in {1, 2, 4})."""
+    kind = rng.integers(0, 8)
+    tr = bool(rng.integers(0, 2))
+    k = int(rng.choice([1, 2, 3, 4, 5]))
+    s = int(rng.choice([1, 2]))
+    p = int(rng.integers(0, k // 2 + 1))
+    op = int(rng.integers(0, s)) if tr else 0
+    cin, cout = int(rng.integers(1, 200)), int(rng.integers(1, 193))
+    act = str(rng.choice(["none", "relu", "leaky", "gdn", "igdn"]))
+    B, H, W = int(rng.integers(1, 6)), int(rng.integers(3, 40)), int(rng.integers(3, 40))
+    if kind == 0:    # 8-wave path
+        tr, k, s, p, op, cout = False, 5, 2, 2, 0, int(rng.integers(97, 129))
+    elif kind == 1:  # persistent first layer
+        tr, k, s, p, op, cin, cout, act = False, 5, int(rng.choice([1, 2])), 2, 0, int(rng.integers(1, 5)), 128, "gdn"
+        H, W = int(rng.integers(20, 70)), int(rng.integers(20, 70))
+    elif kind == 2:  # output layer
+        tr, k, s, p, op, cout, act = True, 5, 2, 2, 1, int(rng.integers(1, 4)), str(rng.choice(["none", "relu"]))
+        W = int(rng.choice([8, 12, 16, 64, 68, 9, 13]))
+    elif kind == 3:  # codec deconv phases
+        tr, k, s, p, op = True, 5, 2, 2, 1
+    if act in ("gdn", "igdn") and cout > 192:
+        act = "none"
+    if tr and op >= s:
+        op = 0
+    oh = (H - 1) * s - 2 * p + k + op if tr else (H + 2 * p - k) // s + 1
+    ow = (W - 1) * s - 2 * p + k + op if tr else (W + 2 * p - k) // s + 1
+    if oh < 1 or ow < 1:
+        return None
+    return (cin, cout, k, s, p, op, tr, act, B, H, W)
+
+
+@pytest.mark.parametrize("seed", range(160))
+def test_conv_fuzz(seed):
+    rng = np.random.default_rng(1000 + seed)
+    case = None
+    while case is None:
+        case = _random_case(rng)
+    test_conv_matches_torch(case)
+
+
 def test_slimmable_weight_slicing():
     """DynamicConv2d semantics (slimmable_layers.py:142-170): W[:co,:ci], b[:co]."""
     from cbench_basic_amd.nn import kernels as K
