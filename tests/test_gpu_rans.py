@@ -164,3 +164,57 @@ def test_batched_streams_device(oracle):
     out, state, pos = T.decode_batch(torch.from_numpy(allw).cuda(), torch.from_numpy(woff).cuda(), torch.from_numpy(idx).cuda(),
                                      torch.from_numpy(seg).cuda())
     assert np.array_equal(out.cpu().numpy(), sym)
+
+
+@pytest.mark.parametrize("seed", range(72))
+def test_batched_streams_fuzz(oracle, seed):
+    """Random tables (narrow and wide rows, precision 12..16, bypass on/off) and ragged stream lengths through the
+    batched device entry points -- the lane-parallel fast encoder / decoder whenever the table allows them -- against
+    the oracle stream by stream; includes bypass-heavy data that overflows the reference's n+2-word slot."""
+    import torch
+    from cbench_basic_amd.nn.kernels import RansTables
+    rng = np.random.default_rng(500 + seed)
+    nd = int(rng.integers(1, 40))
+    wide = seed % 3 == 0
+    ns = int(rng.integers(70, 1500)) if wide else int(rng.integers(2, 64))
+    byp = bool(seed % 2)
+    prec = 16 if seed % 4 == 0 else int(rng.integers(12, 17))
+    freqs = rng.integers(1, 200, (nd, ns)).astype(np.int32)
+    nsym = rng.integers(max(2, ns // 2), ns + 1, nd).astype(np.int32)
+    nsym[0] = ns
+    off = rng.integers(-40, 5, nd).astype(np.int32)
+    T = RansTables(freqs=freqs, nsym=nsym, offsets=off, precision=prec, bypass=byp, bypass_precision=4)
+    eo = oracle.Rans64Encoder(prec, byp, 4)
+    eo.init_params(freqs, nsym, off)
+    lens = [int(v) for v in rng.choice([0, 1, 2, 63, 64, 65, 127, 128, 129, 1000, 5000], size=int(rng.integers(1, 9)))]
+    seg = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    tot = int(seg[-1])
+    idx = rng.integers(0, nd, tot).astype(np.int32)
+    if byp:
+        sym = (off[idx] + rng.integers(-3, nsym[idx] + 3)).astype(np.int32)
+        if seed % 6 == 1:
+            sym[::3] = rng.integers(-10 ** 6, 10 ** 6, sym[::3].size)  # long escape codes
+    else:
+        sym = (off[idx] + rng.integers(0, 1 << 30, tot) % nsym[idx]).astype(np.int32)
+    slot = max(lens) * 3 + 4
+    words, nwords = T.encode_batch(torch.from_numpy(sym).cuda(), torch.from_numpy(idx).cuda(), torch.from_numpy(seg).cuda(), slot)
+    words, nwords = words.cpu().numpy().view(np.uint32), nwords.cpu().numpy()
+    streams = []
+    for i, L in enumerate(lens):
+        b = words[i, slot - nwords[i]:].tobytes()
+        assert b == eo.encode_with_indexes(sym[seg[i]:seg[i + 1]], idx[seg[i]:seg[i + 1]]), (i, L)
+        streams.append(np.frombuffer(b, np.uint32))
+    woff = np.concatenate([[0], np.cumsum([s.size for s in streams])]).astype(np.int64)
+    allw = np.concatenate(streams).view(np.int32)
+    out, _, _ = T.decode_batch(torch.from_numpy(allw).cuda(), torch.from_numpy(woff).cuda(), torch.from_numpy(idx).cuda(),
+                               torch.from_numpy(seg).cuda())
+    assert np.array_equal(out.cpu().numpy(), sym)
+    # equal-length convenience path with the reference's n+2 slot and its overflow fallback
+    if tot >= 64:
+        n = 32
+        k = tot // n
+        strs = T.encode_batch_to_bytes(torch.from_numpy(sym[: k * n]).cuda(), torch.from_numpy(idx[: k * n]).cuda(), n)
+        for i in (0, k - 1):
+            assert strs[i] == eo.encode_with_indexes(sym[i * n:(i + 1) * n], idx[i * n:(i + 1) * n])
+        back = T.decode_batch_from_bytes(strs, torch.from_numpy(idx[: k * n]).cuda(), n)
+        assert np.array_equal(back.cpu().numpy(), sym[: k * n])
