@@ -156,6 +156,8 @@ class RansTables:
         ns = seg.numel() - 1
         if slot_words is None:
             raise ValueError("slot_words is required")
+        if symbols.numel() == 0:  # every stream empty: the C ABI still wants valid pointers
+            symbols = indexes = torch.zeros((1,), device=seg.device, dtype=torch.int32)
         words = torch.empty((ns, slot_words), device=symbols.device, dtype=torch.int32)
         nwords = torch.empty((ns,), device=symbols.device, dtype=torch.int32)
         _lib.check(_lib.lib().basic_rans_encode_batch_dev(self._h, symbols.data_ptr(), indexes.data_ptr(), seg.data_ptr(), ns,
@@ -254,6 +256,8 @@ class RansTables:
         ns = seg.numel() - 1
         if out is None:
             out = torch.empty_like(indexes)
+        if indexes.numel() == 0:  # every stream empty: nothing to decode
+            return out, state, pos
         if state is None:
             state = torch.zeros((ns,), device=words.device, dtype=torch.int64)
             pos = torch.full((ns,), -1, device=words.device, dtype=torch.int64)
