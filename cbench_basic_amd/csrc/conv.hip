@@ -1098,10 +1098,16 @@ int launch_one(const TapLaunch &g, int blocks, int nsplit, size_t lds_bytes, hip
 // Unrolled instantiations for the tap grids of the codec's layers (5x5 and 3x3 convolutions, the four
 // sub-pixel phases of the 5x5 stride-2 transposed convolution); anything else takes the runtime tap table.
 template <int MT>
-int launch_mt(const TapLaunch &g, int kh, int kw, int blocks, int nsplit, size_t lds_bytes, hipStream_t st)
+int launch_mt(const TapLaunch &g, int kh, int kw, int plan_ck, int plan_waves_, int blocks, int nsplit, size_t lds_bytes,
+              hipStream_t st)
 {
     constexpr int WM = plan_waves(MT, kMaxTaps), WF = plan_waves(MT, kFewTaps), WV = plan_waves(MT, kVeryFewTaps);
     constexpr int kMany = stage_channels(kMaxTaps, WM), kFew = stage_channels(kFewTaps, WF), kVeryFew = stage_channels(kVeryFewTaps, WV);
+    // the packing (channels per stage) and the LDS size were derived from the plan's values: they must be the
+    // instantiation's, or the kernel would walk off its LDS allocation
+    const int inst_ck = g.ntaps > kFewTaps ? kMany : (g.ntaps > kVeryFewTaps ? kFew : kVeryFew);
+    const int inst_waves = g.ntaps > kFewTaps ? WM : (g.ntaps > kVeryFewTaps ? WF : WV);
+    BASIC_REQUIRE(inst_ck == plan_ck && inst_waves == plan_waves_, "conv_forward: plan / kernel instantiation mismatch");
     if (g.ntaps > kFewTaps) {
         if (kh == 5 && kw == 5) return launch_one<MT, kMany, 5, 5, WM>(g, blocks, nsplit, lds_bytes, st);
         return launch_one<MT, kMany, 0, 0, WM>(g, blocks, nsplit, lds_bytes, st);
@@ -1211,12 +1217,12 @@ extern "C" int basic_conv_forward_dev(const basic_conv_plan *p, const float *d_i
             }
         }
         switch (ch.mt) {
-            case 1: rc = launch_mt<1>(g, ph.kh, ph.kw, blocks, ch.nsplit, lds_bytes, st); break;
-            case 2: rc = launch_mt<2>(g, ph.kh, ph.kw, blocks, ch.nsplit, lds_bytes, st); break;
-            case 3: rc = launch_mt<3>(g, ph.kh, ph.kw, blocks, ch.nsplit, lds_bytes, st); break;
-            case 4: rc = launch_mt<4>(g, ph.kh, ph.kw, blocks, ch.nsplit, lds_bytes, st); break;
-            case 5: rc = launch_mt<5>(g, ph.kh, ph.kw, blocks, ch.nsplit, lds_bytes, st); break;
-            case 6: rc = launch_mt<6>(g, ph.kh, ph.kw, blocks, ch.nsplit, lds_bytes, st); break;
+            case 1: rc = launch_mt<1>(g, ph.kh, ph.kw, ph.ck, ph.waves, blocks, ch.nsplit, lds_bytes, st); break;
+            case 2: rc = launch_mt<2>(g, ph.kh, ph.kw, ph.ck, ph.waves, blocks, ch.nsplit, lds_bytes, st); break;
+            case 3: rc = launch_mt<3>(g, ph.kh, ph.kw, ph.ck, ph.waves, blocks, ch.nsplit, lds_bytes, st); break;
+            case 4: rc = launch_mt<4>(g, ph.kh, ph.kw, ph.ck, ph.waves, blocks, ch.nsplit, lds_bytes, st); break;
+            case 5: rc = launch_mt<5>(g, ph.kh, ph.kw, ph.ck, ph.waves, blocks, ch.nsplit, lds_bytes, st); break;
+            case 6: rc = launch_mt<6>(g, ph.kh, ph.kw, ph.ck, ph.waves, blocks, ch.nsplit, lds_bytes, st); break;
             default: set_error("conv_forward: cout > 192 unsupported"); rc = BASIC_ERR_INVALID;
         }
         if (rc) return rc;
