@@ -179,6 +179,42 @@ def test_masked_conv_positions(cfg):
     assert err <= TOL * max(1.0, float(ref.abs().max())), float(err)
 
 
+@pytest.mark.parametrize("seed", range(40))
+def test_masked_conv_fuzz(seed):
+    """Random channel counts / group structures / map sizes / position lists for the topo-group masked conv
+    (both the one-wave and the split-K variants are reached through the position count)."""
+    from cbench_basic_amd.nn import kernels as K
+    rng = np.random.default_rng(900 + seed)
+    gi, go = int(rng.choice([1, 2, 3, 4, 6])), int(rng.choice([1, 2, 3, 4, 6]))
+    cin, cout = gi * int(rng.integers(1, 40)), go * int(rng.integers(1, 40))
+    k = int(rng.choice([1, 3, 5]))
+    same = bool(rng.integers(0, 2))
+    B, H, W = int(rng.integers(1, 4)), int(rng.integers(2, 20)), int(rng.integers(2, 20))
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) * (1.0 / (cin * k * k) ** 0.5)
+    b = torch.randn(cout, generator=g) * 0.1
+    topo_in = torch.randint(-1, 5, (gi, H, W), generator=g)
+    topo_out = torch.randint(0, 5, (go, H, W), generator=g)
+    ref = _masked_conv_ref(x, w, b, topo_in, topo_out, same)
+    plan = K.MaskedConvPlan(w, b, gi, go, same)
+    npos = int(rng.integers(1, B * H * W + 1))
+    sel = torch.randperm(B * H * W, generator=g)[:npos].sort().values.int()
+    off = int(rng.choice([0, 3]))
+    out = torch.full((B, cout + off, H, W), -7.0).cuda()
+    plan(x.cuda(), topo_in.int().cuda(), topo_out.int().cuda(), sel.cuda(), out, out_offset=off)
+    torch.cuda.synchronize()
+    out = out.cpu()
+    mask = torch.zeros(B * H * W, dtype=torch.bool)
+    mask[sel.long()] = True
+    mask = mask.reshape(B, 1, H, W)
+    got = out[:, off:]
+    assert torch.all(out[:, :off] == -7.0)
+    assert torch.all(got[(~mask).expand_as(got)] == -7.0), "positions outside the list were touched"
+    err = ((got - ref).abs() * mask).max()
+    assert err <= TOL * max(1.0, float(ref.abs().max())), float(err)
+
+
 def test_entropy_param_kernels():
     from cbench_basic_amd.nn import kernels as K
     g = torch.Generator().manual_seed(0)
