@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Run the codec benchmark on one MI355X and write metrics.csv / metrics_2d.csv (the artefacts of the reference's
+tools/run_benchmark.py for the testing half of a benchmark config).
+
+  python tools/run_benchmark.py --codec hyperprior --images /data/kodak --out runs/hp_kodak
+  python tools/run_benchmark.py --codec basic --synthetic 8 --size 256 --complexity-levels 0 1 2 3 4 5 6 7 --out runs/basic
+  python tools/run_benchmark.py --codec topogroup --method checkerboard --synthetic 4 --out runs/ckbd
+
+Weights: --checkpoint takes a state_dict saved from the reference (keys as in INTEGRATION.md); without it the
+seeded synthetic weights of cbench_basic_amd.presets are used (plumbing / throughput runs).
+"""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument("--codec", choices=["hyperprior", "topogroup", "basic"], default="hyperprior")
+    ap.add_argument("--method", default="checkerboard", help="topo-group pattern of --codec topogroup")
+    ap.add_argument("--checkpoint", default=None, help="state_dict (.pt) of the entropy coder or of the whole codec")
+    ap.add_argument("--images", default=None, help="folder of PNG/JPEG images")
+    ap.add_argument("--synthetic", type=int, default=0, help="number of synthetic images (torch.manual_seed(i); rand)")
+    ap.add_argument("--size", type=int, default=256, help="height = width of the synthetic images")
+    ap.add_argument("--batch-size", type=int, default=1)
+    ap.add_argument("--complexity-levels", type=int, nargs="*", default=[])
+    ap.add_argument("--rate-levels", type=int, nargs="*", default=[])
+    ap.add_argument("--forward-pass", action="store_true", help="also record the forward-pass rate estimate")
+    ap.add_argument("--out", required=True)
+    args = ap.parse_args()
+    if not torch.cuda.is_available():
+        raise SystemExit("needs an MI355X: the codec has no CPU path")
+
+    from cbench_basic_amd import presets
+    from cbench_basic_amd.benchmark import BasicLosslessCompressionBenchmark, PytorchBatchedDistortion
+    from cbench_basic_amd.data import ImageFolderDataset, RandomImageDataset, batched
+    codec = dict(hyperprior=presets.hyperprior_codec, basic=presets.basic_codec,
+                 topogroup=lambda: presets.topogroup_ar_codec(method=args.method))[args.codec]()
+    if args.checkpoint:
+        sd = torch.load(args.checkpoint, map_location="cpu")
+        sd = sd.get("state_dict", sd)
+        missing = codec.load_state_dict(sd, strict=False) if any(k.startswith("entropy_coder.") for k in sd) \
+            else codec.entropy_coder.load_state_dict(sd, strict=False)
+        print("checkpoint loaded; missing keys:", len(missing.missing_keys), "unexpected:", len(missing.unexpected_keys))
+    else:
+        presets.seed_synthetic_weights(codec, seed=0)
+    codec = codec.eval().to("cuda")
+    if args.images:
+        ds = ImageFolderDataset(args.images)
+    else:
+        ds = RandomImageDataset(num=args.synthetic or 8, size=(3, args.size, args.size))
+    bench = BasicLosslessCompressionBenchmark(codec, list(batched(ds, args.batch_size)),
+                                              distortion_metric=PytorchBatchedDistortion(),
+                                              nn_codec_use_forward_pass=args.forward_pass,
+                                              testing_complexity_levels=args.complexity_levels,
+                                              testing_variable_rate_levels=args.rate_levels, output_dir=args.out)
+    metrics = bench.run_benchmark(ignore_exist_metrics=True)
+    print(json.dumps(metrics, indent=1))
+
+
+if __name__ == "__main__":
+    main()
