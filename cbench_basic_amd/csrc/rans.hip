@@ -642,11 +642,12 @@ __global__ __launch_bounds__(64) void rans_encode_fast_kernel(TablesDev T, const
         } while (0)
         const int j_lo = hi >= 64 ? 0 : static_cast<int>(64 - hi);
         int j = 63;
-        for (; j - 1 >= j_lo; j -= 2) {
-            BASIC_ENC_STEP(j);
-            BASIC_ENC_STEP(j - 1);
+        for (; j - 15 >= j_lo; j -= 16) {  // sixteen symbols per loop trip: the loop bookkeeping is issue slots too
+#define BASIC_ENC_STEP4(J) BASIC_ENC_STEP(J); BASIC_ENC_STEP((J) - 1); BASIC_ENC_STEP((J) - 2); BASIC_ENC_STEP((J) - 3)
+            BASIC_ENC_STEP4(j); BASIC_ENC_STEP4(j - 4); BASIC_ENC_STEP4(j - 8); BASIC_ENC_STEP4(j - 12);
+#undef BASIC_ENC_STEP4
         }
-        if (j >= j_lo) BASIC_ENC_STEP(j);
+        for (; j >= j_lo; --j) BASIC_ENC_STEP(j);
 #undef BASIC_ENC_STEP
         cur = nxt;
         i2 = i3; row2 = row3; s2 = s3;
@@ -973,9 +974,18 @@ __global__ __launch_bounds__(64) void rans_decode_fast_kernel(TablesDev T, const
         fetch(0, ea);
         fetch(cnt > 1 ? 1 : 0, eb);
         int j = 0;
+        for (; j + 17 < cnt; j += 16) {  // sixteen symbols per loop trip, no clamping of the prefetch index in here
+#pragma unroll
+            for (int u = 0; u < 16; u += 2) {
+                decode_one(j + u, ea);
+                fetch(j + u + 2, ea);  // two symbols ahead
+                decode_one(j + u + 1, eb);
+                fetch(j + u + 3, eb);
+            }
+        }
         for (; j + 1 < cnt; j += 2) {
             decode_one(j, ea);
-            fetch(j + 2 < cnt ? j + 2 : cnt - 1, ea);  // two symbols ahead
+            fetch(j + 2 < cnt ? j + 2 : cnt - 1, ea);
             decode_one(j + 1, eb);
             fetch(j + 3 < cnt ? j + 3 : cnt - 1, eb);
         }
