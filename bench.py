@@ -36,6 +36,7 @@ def parse():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--cpu-images", type=int, default=2000, help="bounded CPU-baseline sample (images)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-dominant", action="store_true", help="skip the single-launch roofline (counter passes: keeps the launch mix = timed passes)")
     return ap.parse_args()
 
 
@@ -218,7 +219,7 @@ def main():
                           kernel="conv_tap_mfma_kernel<MT,CK,KH,KW,WAVES> + first/last-layer kernels (the 38 transform launches of one encode+decode pass)",
                           flops_per_launch=flops_pass / launches, launches_per_pass=launches,
                           avg_launch_ms=conv_s / launches * 1e3, pass_ms=conv_s * 1e3,
-                          dominant=measure_dominant_kernel(codec, x)),
+                          dominant=None if args.no_dominant else measure_dominant_kernel(codec, x)),
         )
         if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only; at N > 1 the other ranks would just wait for it
             out["cpu_baseline"] = cpu_baseline(cpu_state, args.cpu_images, args.size)

@@ -29,7 +29,7 @@ def main():
     launches = sum(v["launches"] for v in fs.values())
     kib = sum(v["kib_total"] for v in fs.values()) + sum(v["kib_total"] for v in ws.values())
     doc = dict(
-        command="rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline",
+        command="rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-dominant",
         note="FETCH_SIZE/WRITE_SIZE in KiB as reported.  The weight slabs and gamma are read with 16-byte LDS-DMA pieces "
              "(the case MI355X_MICROARCH.md says FETCH_SIZE under-reports by 2x) but they are L2 hits re-read by every "
              "workgroup, not HBM streams; the activation patches are 4-byte-per-lane gathers, outside that calibration. "
