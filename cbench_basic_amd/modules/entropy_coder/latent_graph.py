@@ -14,7 +14,6 @@ scope; the greedy complexity search itself (post_training_process) is a "next" r
 SURVEY 8f -- its RESULT (per-level node parameters) can be installed with
 ``set_complexity_level_params``.
 """
-import copy
 from typing import Any, Dict, List, Optional
 
 import math
