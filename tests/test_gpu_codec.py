@@ -73,7 +73,7 @@ def test_transforms_and_symbols(setup, shape):
         assert _rel(xhat.cpu(), xhat_ref) < 1e-4
 
 
-@pytest.mark.parametrize("shape", [(1, 3, 64, 64), (3, 3, 64, 96)])
+@pytest.mark.parametrize("shape", [(1, 3, 64, 64), (3, 3, 64, 96), (2, 3, 192, 128), (5, 3, 64, 64), (1, 3, 128, 256), (4, 3, 128, 64)])
 def test_compress_decompress_vs_oracle(setup, shape):
     from oracle.codec_oracle import psnr
     codec, oracle = setup
