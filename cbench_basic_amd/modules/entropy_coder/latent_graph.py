@@ -10,13 +10,14 @@ update_state hot path:
 
 Graph traversal is tiny host logic; every tensor operation it triggers is a HIP kernel.
 Training-only machinery (losses, MC sampling, FLOPs regularisers, sandwich rule) is out of
-scope; the greedy complexity search itself (post_training_process) is a "next" row of
-SURVEY 8f -- its RESULT (per-level node parameters) can be installed with
-``set_complexity_level_params``.
+scope.  The greedy complexity-level search of BaSIC (post_training_process, latent_graph.py:1397-1640) is here:
+selection logic in complexity_search.py, evaluation = this codec's own forward on the GPU; a ready-made result
+(per-level node parameters) can also be installed with ``set_complexity_level_params``.
 """
-from typing import Any, Dict, List, Optional
+from typing import Any, Dict, Iterable, List, Optional
 
 import math
+import time
 import torch
 import torch.nn as nn
 
@@ -24,6 +25,7 @@ from ...base import HotPathModule
 from ...codecs.base import (VariableComplexityCodecInterface, VariableRateCodecInterface,
                             VariableTaskCodecInterface)
 from ...utils.bytes_ops import merge_bytes, split_merged_bytes
+from .complexity_search import search_complexity_levels
 
 
 class LossyDummyEntropyCoder(HotPathModule):
@@ -35,7 +37,22 @@ class LossyDummyEntropyCoder(HotPathModule):
         self.lambda_rd = lambda_rd
         self.distortion_type = distortion_type
 
-    def forward(self, data, *args, prior=None, **kwargs):
+    def forward(self, data, *args, prior=None, lambda_rd=None, prior_target=None, **kwargs):
+        """latent_graph.py:121-141: distortion metrics of the reconstruction (= prior).  metric_dict gets ``mse`` and
+        ``weighted_distortion`` = lambda_rd * (sum of squared errors per image, averaged over the batch) (:83-88,:139)."""
+        if isinstance(data, torch.Tensor) and isinstance(prior, torch.Tensor):
+            if self.distortion_type != "mse":
+                raise NotImplementedError(f"distortion_type {self.distortion_type}")
+            target = data if prior_target is None else prior_target
+            rec = prior
+            for dim, size in enumerate(target.shape[2:], 2):  # crop to the target size (:127-129)
+                if rec.shape[dim] != size:
+                    rec = rec.narrow(dim, 0, size)
+            from ...nn import kernels as K
+            mse = K.mse_per_image(rec.contiguous(), target.contiguous())  # [B], HIP reduction
+            loss_distortion = (mse * (target.numel() // target.shape[0])).mean()
+            self.update_cache("metric_dict", mse=mse.mean(),
+                              weighted_distortion=loss_distortion * (self.lambda_rd if lambda_rd is None else lambda_rd))
         return prior
 
     def encode(self, data, *args, prior=None, **kwargs) -> bytes:
@@ -46,6 +63,29 @@ class LossyDummyEntropyCoder(HotPathModule):
 
     def update_state(self, *args, **kwargs):
         pass
+
+
+class ParamDictModuleWrapper(nn.Module):
+    """latent_graph.py:270-298: keeps a dict of node values as buffers so the searched complexity levels travel in the
+    state_dict under the reference's keys (``_complexity_param_all_levels.<level>.<node>``)."""
+
+    def __init__(self, params: Dict[str, Any]):
+        super().__init__()
+        self.none_params = []
+        for name, value in params.items():
+            if value is None:
+                self.none_params.append(name)
+            elif isinstance(value, dict):
+                setattr(self, name, ParamDictModuleWrapper(value))
+            else:
+                self.register_buffer(name, torch.as_tensor(value).detach().clone())
+
+    def forward(self, *args, **kwargs):
+        out = {name: None for name in self.none_params}
+        out.update(self._buffers)
+        for name, m in self._modules.items():
+            out[name] = m()
+        return out
 
 
 class LatentGraphicalANSEntropyCoder(HotPathModule, VariableRateCodecInterface, VariableComplexityCodecInterface,
@@ -72,9 +112,18 @@ class LatentGraphicalANSEntropyCoder(HotPathModule, VariableRateCodecInterface, 
                  latent_generative_input_mapping: Optional[Dict[str, Dict[str, str]]] = None,
                  latent_node_inference_topo_order: Optional[List[str]] = None,
                  latent_node_generative_topo_order: Optional[List[str]] = None,
+                 complexity_metric_list=None,
                  complexity_level_greedy_search=False,
+                 complexity_level_greedy_search_dataset: Optional[Iterable] = None,
+                 complexity_level_greedy_search_dataset_cached=False,
+                 complexity_level_greedy_search_iterative=False,
                  complexity_level_greedy_search_num_levels: Optional[int] = None,
+                 complexity_level_greedy_search_custom_constraint: Optional[List[float]] = None,
+                 complexity_level_greedy_search_performance_metric: Optional[str] = None,
+                 complexity_level_greedy_search_complexity_metric: Optional[str] = None,
+                 complexity_level_greedy_search_add_controller_nodes_as_complexity_metric=True,
                  complexity_level_controller_nodes=(),
+                 complexity_level_greedy_search_custom_params: Optional[List[Dict[str, int]]] = None,
                  task_names: Optional[List[str]] = None,
                  **kwargs):
         super().__init__()
@@ -118,14 +167,56 @@ class LatentGraphicalANSEntropyCoder(HotPathModule, VariableRateCodecInterface, 
         self._num_rate_levels = _levels(self.DEFAULT_RATE_LEVEL_NODE_NAME)
         self._num_tasks = _levels(self.DEFAULT_TASK_INDEX_NODE_NAME)
         self._num_complex_levels = _levels(self.DEFAULT_COMPLEX_LEVEL_NODE_NAME)
-        if complexity_level_greedy_search and complexity_level_greedy_search_num_levels is not None:
-            self._num_complex_levels = complexity_level_greedy_search_num_levels
         self._current_rate_level = -1
         self._current_task_idx = -1
         self._current_complex_level = -1
-        self._complexity_param_all_levels = None  # list of {node name: value}, one per level
+        self._complexity_param_all_levels = None  # ModuleList of ParamDictModuleWrapper, one per level
+        self._searching = False  # True while post_training_process evaluates explicit controller settings
+        self._valid_host = None
+        self.register_load_state_dict_post_hook(lambda module, incompatible: setattr(module, "_valid_host", None))
+        # greedy complexity-level search (latent_graph.py:590-634)
+        self.complexity_metric_list = list(complexity_metric_list or [])
+        self.complexity_level_greedy_search_dataset = complexity_level_greedy_search_dataset
+        self.complexity_level_greedy_search_dataset_cached = complexity_level_greedy_search_dataset_cached
+        self.complexity_level_greedy_search_iterative = complexity_level_greedy_search_iterative
+        self.complexity_level_greedy_search_custom_constraint = complexity_level_greedy_search_custom_constraint
+        self.complexity_level_greedy_search_custom_params = complexity_level_greedy_search_custom_params
+        self.complexity_level_greedy_search_complexity_metric = complexity_level_greedy_search_complexity_metric
+        self.complexity_level_greedy_search_performance_metric = complexity_level_greedy_search_performance_metric
+        if complexity_level_greedy_search:
+            if complexity_level_greedy_search_num_levels is not None:
+                self._num_complex_levels = complexity_level_greedy_search_num_levels
+            elif complexity_level_greedy_search_custom_constraint is not None:
+                self._num_complex_levels = len(complexity_level_greedy_search_custom_constraint)
+            valid = False
+            if complexity_level_greedy_search_custom_params is not None:
+                levels = [{k: self.node_generators[k](v) for k, v in idx.items()}
+                          for idx in complexity_level_greedy_search_custom_params]
+                self._num_complex_levels = len(levels)
+            else:  # every level starts as the most complex setting until post_training_process has run (:604-615)
+                most = {k: self.node_generators[k](self.node_generators[k].min_sample) for k in self.complexity_level_controller_nodes}
+                levels = [most for _ in range(self._num_complex_levels)]
+            self._complexity_param_all_levels = nn.ModuleList([ParamDictModuleWrapper(lv) for lv in levels])
+            self.register_buffer("_complexity_param_valid", torch.tensor([valid]))
+            if self.complexity_level_greedy_search_complexity_metric is None:
+                self.complexity_level_greedy_search_complexity_metric = "FLOPs"
+            self.complexity_metric_list.append(self.complexity_level_greedy_search_complexity_metric)
+            if self.complexity_level_greedy_search_performance_metric is None:
+                self.complexity_level_greedy_search_performance_metric = "loss"
+            self.complexity_metric_list.append(self.complexity_level_greedy_search_performance_metric)
+            if complexity_level_greedy_search_add_controller_nodes_as_complexity_metric:
+                self.complexity_metric_list.extend(self.complexity_level_controller_nodes)
+        if self._num_complex_levels > 0 and len(self.complexity_metric_list) > 0:  # (:641-645)
+            self.register_buffer("_complexity_metric_list_cache",
+                                 torch.zeros(self._num_complex_levels, len(self.complexity_metric_list)))
         if self._num_tasks > 0 and self.task_names is None:
             self.task_names = list(range(self._num_tasks))
+
+    def _levels_valid(self):
+        """_complexity_param_valid as a host bool (read once; refreshed after load_state_dict / search)."""
+        if self._valid_host is None:
+            self._valid_host = bool(self._complexity_param_valid.item())
+        return self._valid_host
 
     # ---- default nodes (latent_graph.py:650-683)
     def _get_default_node_dict(self, force_add_default_dynamic_nodes=False, **kwargs):
@@ -143,8 +234,8 @@ class LatentGraphicalANSEntropyCoder(HotPathModule, VariableRateCodecInterface, 
             elif force_add_default_dynamic_nodes:
                 out[self.DEFAULT_TASK_INDEX_NODE_NAME] = 0
         if self._num_complex_levels > 0 and self.DEFAULT_COMPLEX_LEVEL_NODE_NAME not in out:
-            if self.complexity_level_greedy_search and self._complexity_param_all_levels is not None:
-                out.update(**self._complexity_param_all_levels[self._current_complex_level])  # :673-675
+            if self.complexity_level_greedy_search and self._levels_valid() and not self._searching:
+                out.update(**self._complexity_param_all_levels[self._current_complex_level]())  # :673-675
             elif self._current_complex_level >= 0:
                 out[self.DEFAULT_COMPLEX_LEVEL_NODE_NAME] = self._current_complex_level
             elif force_add_default_dynamic_nodes:
@@ -319,14 +410,135 @@ class LatentGraphicalANSEntropyCoder(HotPathModule, VariableRateCodecInterface, 
         return max(1, self._num_complex_levels)
 
     def set_complexity_level_params(self, params_per_level: List[Dict[str, Any]]):
-        """Install the outcome of the greedy search (latent_graph.py:1615-1619): one dict of
-        controller-node values (e.g. slim one-hots pgmxy/pgmyz/pgmzy/pgmyx) per level."""
-        self._complexity_param_all_levels = list(params_per_level)
+        """Install a ready-made outcome of the search (latent_graph.py:1615-1619): one dict of controller-node values
+        (e.g. slim one-hots pgmxy/pgmyz/pgmzy/pgmyx) per level."""
+        dev = self.device
+        self._complexity_param_all_levels = nn.ModuleList([ParamDictModuleWrapper(p) for p in params_per_level]).to(dev)
         self._num_complex_levels = len(params_per_level)
         self.complexity_level_greedy_search = True
+        if not hasattr(self, "_complexity_param_valid"):
+            self.register_buffer("_complexity_param_valid", torch.tensor([True], device=dev))
+        self._complexity_param_valid.fill_(True)
+        self._valid_host = None
+        if len(self.complexity_metric_list) > 0:
+            self.register_buffer("_complexity_metric_list_cache",
+                                 torch.zeros(self._num_complex_levels, len(self.complexity_metric_list), device=dev))
 
-    def get_current_complex_metrics(self, *args, **kwargs):
-        return dict()
+    def get_current_complex_metrics(self, *args, **kwargs):  # latent_graph.py:1675-1687
+        if not hasattr(self, "_complexity_metric_list_cache"):
+            return dict()
+        row = self._complexity_metric_list_cache[self._current_complex_level]
+        return {name: row[i].item() for i, name in enumerate(self.complexity_metric_list)}
+
+    # ---- complexity accounting and the greedy level search (latent_graph.py:1303-1640)
+    def get_current_flops(self, input=None):
+        """Sum of the dynamic transforms' operation counters of the last forward (nn/base.py:675-680)."""
+        total = 0.0
+        for m in self.modules():
+            if m is not self and hasattr(m, "get_current_flops"):
+                total += float(m.get_current_flops())
+        return total
+
+    def _test_dataset_complexity_performance(self, dataset, *args, performance_method="loss", complexity_method="FLOPs",
+                                             **node_params):
+        """(complexity, performance) of one controller setting over a dataset, both divided by the number of input
+        elements (latent_graph.py:1320-1395).
+
+        performance "loss" = the rate and distortion loss terms: loss_rate = prior_entropy / ln 2 of every coded node
+        (bits per image; compressai_coder.py:213-215, pgm_coder.py:516) + loss_distortion = lambda_rd * SSE per image
+        (:83-88).  The reference evaluates them in train mode, i.e. with its additive-uniform-noise proxies, so its
+        number is a random variable; here they are evaluated on the ROUNDED latents the codec actually codes
+        (eval-mode forward), which is deterministic.  complexity "FLOPs" = get_current_flops(); the timing variants
+        ("compress_time", "decompress_time", "total_time") wall-clock encode / decode."""
+        if performance_method != "loss":
+            raise NotImplementedError(performance_method)
+        coders = [c for c in self.latent_node_entropy_coders.values() if hasattr(c, "estimate_rate")]
+        saved = [c.estimate_rate for c in coders]
+        for c in coders:
+            c.estimate_rate = True
+        performance, complexity, total_dims = 0.0, 0.0, 0
+        searching, self._searching = self._searching, True
+        try:
+            for data in dataset:
+                if isinstance(data, (list, tuple)):
+                    data = data[0]
+                total_dims += data.numel()
+                self.forward(data, *args, **node_params)
+                loss = 0.0
+                for name, coder in self.latent_node_entropy_coders.items():
+                    md = coder.get_raw_cache("metric_dict") if hasattr(coder, "get_raw_cache") else {}
+                    if "prior_entropy" in md:
+                        loss += float(md["prior_entropy"]) / math.log(2)
+                    if "weighted_distortion" in md:
+                        loss += float(md["weighted_distortion"])
+                performance += loss
+                if complexity_method == "FLOPs":
+                    complexity += self.get_current_flops()
+                elif complexity_method in ("compress_time", "decompress_time", "total_time"):
+                    torch.cuda.synchronize()
+                    t0 = time.time()
+                    byte_string = self.encode(data, *args, **node_params)
+                    t1 = time.time()
+                    out = self.decode(byte_string, *args, **node_params)
+                    if isinstance(out, torch.Tensor) and out.is_cuda:
+                        torch.cuda.synchronize()
+                    t2 = time.time()
+                    complexity += {"compress_time": t1 - t0, "decompress_time": t2 - t1, "total_time": t2 - t0}[complexity_method]
+                else:
+                    raise NotImplementedError(complexity_method)
+                self.reset_all_cache()
+        finally:
+            self._searching = searching
+            for c, v in zip(coders, saved):
+                c.estimate_rate = v
+        if total_dims == 0:
+            raise ValueError("complexity_level_greedy_search_dataset is empty")
+        return complexity / total_dims, performance / total_dims
+
+    def post_training_process(self, *args, force=False, dataset=None, **kwargs) -> None:
+        """latent_graph.py:1397-1640: fill the complexity levels by searching the controller settings.  Runs once
+        (``_complexity_param_valid``) unless ``force``; ``dataset`` overrides complexity_level_greedy_search_dataset."""
+        if not self.complexity_level_greedy_search:
+            return
+        self.update_state()
+        if not (force or not self._levels_valid()):
+            return
+        names = list(self.complexity_level_controller_nodes)
+        if self.complexity_level_greedy_search_custom_params is not None:
+            levels = [dict(idx) for idx in self.complexity_level_greedy_search_custom_params]
+            rows = None
+        else:
+            if self.complexity_level_greedy_search_iterative:
+                raise NotImplementedError("complexity_level_greedy_search_iterative (see complexity_search.py)")
+            data = dataset if dataset is not None else self.complexity_level_greedy_search_dataset
+            if data is None:
+                raise ValueError("complexity_level_greedy_search_dataset is required for the complexity search")
+            if self.complexity_level_greedy_search_dataset_cached or not isinstance(data, (list, tuple)):
+                data = list(data)
+            gens = {n: self.node_generators[n] for n in names}
+
+            def evaluate(idx):
+                return self._test_dataset_complexity_performance(
+                    data, performance_method=self.complexity_level_greedy_search_performance_metric,
+                    complexity_method=self.complexity_level_greedy_search_complexity_metric,
+                    **{n: gens[n](idx[n]) for n in names})
+
+            result = search_complexity_levels(
+                evaluate, names, {n: gens[n].min_sample for n in names}, {n: gens[n].max_sample for n in names},
+                num_levels=self._num_complex_levels, custom_constraint=self.complexity_level_greedy_search_custom_constraint)
+            levels = result.levels
+            rows = result.metric_rows(self.complexity_metric_list, self.complexity_level_greedy_search_complexity_metric,
+                                      self.complexity_level_greedy_search_performance_metric)
+            self.complexity_search_result = result
+        dev = self.device
+        self._complexity_param_all_levels = nn.ModuleList(
+            [ParamDictModuleWrapper({n: self.node_generators[n](v) for n, v in lvl.items()}) for lvl in levels]).to(dev)
+        self._num_complex_levels = len(levels)
+        if rows is not None and hasattr(self, "_complexity_metric_list_cache"):
+            self._complexity_metric_list_cache = torch.tensor(rows, dtype=torch.float32, device=dev)
+        self._complexity_param_valid.fill_(True)
+        self._valid_host = None
+        self.eval()
 
     def set_task(self, task, *args, **kwargs) -> bool:
         if self._num_tasks == 0:

@@ -22,6 +22,7 @@ class SlimmableConv2dPGMModel(nn.Module):
         self.pgm_model = self.build_pgm_model()
         self._plans = {}
         self._key = None
+        self.total_ops = 0.0
 
     def build_pgm_model(self) -> nn.Module:
         raise NotImplementedError()
@@ -79,12 +80,36 @@ class SlimmableConv2dPGMModel(nn.Module):
             h, w = p.out_hw(h, w)
         return total
 
+    def reference_ops(self, level, batch, h, w):
+        """The reference's complexity counter for one forward at this width level: multiply-accumulates plus one per
+        output element for a bias, summed over DynamicConv2d (count_dynamic_convNd, slimmable_layers.py:186-206) and
+        DynamicGDN (count_gdn: a C x C 1x1 convolution with bias, :284-293); activations count nothing.  This is the
+        "FLOPs" the greedy complexity search ranks controller settings by (pgm_layers.py:816-825)."""
+        total, cin = 0, self.in_channels
+        for m in self.pgm_model:
+            if isinstance(m, DynamicConv2d):
+                cout, k, s, p = m.out_channels_at(level), m.kernel_size, m.stride, m.padding
+                if m.transposed:
+                    h, w = (h - 1) * s - 2 * p + k + (s - 1), (w - 1) * s - 2 * p + k + (s - 1)
+                else:
+                    h, w = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
+                total += batch * cout * h * w * (cin * k * k + (1 if m.conv.bias is not None else 0))
+                cin = cout
+            elif isinstance(m, DynamicGDN):
+                total += batch * cin * h * w * (cin + 1)
+        return total
+
+    def get_current_flops(self, input=None):
+        """total_ops of the last forward (pgm_layers.py:761-763)."""
+        return self.total_ops
+
     def forward(self, input, *args, pgm=None, input_mask=None, **kwargs):
         if input_mask is not None:
             raise NotImplementedError("input_mask")
         if pgm is not None and not isinstance(pgm, int) and pgm.dim() == 4 and pgm.shape[0] != 1:
             raise NotImplementedError("per-sample slim levels")
         level = self.level_of(pgm, self.num_levels())
+        self.total_ops = float(self.reference_ops(level, input.shape[0], input.shape[2], input.shape[3]))
         x = input
         for p in self.plans(level):
             x = p(x)

@@ -53,10 +53,14 @@ def topogroup_ar_codec(method="checkerboard", N=128, M=192, channel_groups=1, ex
 BASIC_WIDTHS = [48, 72, 96, 144, 192]
 
 
-def basic_codec(widths=BASIC_WIDTHS, M=192, num_complex_levels=8):
+def basic_codec(widths=BASIC_WIDTHS, M=192, num_complex_levels=8, search_dataset=None):
     """BaSIC "hyperprior-ar-sc-slimmable-full-dynamic" (configs/presets/lossy_latent_graph_scalable_ar_models.py:
     73-197): slimmable g_a/g_s, MS-slimmable h_a/h_s, 192-ch EntropyBottleneck, scanline AR y-coder with the
-    masked-conv context model, four slim controller nodes selected per complexity level."""
+    masked-conv context model, four slim controller nodes selected per complexity level.
+
+    ``search_dataset`` (iterable of image batches) = the "...-greedy-search-8level" variant (:733-757): the levels are
+    found by ``post_training_process`` (once weights are loaded and the codec sits on the GPU); without it a fixed
+    monotone ladder of controller settings is installed."""
     from .modules.prior_model.prior_coder.pgm_coder import (GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder,
                                                             TopoGroupDynamicMaskConv2dContextModel)
     from .nn.layers.param_generator import IndexSelectParameterGeneratorWrapper, NNParameterGenerator
@@ -91,12 +95,14 @@ def basic_codec(widths=BASIC_WIDTHS, M=192, num_complex_levels=8):
         latent_inference_input_mapping=dict(x_y={"pgmxy": "pgm"}, y_z={"pgmyz": "pgm"}),
         latent_generative_input_mapping=dict(y_x={"pgmyx": "pgm"}, z_y={"pgmzy": "pgm"}, y={"z": "prior"}),
         complexity_level_greedy_search=True, complexity_level_greedy_search_num_levels=num_complex_levels,
+        complexity_level_greedy_search_dataset=search_dataset, complexity_level_greedy_search_dataset_cached=True,
         complexity_level_controller_nodes=["pgmxy", "pgmyz", "pgmzy", "pgmyx"],
     )
-    # The searched levels need trained weights + a dataset (latent_graph.py:1397-1640, a "next" row); install a
-    # fixed monotone ladder of controller indices instead (index 0 = widest, n-1 = narrowest).
-    ladder = basic_default_ladder(n, num_complex_levels)
-    ec.set_complexity_level_params([{k: ec.node_generators[k](index=i) for k, i in lvl.items()} for lvl in ladder])
+    if search_dataset is None:
+        # Searched levels need trained weights + a dataset; without them install a fixed monotone ladder of
+        # controller indices (index 0 = widest, n-1 = narrowest).
+        ladder = basic_default_ladder(n, num_complex_levels)
+        ec.set_complexity_level_params([{k: ec.node_generators[k](index=i) for k, i in lvl.items()} for lvl in ladder])
     return GeneralCodec(entropy_coder=ec)
 
 

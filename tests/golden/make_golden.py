@@ -252,9 +252,97 @@ def harness():
             print("save_metrics not runnable here:", repr(e))
     save("harness.npz", **out)
 
+# ---------------------------------------------------------------- 8. greedy complexity-level search (latent_graph.py:1397-1640)
+def complexity_search():
+    """The reference's own post_training_process run on synthetic (FLOPs, loss) tables: the dataset evaluation
+    (_test_dataset_complexity_performance) is replaced by a table lookup, everything else (target FLOPs, candidate order,
+    tie breaking, level insertion, metric cache) is the reference's code.  Fixture = tables + selected levels + metric cache."""
+    import itertools
+    import logging
+    from cbench.modules.entropy_coder.latent_graph import LatentGraphicalANSEntropyCoder
+    from cbench.nn.layers.param_generator import IndexSelectParameterGeneratorWrapper, NNParameterGenerator
+    logging.disable(logging.CRITICAL)
+
+    def node(n):
+        return IndexSelectParameterGeneratorWrapper(
+            batched_generator=NNParameterGenerator(shape=(n, 1, 1, n), init_method="value",
+                                                   init_value=torch.eye(n).flip(-1).unsqueeze(1).unsqueeze(1), fix_params=True),
+            fix_for_inference=True)
+
+    cases = [  # (controller sizes, num_levels, custom constraint fractions of [min,max], table seed, loss noise)
+        (dict(pa=3, pb=4, pc=2), 5, None, 5, 0.5),
+        (dict(pgmxy=5, pgmyz=5, pgmzy=5, pgmyx=5), 8, None, 1, 0.05),
+        (dict(pgmxy=5, pgmyz=5, pgmzy=5, pgmyx=5), 8, None, 2, 3.0),
+        (dict(pa=4, pb=3), 4, None, 3, 0.0),           # ties in loss: the later candidate wins
+        (dict(pa=3, pb=3, pc=3), None, [0.9, 0.55, 0.3, 0.05], 4, 0.2),  # custom FLOPs constraints
+    ]
+    out = {"ncases": np.int64(len(cases))}
+    for ci, (sizes, nlev, custom, seed, noise) in enumerate(cases):
+        names, shape = list(sizes), tuple(sizes.values())
+        rng = np.random.default_rng(seed)
+        w = rng.uniform(1, 12, len(shape)).round(1)
+        flops, loss = np.zeros(shape), np.zeros(shape)
+        for t in itertools.product(*[range(n) for n in shape]):
+            c = float(sum(w[k] * (shape[k] - 1 - t[k]) for k in range(len(shape))))
+            flops[t] = 10 + c
+            loss[t] = 100.0 / (1 + c) + (rng.uniform(0, noise) if noise > 0 else 0.0)
+        if noise == 0.0:
+            loss = np.round(loss, 0)  # many exact ties
+        tmax, tmin = tuple(0 for _ in shape), tuple(n - 1 for n in shape)
+        loss[tmax], loss[tmin] = loss.min() - 1, loss.max() + 1
+        kw = dict(complexity_level_greedy_search_num_levels=nlev)
+        if custom is not None:
+            lo, hi = flops[tmin], flops[tmax]
+            kw = dict(complexity_level_greedy_search_custom_constraint=[float(lo + f * (hi - lo)) for f in custom])
+        ec = LatentGraphicalANSEntropyCoder(
+            node_generator_dict={k: node(n) for k, n in sizes.items()},
+            latent_node_inference_topo_order=["x"], latent_node_generative_topo_order=["x"],
+            complexity_level_greedy_search=True, complexity_level_greedy_search_dataset=[],
+            complexity_level_greedy_search_dataset_cached=True, complexity_level_controller_nodes=names, **kw)
+
+        def fake(dataset, *a, performance_method=None, complexity_method=None, **params):
+            t = tuple(int(sizes[k] - 1 - params[k].reshape(-1).argmax().item()) for k in names)
+            return float(flops[t]), float(loss[t])
+        ec._test_dataset_complexity_performance = fake
+        ec.update_state = lambda *a, **k: None
+        ec.post_training_process()
+        levels = []
+        for m in ec._complexity_param_all_levels:
+            d = m()
+            levels.append([int(sizes[k] - 1 - d[k].reshape(-1).argmax().item()) for k in names])
+        out[f"c{ci}_names"] = np.array(names)
+        out[f"c{ci}_sizes"] = np.array(shape)
+        out[f"c{ci}_num_levels"] = np.int64(-1 if nlev is None else nlev)
+        out[f"c{ci}_constraint"] = np.array(kw.get("complexity_level_greedy_search_custom_constraint", []), dtype=np.float64)
+        out[f"c{ci}_flops"], out[f"c{ci}_loss"] = flops, loss
+        out[f"c{ci}_levels"] = np.array(levels, dtype=np.int64)
+        out[f"c{ci}_metric_names"] = np.array(list(ec.complexity_metric_list))
+        out[f"c{ci}_metric_cache"] = ec._complexity_metric_list_cache.double().numpy()
+        print(ci, levels)
+    # FLOP counters of the reference's slimmable transforms (slimmable_layers.py:186-206,284-293 through
+    # pgm_layers.py:781-845): total_ops per width level on small zero inputs
+    from cbench.nn.layers import pgm_layers as P
+    W = [48, 72, 96, 144, 192]
+    mods = dict(
+        g_a=(P.HyperpriorAnalysisSlimmableConv2dPGMModel(in_channels=3, out_channels=192, mid_channels_list=W), (2, 3, 64, 64)),
+        h_a=(P.MeanScaleHyperpriorHyperAnalysisSlimmableConv2dPGMModel(in_channels=192, out_channels=192, mid_channels_list=W), (2, 192, 4, 4)),
+        h_s=(P.MeanScaleHyperpriorHyperSynthesisSlimmableConv2dPGMModel(in_channels=192, out_channels=384, mid_channels_list=W), (2, 192, 1, 1)),
+        g_s=(P.HyperpriorSynthesisSlimmableConv2dPGMModel(in_channels=192, out_channels=3, mid_channels_list=W), (2, 192, 4, 4)))
+    out["ops_widths"] = np.array(W)
+    for k, (m, shape) in mods.items():
+        m.eval()
+        row = []
+        for lvl in range(len(W)):
+            with torch.no_grad():
+                m(torch.zeros(shape), pgm=torch.eye(len(W))[lvl].reshape(1, 1, 1, len(W)))
+            row.append(float(m.get_current_flops()))
+        out[f"ops_{k}_shape"], out[f"ops_{k}"] = np.array(shape), np.array(row, dtype=np.float64)
+    logging.disable(logging.NOTSET)
+    save("complexity_search.npz", **out)
+
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["rans", "tables", "topo", "mconv", "ar", "framing", "harness"]
-    fn = dict(rans=rans_kats, tables=gauss_tables, topo=topo_maps, mconv=masked_conv, ar=ar_coder, framing=framing, harness=harness)
+    which = sys.argv[1:] or ["rans", "tables", "topo", "mconv", "ar", "framing", "harness", "search"]
+    fn = dict(rans=rans_kats, tables=gauss_tables, topo=topo_maps, mconv=masked_conv, ar=ar_coder, framing=framing, harness=harness, search=complexity_search)
     for w in which:
         fn[w]()

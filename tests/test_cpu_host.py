@@ -235,3 +235,48 @@ def test_benchmark_harness_formats(tmp_path):
     torch.manual_seed(2)
     want = torch.rand(3, 8, 8)
     assert torch.equal(rd[2], want) and [x.shape[0] for x in batched(rd, 2)] == [2, 1]
+
+
+def test_complexity_level_search_matches_reference_golden():
+    """Selection logic of post_training_process vs the reference's own method run on synthetic (FLOPs, loss) tables
+    (tests/golden/make_golden.py::complexity_search), and the reference's operation counters of the slimmable
+    transforms at every width level."""
+    import numpy as np
+    import torch
+    from cbench_basic_amd.modules.entropy_coder.complexity_search import search_complexity_levels
+    from cbench_basic_amd.modules.entropy_coder.latent_graph import ParamDictModuleWrapper
+    from cbench_basic_amd.nn.layers import pgm_layers as P
+    g = np.load(os.path.join(ROOT, "tests", "golden", "complexity_search.npz"))
+    for ci in range(int(g["ncases"])):
+        names = [str(x) for x in g[f"c{ci}_names"]]
+        sizes, F, L = g[f"c{ci}_sizes"], g[f"c{ci}_flops"], g[f"c{ci}_loss"]
+        nl, con = int(g[f"c{ci}_num_levels"]), [float(v) for v in g[f"c{ci}_constraint"]]
+        calls = []
+
+        def evaluate(idx):
+            t = tuple(idx[n] for n in names)
+            calls.append(t)
+            return float(F[t]), float(L[t])
+        r = search_complexity_levels(evaluate, names, {n: 0 for n in names}, {n: int(s) - 1 for n, s in zip(names, sizes)},
+                                     num_levels=None if nl < 0 else nl, custom_constraint=con or None)
+        got = np.array([[lv[n] for n in names] for lv in r.levels])
+        assert (got == g[f"c{ci}_levels"]).all(), (ci, got, g[f"c{ci}_levels"])
+        rows = np.array(r.metric_rows([str(x) for x in g[f"c{ci}_metric_names"]], "FLOPs", "loss"))
+        assert np.abs(rows.astype(np.float32) - g[f"c{ci}_metric_cache"].astype(np.float32)).max() == 0  # float32 buffer there
+        assert len(calls) == len(set(calls)) == int(np.prod(sizes))  # every setting evaluated exactly once
+    # degenerate configuration: the reference asserts "Complexity should be configured as 0 max!"
+    with pytest.raises(ValueError):
+        search_complexity_levels(lambda idx: (1.0, 1.0), ["a"], {"a": 0}, {"a": 2}, num_levels=3)
+
+    W = [int(v) for v in g["ops_widths"]]
+    mods = dict(g_a=P.HyperpriorAnalysisSlimmableConv2dPGMModel(in_channels=3, out_channels=192, mid_channels_list=W),
+                h_a=P.MeanScaleHyperpriorHyperAnalysisSlimmableConv2dPGMModel(in_channels=192, out_channels=192, mid_channels_list=W),
+                h_s=P.MeanScaleHyperpriorHyperSynthesisSlimmableConv2dPGMModel(in_channels=192, out_channels=384, mid_channels_list=W),
+                g_s=P.HyperpriorSynthesisSlimmableConv2dPGMModel(in_channels=192, out_channels=3, mid_channels_list=W))
+    for k, m in mods.items():
+        b, _, h, w = [int(v) for v in g[f"ops_{k}_shape"]]
+        got = np.array([m.reference_ops(lv, b, h, w) for lv in range(len(W))], dtype=np.float64)
+        assert (got == g[f"ops_{k}"]).all(), (k, got, g[f"ops_{k}"])
+
+    wrap = ParamDictModuleWrapper(dict(pgmxy=torch.eye(3)[1].reshape(1, 1, 3), nothing=None))
+    assert list(wrap.state_dict()) == ["pgmxy"] and wrap()["nothing"] is None and wrap()["pgmxy"].argmax().item() == 1

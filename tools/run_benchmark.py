@@ -31,6 +31,9 @@ def main():
     ap.add_argument("--complexity-levels", type=int, nargs="*", default=[])
     ap.add_argument("--rate-levels", type=int, nargs="*", default=[])
     ap.add_argument("--forward-pass", action="store_true", help="also record the forward-pass rate estimate")
+    ap.add_argument("--complexity-search", action="store_true",
+                    help="--codec basic: find the complexity levels with the greedy search over the test images "
+                         "(post_training_process) instead of the fixed ladder")
     ap.add_argument("--out", required=True)
     args = ap.parse_args()
     if not torch.cuda.is_available():
@@ -39,7 +42,13 @@ def main():
     from cbench_basic_amd import presets
     from cbench_basic_amd.benchmark import BasicLosslessCompressionBenchmark, PytorchBatchedDistortion
     from cbench_basic_amd.data import ImageFolderDataset, RandomImageDataset, batched
-    codec = dict(hyperprior=presets.hyperprior_codec, basic=presets.basic_codec,
+    if args.images:
+        ds = ImageFolderDataset(args.images)
+    else:
+        ds = RandomImageDataset(num=args.synthetic or 8, size=(3, args.size, args.size))
+    batches = list(batched(ds, args.batch_size))
+    codec = dict(hyperprior=presets.hyperprior_codec,
+                 basic=lambda: presets.basic_codec(search_dataset=batches if args.complexity_search else None),
                  topogroup=lambda: presets.topogroup_ar_codec(method=args.method))[args.codec]()
     if args.checkpoint:
         sd = torch.load(args.checkpoint, map_location="cpu")
@@ -50,11 +59,7 @@ def main():
     else:
         presets.seed_synthetic_weights(codec, seed=0)
     codec = codec.eval().to("cuda")
-    if args.images:
-        ds = ImageFolderDataset(args.images)
-    else:
-        ds = RandomImageDataset(num=args.synthetic or 8, size=(3, args.size, args.size))
-    bench = BasicLosslessCompressionBenchmark(codec, list(batched(ds, args.batch_size)),
+    bench = BasicLosslessCompressionBenchmark(codec, batches,
                                               distortion_metric=PytorchBatchedDistortion(),
                                               nn_codec_use_forward_pass=args.forward_pass,
                                               testing_complexity_levels=args.complexity_levels,
