@@ -169,7 +169,7 @@ class GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(HotPathModule):
                  use_param_merger=True, use_joint_ar_model_impl=False, param_merger_expand_bottleneck=False,
                  use_autoregressive_encode=True, use_bypass_coding=True, freq_precision=16, bypass_precision=4,
                  lower_bound_scale=0.11, quantizer_params=None, fixed_input_shape=None,
-                 force_input_prior_shape_aligned=True, batch_stream_mode="auto", **kwargs):
+                 force_input_prior_shape_aligned=True, batch_stream_mode="auto", topo_group_predictor=None, **kwargs):
         super().__init__()
         if use_joint_ar_model_impl:
             raise NotImplementedError("use_joint_ar_model_impl (pgm_coder.py:1975-2070) is a 'next' row (SURVEY 8f rank 4)")
@@ -210,6 +210,14 @@ class GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(HotPathModule):
                 mk = lambda i, o: TopoGroupDynamicMaskConv2d(i, o, 1, dynamic_channel_groups=G * 2, allow_same_topogroup_conv=True)
                 self.param_merger = nn.Sequential(mk(C2 * 2, bott), nn.LeakyReLU(inplace=True), mk(bott, bott),
                                                   nn.LeakyReLU(inplace=True), mk(bott, C2 * 2))
+        # learned topo groups (pgm_coder.py:1095-1103): at inference the reference reads the predictor's CACHED output
+        # (buffer ``topo_group_predictor_cache``, integer ids or logits [1, G_c * L, h, w]); the cache travels in the
+        # state_dict, so a tensor (or any module / callable producing one) is enough here
+        self.topo_group_predictor = topo_group_predictor if isinstance(topo_group_predictor, nn.Module) else None
+        if topo_group_predictor is not None:
+            with torch.no_grad():
+                cache = topo_group_predictor() if callable(topo_group_predictor) else topo_group_predictor
+            self.register_buffer("topo_group_predictor_cache", torch.as_tensor(cache).detach().clone())
         self.scale_table = get_scale_table()
         self._tables = None
         self._layers = None
@@ -271,11 +279,54 @@ class GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(HotPathModule):
                     L["m"].append((K.MaskedConvPlan(c.weight, c.bias, gi, G, True, act), "cat" if i == 0 else "pgm", "pgm"))
         return L
 
-    def _plan(self, h, w):
-        key = (h, w, str(self.device))
+    def _topo_from_pgm(self, pgm, h, w) -> np.ndarray:
+        """_preprocess_pgm in coding mode (pgm_coder.py:1340-1380, fast_mode=True): logits -> argmax over the last L
+        of each channel group's G_c * L channels; a map larger than the latent is trimmed, a smaller one is tiled
+        from the top-left corner (F.fold of whole patches: positions beyond the last whole patch stay group 0)."""
+        G = self.channel_groups
+        t = pgm.detach()
+        if t.dim() != 4:
+            raise ValueError("pgm must be [1, G_c (* L), h, w]")
+        if t.shape[0] != 1:
+            raise NotImplementedError("per-sample topo groups")
+        if torch.is_floating_point(t):
+            if t.shape[1] % G:
+                raise ValueError("logits channels must be a multiple of channel_groups")
+            t = t.reshape(1, G, t.shape[1] // G, t.shape[2], t.shape[3]).argmax(2)
+        if t.shape[1] != G:
+            raise ValueError(f"pgm has {t.shape[1]} channel groups, the coder {G}")
+        patch = t[0].cpu().numpy().astype(np.int64)[:, :h, :w]
+        ph, pw = patch.shape[1:]
+        if ph == h and pw == w:
+            return patch
+        topo = np.zeros((G, h, w), dtype=np.int64)
+        for i in range(h // ph):
+            for j in range(w // pw):
+                topo[:, i * ph:(i + 1) * ph, j * pw:(j + 1) * pw] = patch
+        return topo
+
+    def _plan(self, h, w, pgm=None):
+        if pgm is None and hasattr(self, "topo_group_predictor_cache"):
+            pgm = self.topo_group_predictor_cache              # eval path of _get_pgm (:1551)
+        if pgm is None:
+            key = (h, w, str(self.device))
+            if key not in self._plans:
+                topo = default_topo_groups(self.default_topo_group_method, self.channel_groups, h, w)
+                self._plans[key] = _GroupPlan(topo, self.in_channels, self.device)
+                self._plans[key].key = ("default",)
+            return self._plans[key]
+        ident = None
+        if pgm is getattr(self, "topo_group_predictor_cache", None):   # the module's own buffer: no D2H per call
+            ident = ("cache", pgm._version, h, w, str(self.device))
+            if ident in self._plans:
+                return self._plans[ident]
+        topo = self._topo_from_pgm(pgm, h, w)
+        key = (h, w, str(self.device), topo.tobytes())
         if key not in self._plans:
-            topo = default_topo_groups(self.default_topo_group_method, self.channel_groups, h, w)
             self._plans[key] = _GroupPlan(topo, self.in_channels, self.device)
+            self._plans[key].key = ("pgm", sum(1 for k in self._plans if len(k) == 4))
+        if ident is not None:
+            self._plans[ident] = self._plans[key]
         return self._plans[key]
 
     # ------------------------------------------------------------------ context model at one group's positions
@@ -334,12 +385,12 @@ class GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(HotPathModule):
     # per-group launch sequence is captured once per (batch, H, W) into a HIP graph and replayed.
     GRAPH_MIN_GROUPS = 8
 
-    def _run_encode(self, y, prior):
+    def _run_encode(self, y, prior, pgm=None):
         self._ready()
-        plan = self._plan(y.shape[2], y.shape[3])
+        plan = self._plan(y.shape[2], y.shape[3], pgm)
         if len(plan.groups) < self.GRAPH_MIN_GROUPS or not getattr(self, "use_hip_graphs", True):
-            return self._run_encode_impl(y, prior)
-        key = ("enc", tuple(y.shape), prior is not None)
+            return self._run_encode_impl(y, prior, plan)
+        key = ("enc", tuple(y.shape), prior is not None, plan.key)
         entry = self._graphs.get(key)
         if entry is None:
             sy = torch.empty_like(y)
@@ -347,11 +398,11 @@ class GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(HotPathModule):
             sy.copy_(y)
             if sp is not None:
                 sp.copy_(prior)
-            self._run_encode_impl(sy, sp)          # eager warm-up: builds position lists, sets kernel attributes
+            self._run_encode_impl(sy, sp, plan)    # eager warm-up: builds position lists, sets kernel attributes
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                out = self._run_encode_impl(sy, sp)
+                out = self._run_encode_impl(sy, sp, plan)
             entry = self._graphs[key] = (graph, sy, sp, out)
         graph, sy, sp, out = entry
         sy.copy_(y)
@@ -360,9 +411,8 @@ class GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(HotPathModule):
         graph.replay()
         return out
 
-    def _run_encode_impl(self, y, prior):
+    def _run_encode_impl(self, y, prior, plan):
         B, C, H, W = y.shape
-        plan = self._plan(H, W)
         ws = self._alloc(B, H, W, prior)
         n = plan.per_image
         sym = torch.empty((B, n), device=self.device, dtype=torch.int32)
@@ -384,14 +434,12 @@ class GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(HotPathModule):
         context model on round(y) (:421-429), likelihood cdf(q+.5) - cdf(q-.5) under N(mu, max(sigma, 0.11)),
         metric_dict["prior_entropy"] = -sum log(max(p, eps)) / batch (:374-389,:520-522)."""
         self._ready()
-        if pgm is not None:
-            raise NotImplementedError("externally supplied topo groups")
         input = input.contiguous()
         prior = self._check_prior(input.shape, prior)
         q = torch.round(input)
         if getattr(self, "estimate_rate", False):
             B, C, H, W = input.shape
-            plan = self._plan(H, W)
+            plan = self._plan(H, W, pgm)   # logits are taken at their argmax here too (the coding-mode groups)
             ws = self._alloc(B, H, W, prior)
             ws["ybuf"] = q
             allpos = torch.arange(B * H * W, device=self.device, dtype=torch.int32)
@@ -402,12 +450,10 @@ class GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(HotPathModule):
 
     def encode(self, input, *args, prior=None, pgm=None, quantizer_params=None, **kwargs) -> bytes:
         self._ready()
-        if pgm is not None:
-            raise NotImplementedError("externally supplied topo groups")
         input = input.contiguous()
         prior = self._check_prior(input.shape, prior)
         B = input.shape[0]
-        sym, idx, _, plan = self._run_encode(input, prior)
+        sym, idx, _, plan = self._run_encode(input, prior, pgm)
         n = plan.per_image
         if self._per_image(B):
             strings = self._tables.encode_batch_to_bytes(sym.reshape(-1), idx.reshape(-1), n)
@@ -429,8 +475,6 @@ class GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(HotPathModule):
 
     def decode(self, byte_string: bytes, *args, prior=None, pgm=None, quantizer_params=None, **kwargs):
         self._ready()
-        if pgm is not None:
-            raise NotImplementedError("externally supplied topo groups")
         ptr = 0
         if self.fixed_input_shape is not None:
             B, spatial = self.fixed_input_shape[0], tuple(self.fixed_input_shape[1:])
@@ -444,7 +488,7 @@ class GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(HotPathModule):
         H, W = spatial
         prior = self._check_prior((B, self.in_channels, H, W), prior)
         body = byte_string[ptr:]
-        plan = self._plan(H, W)
+        plan = self._plan(H, W, pgm)
         n, C = plan.per_image, self.in_channels
         per_image = self._per_image(B)
         if per_image:
@@ -468,10 +512,10 @@ class GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(HotPathModule):
         if not use_graph:
             d_words = torch.from_numpy(words_np.copy()).to(dev)
             d_woff = torch.from_numpy(woff).to(dev)
-            return self._run_decode_impl(d_words, d_woff, prior, B, H, W, per_image)
+            return self._run_decode_impl(d_words, d_woff, prior, B, H, W, per_image, plan)
         # static buffers: per-image streams never exceed the encoder's slot bound plus slack
         cap = B * (3 * n + 4)
-        key = ("dec", B, H, W, prior is not None)
+        key = ("dec", B, H, W, prior is not None, plan.key)
         entry = self._graphs.get(key)
         if entry is None:
             sw = torch.zeros((cap,), device=dev, dtype=torch.int32)
@@ -481,11 +525,11 @@ class GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(HotPathModule):
             so.copy_(torch.from_numpy(woff))
             if sp is not None:
                 sp.copy_(prior)
-            self._run_decode_impl(sw, so, sp, B, H, W, True)   # eager warm-up
+            self._run_decode_impl(sw, so, sp, B, H, W, True, plan)   # eager warm-up
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                out = self._run_decode_impl(sw, so, sp, B, H, W, True)
+                out = self._run_decode_impl(sw, so, sp, B, H, W, True, plan)
             entry = self._graphs[key] = (graph, sw, so, sp, out)
         graph, sw, so, sp, out = entry
         if words_np.size > cap:
@@ -497,9 +541,8 @@ class GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(HotPathModule):
         graph.replay()
         return out.clone()
 
-    def _run_decode_impl(self, d_words, d_woff, prior, B, H, W, per_image):
+    def _run_decode_impl(self, d_words, d_woff, prior, B, H, W, per_image, plan):
         dev, C = self.device, self.in_channels
-        plan = self._plan(H, W)
         n = plan.per_image
         ns = B if per_image else 1
         state = torch.zeros((ns,), device=dev, dtype=torch.int64)
@@ -532,3 +575,55 @@ class GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(HotPathModule):
             _lib.check(L.basic_pgm_gauss_scatter_group_dev(sym.data_ptr(), params.data_ptr(), B, C, H * W, grp["elems"].data_ptr(), ng,
                                                           n, grp["base"], ws["ybuf"].data_ptr(), K._stream()))
         return ws["ybuf"]
+
+
+class CombinedNNTrainablePGMPriorCoder(HotPathModule):
+    """pgm_coder.py:632-715: a bank of prior coders of which ``blend_weight`` (a one-hot from a controller node, e.g.
+    BaSIC's ``pgmy``) selects one per call -- the entropy-coder side of BaSIC's complexity scaling (scanline AR down to
+    2-stage grouped coders, configs/presets/lossy_latent_graph_scalable_ar_models.py:198-372)."""
+
+    def __init__(self, coders, *args, blend_weight_one_hot_threshold=0.9, fix_weight=False, training_use_max_capacity=False,
+                 **kwargs):
+        super().__init__()
+        self.coders = nn.ModuleList(coders)
+        if fix_weight:
+            self.register_buffer("default_blend_weight", torch.zeros(len(coders)), persistent=False)
+        else:
+            self.default_blend_weight = nn.Parameter(torch.zeros(len(coders)))
+        self.blend_weight_one_hot_threshold = blend_weight_one_hot_threshold
+        self.training_use_max_capacity = training_use_max_capacity
+
+    @property
+    def estimate_rate(self):
+        return all(getattr(c, "estimate_rate", False) for c in self.coders)
+
+    @estimate_rate.setter
+    def estimate_rate(self, value):
+        for c in self.coders:
+            if hasattr(c, "estimate_rate"):
+                c.estimate_rate = value
+
+    def _select(self, blend_weight):
+        if blend_weight is None:
+            blend_weight = torch.softmax(self.default_blend_weight, dim=0)
+        if isinstance(blend_weight, int):
+            return self.coders[blend_weight]
+        return self.coders[int(torch.as_tensor(blend_weight).reshape(-1).argmax().item())]
+
+    def forward(self, input, prior=None, blend_weight=None, **kwargs):
+        coder = self._select(blend_weight)
+        ret = coder(input, prior=prior, **kwargs)
+        pe = coder.get_raw_cache("metric_dict").pop("prior_entropy", None)   # (:697-699)
+        if pe is not None:
+            self.update_cache("metric_dict", prior_entropy=pe)
+        return ret
+
+    def encode(self, input, *args, prior=None, blend_weight=None, **kwargs) -> bytes:
+        return self._select(blend_weight).encode(input, prior=prior, **kwargs)
+
+    def decode(self, byte_string: bytes, *args, prior=None, blend_weight=None, **kwargs):
+        return self._select(blend_weight).decode(byte_string, prior=prior, **kwargs)
+
+    def update_state(self, *args, **kwargs) -> None:
+        for coder in self.coders:
+            coder.update_state(*args, **kwargs)

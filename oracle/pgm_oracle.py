@@ -124,13 +124,30 @@ def gaussian_ans_params(table, freq_precision=16):
     return f, np.array(nsym, np.int32), np.array(offs, np.int32)
 
 
+def topo_from_pgm(pgm, G, h, w):
+    """Coding-mode _preprocess_pgm (pgm_coder.py:1340-1380, fast_mode=True): float logits [1, G*L, ph, pw] ->
+    argmax over L; trim to the latent; tile whole patches with F.fold (stride = patch), so positions past the last
+    whole patch are group 0.  Returns int64 [1, G, h, w]."""
+    t = torch.as_tensor(pgm)
+    if torch.is_floating_point(t):
+        t = t.reshape(t.shape[0], G, t.shape[1] // G, *t.shape[2:]).movedim(2, -1).argmax(-1)
+    assert t.shape[0] == 1 and t.shape[1] == G
+    t = t[:, :, :h, :w].long()
+    ph, pw = t.shape[2:]
+    if ph < h or pw < w:
+        cols = t.reshape(1, -1, 1).repeat(1, 1, (h // ph) * (w // pw)).float()
+        t = F.fold(cols, (h, w), (ph, pw), stride=(ph, pw)).long()
+    return t
+
+
 class TopoGroupGaussianOracle:
     """GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder on the CPU, from a state_dict."""
 
     def __init__(self, sd, in_channels, channel_groups=1, method="none", expand_bottleneck=False, use_param_merger=True,
-                 context_model=False):
+                 context_model=False, pgm=None):
         self.sd = {k: v.detach().float().cpu() for k, v in sd.items()}
         self.C, self.method = in_channels, method
+        self.pgm = pgm  # supplied / learned topo groups (integer map or logits); None = the default pattern
         self.G = in_channels // 16 if method in ("elic", "channelwise-g10") else channel_groups
         self.use_param_merger, self.context_model = use_param_merger, context_model
         self.table = scale_table()
@@ -168,6 +185,11 @@ class TopoGroupGaussianOracle:
                 x = F.leaky_relu(x)
         return x.reshape(B, 2 * G, C2 // G, *buf.shape[2:])[:, :G].reshape(B, C2, *buf.shape[2:])
 
+    def _pgm(self, H, W):
+        if self.pgm is not None:
+            return topo_from_pgm(self.pgm, self.G, H, W)
+        return default_pgm(self.method, self.G, H, W)
+
     def _split(self, params):
         p = params.reshape(params.shape[0], params.shape[1] // 2, 2, *params.shape[2:])
         return p[:, :, 0], p[:, :, 1]  # split_interleave: mean, scale
@@ -183,7 +205,7 @@ class TopoGroupGaussianOracle:
     def forward_entropy(self, y, prior):
         """Eval forward's rate estimate (pgm_coder.py:391-429,374-389,520-522): nats per image."""
         B, C, H, W = y.shape
-        pgm = default_pgm(self.method, self.G, H, W)
+        pgm = self._pgm(H, W)
         q = torch.round(y)
         mean, scale = self._split(self._params(q, pgm, prior))
         dist = D.Normal(mean, torch.max(scale, torch.tensor([0.11])))
@@ -192,7 +214,7 @@ class TopoGroupGaussianOracle:
 
     def encode(self, y, prior):
         B, C, H, W = y.shape
-        pgm = default_pgm(self.method, self.G, H, W)
+        pgm = self._pgm(H, W)
         buf = torch.zeros_like(y)
         syms, idxs = [], []
         for mask in self.masks(pgm, y.shape):
@@ -209,7 +231,7 @@ class TopoGroupGaussianOracle:
 
     def decode(self, data, prior, shape):
         B, C, H, W = shape
-        pgm = default_pgm(self.method, self.G, H, W)
+        pgm = self._pgm(H, W)
         buf = torch.zeros(shape)
         self.dec.set_stream(data)
         for mask in self.masks(pgm, shape):

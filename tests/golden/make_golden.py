@@ -340,9 +340,107 @@ def complexity_search():
     logging.disable(logging.NOTSET)
     save("complexity_search.npz", **out)
 
+# ---------------------------------------------------------------- 9. AR coder with supplied / learned topo groups, combined coder
+def ar_coder_pgm():
+    """encode(..., pgm=...) with integer maps and logits (tiled / trimmed to the latent, pgm_coder.py:1340-1380), the
+    eval path of a topo_group_predictor (its cached output, :1551) and CombinedNNTrainablePGMPriorCoder (:632-715)."""
+    from cbench.modules.prior_model.prior_coder.pgm_coder import CombinedNNTrainablePGMPriorCoder
+
+    class FixedPredictor(torch.nn.Module):
+        def __init__(self, value):
+            super().__init__()
+            self.register_buffer("value", value)
+
+        def forward(self, *a, **k):
+            return self.value
+
+    def seeded(coder, seed):
+        names, shapes = [], []
+        torch.manual_seed(seed)
+        with torch.no_grad():
+            for name, p in coder.named_parameters():
+                p.copy_(torch.randn(p.shape) * (0.05 if p.dim() > 1 else 0.02))
+                names.append(name)
+                shapes.append(",".join(str(d) for d in p.shape))
+        return names, shapes
+
+    def inputs(seed, B, C, H, W):
+        gen = torch.Generator().manual_seed(seed)
+        y = torch.randn(B, C, H, W, generator=gen) * 3
+        prior = torch.cat([torch.randn(B, C, H, W, generator=gen), torch.rand(B, C, H, W, generator=gen) * 4 + 0.2], 1)
+        return y, prior.reshape(B, 2, C, H, W).transpose(1, 2).reshape(B, 2 * C, H, W).contiguous()
+
+    def spy(coder, captured):
+        orig = coder.ans_encoder
+
+        class Spy:
+            def encode_with_indexes(self, data, indexes, **k):
+                captured["symbols"], captured["indexes"] = np.array(data), np.array(indexes)
+                return orig.encode_with_indexes(data, indexes, **k)
+        coder.ans_encoder = Spy()
+
+    g = torch.Generator().manual_seed(77)
+    cases = [  # (C, G, ctx model, (B,H,W), pgm tensor or None, predictor tensor or None)
+        (16, 2, False, (1, 6, 6), torch.randint(0, 4, (1, 2, 2, 2), generator=g), None),          # int patch, tiled
+        (16, 1, False, (1, 5, 7), torch.randn(1, 4, 2, 2, generator=g), None),                    # logits, ragged tiling
+        (16, 1, True, (1, 4, 6), torch.randint(0, 6, (1, 1, 8, 8), generator=g), None),           # larger map, trimmed
+        (16, 2, False, (2, 4, 4), None, torch.randn(1, 2 * 3, 2, 2, generator=g)),                # predictor cache, B=2
+        (16, 4, False, (1, 4, 8), None, torch.randint(0, 8, (1, 4, 2, 2), generator=g)),          # integer predictor cache
+    ]
+    out, keys = {}, []
+    for i, (C, G, ctxm, (B, H, W), pgm, pred) in enumerate(cases):
+        kw = dict(in_channels=C, channel_groups=G)
+        if ctxm:
+            kw["topo_group_context_model"] = TopoGroupDynamicMaskConv2dContextModel(in_channels=C, out_channels=2 * C)
+        if pred is not None:
+            kw["topo_group_predictor"] = FixedPredictor(pred)
+        coder = GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(**kw).eval()
+        names, shapes = seeded(coder, 300 + i)
+        coder.update_state()
+        y, prior = inputs(400 + i, B, C, H, W)
+        cap = {}
+        spy(coder, cap)
+        with torch.no_grad():
+            data = coder.encode(y, prior=prior, pgm=pgm)
+            yhat = coder.decode(data, prior=prior, pgm=pgm)
+        k = f"p{i}"
+        src = pgm if pgm is not None else pred
+        out.update({f"{k}.pnames": np.array(names), f"{k}.pshapes": np.array(shapes),
+                    f"{k}.wsum": np.array([float(sum(p.double().sum() for p in coder.parameters()))]),
+                    f"{k}.y": y.numpy(), f"{k}.prior": prior.numpy(), f"{k}.bytes": b2a(data),
+                    f"{k}.symbols": cap["symbols"].astype(np.int32), f"{k}.indexes": cap["indexes"].astype(np.int32),
+                    f"{k}.yhat": yhat.numpy(), f"{k}.cfg": np.array([C, G, int(ctxm), B, H, W, int(pgm is None)]),
+                    f"{k}.pgm": src.numpy()})
+        keys.append(k)
+        print(f"  {k}: {len(data)} bytes, groups {int(cap['indexes'].size)}, max|yhat-y| {float((yhat - y).abs().max()):.3f}")
+    out["keys"] = np.array(keys)
+
+    # combined coder: sub-coder 0 = scanline + context model, sub-coder 1 = G=2 with an integer predictor cache
+    C, B, H, W = 16, 1, 4, 4
+    pred = torch.randint(0, 4, (1, 2, 2, 2), generator=g)
+    subs = [GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(
+                in_channels=C, default_topo_group_method="scanline",
+                topo_group_context_model=TopoGroupDynamicMaskConv2dContextModel(in_channels=C, out_channels=2 * C)),
+            GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(in_channels=C, channel_groups=2, topo_group_predictor=FixedPredictor(pred))]
+    comb = CombinedNNTrainablePGMPriorCoder(subs).eval()
+    names, shapes = seeded(comb, 390)
+    comb.update_state()
+    y, prior = inputs(490, B, C, H, W)
+    out.update({"comb.pnames": np.array(names), "comb.pshapes": np.array(shapes),
+                "comb.wsum": np.array([float(sum(p.double().sum() for p in comb.parameters()))]),
+                "comb.y": y.numpy(), "comb.prior": prior.numpy(), "comb.pred": pred.numpy()})
+    for sel in (0, 1):
+        bw = torch.eye(2)[sel]
+        with torch.no_grad():
+            data = comb.encode(y, prior=prior, blend_weight=bw)
+            yhat = comb.decode(data, prior=prior, blend_weight=bw)
+        out[f"comb.bytes{sel}"], out[f"comb.yhat{sel}"] = b2a(data), yhat.numpy()
+        print(f"  combined sel {sel}: {len(data)} bytes")
+    save("ar_coder_pgm.npz", **out)
+
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["rans", "tables", "topo", "mconv", "ar", "framing", "harness", "search"]
-    fn = dict(rans=rans_kats, tables=gauss_tables, topo=topo_maps, mconv=masked_conv, ar=ar_coder, framing=framing, harness=harness, search=complexity_search)
+    which = sys.argv[1:] or ["rans", "tables", "topo", "mconv", "ar", "framing", "harness", "search", "arpgm"]
+    fn = dict(rans=rans_kats, tables=gauss_tables, topo=topo_maps, mconv=masked_conv, ar=ar_coder, framing=framing, harness=harness, search=complexity_search, arpgm=ar_coder_pgm)
     for w in which:
         fn[w]()

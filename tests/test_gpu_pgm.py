@@ -104,3 +104,64 @@ def test_pgm_forward_rate_estimate():
         got = float(coder.get_raw_cache("metric_dict")["prior_entropy"])
         ref = float(oracle.forward_entropy(y, prior))
         assert abs(got - ref) <= 2e-3 * abs(ref), (k, got, ref)
+
+
+def test_supplied_and_learned_topo_groups_vs_reference_golden():
+    """encode/decode(..., pgm=) with integer maps and logits (tiled / trimmed), the cached output of a
+    topo_group_predictor, and CombinedNNTrainablePGMPriorCoder against the reference-generated fixture."""
+    from cbench_basic_amd.modules.prior_model.prior_coder.pgm_coder import (
+        CombinedNNTrainablePGMPriorCoder, GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder as Coder,
+        TopoGroupDynamicMaskConv2dContextModel as Ctx)
+    from test_oracle_golden import pgm_case
+    z = load("ar_coder_pgm.npz")
+    for k in z["keys"]:
+        sd = pgm_case(z, k, 300 + int(str(k)[1:]))
+        C, G, ctxm, B, H, W, from_pred = (int(v) for v in z[f"{k}.cfg"])
+        pgm = torch.from_numpy(z[f"{k}.pgm"])
+        kw = dict(in_channels=C, channel_groups=G, batch_stream_mode="reference")
+        if ctxm:
+            kw["topo_group_context_model"] = Ctx(in_channels=C, out_channels=2 * C)
+        if from_pred:
+            kw["topo_group_predictor"] = torch.zeros_like(pgm)   # the cache then arrives with the state_dict
+            sd["topo_group_predictor_cache"] = pgm
+        coder = Coder(**kw).eval()
+        missing, unexpected = coder.load_state_dict(sd, strict=False)
+        assert not unexpected and not [m for m in missing if not m.startswith("_")], (missing, unexpected)
+        coder = coder.cuda()
+        coder.update_state()
+        arg = None if from_pred else pgm.cuda()
+        y, prior = torch.from_numpy(z[f"{k}.y"]).cuda(), torch.from_numpy(z[f"{k}.prior"]).cuda()
+        sym, idx, ybuf, plan = coder._run_encode(y, prior, arg)
+        if B > 1:
+            sym = torch.cat([sym[:, g["base"]: g["base"] + g["n"]].reshape(-1) for g in plan.groups])
+            idx = torch.cat([idx[:, g["base"]: g["base"] + g["n"]].reshape(-1) for g in plan.groups])
+        sym, idx = sym.reshape(-1).cpu().numpy(), idx.reshape(-1).cpu().numpy()
+        ms, mi = int((sym != z[f"{k}.symbols"]).sum()), int((idx != z[f"{k}.indexes"]).sum())
+        print(f"{k}: symbol mismatches {ms}/{sym.size}, index mismatches {mi}/{idx.size}, {len(plan.groups)} groups")
+        assert ms <= 1 and mi <= 1, k
+        data = coder.encode(y, prior=prior, pgm=arg)
+        if ms == 0 and mi == 0:
+            assert data == z[f"{k}.bytes"].tobytes(), k
+        yhat = coder.decode(data, prior=prior, pgm=arg)
+        assert torch.equal(yhat.cpu(), ybuf.cpu()), k
+        yref = coder.decode(z[f"{k}.bytes"].tobytes(), prior=prior, pgm=arg)
+        assert float((yref.cpu() - torch.from_numpy(z[f"{k}.yhat"])).abs().max()) < 1e-3 or ms + mi > 0, k
+
+    sd = pgm_case(z, "comb", 390)
+    pred = torch.from_numpy(z["comb.pred"])
+    sd["coders.1.topo_group_predictor_cache"] = pred
+    comb = CombinedNNTrainablePGMPriorCoder([
+        Coder(in_channels=16, default_topo_group_method="scanline", topo_group_context_model=Ctx(in_channels=16, out_channels=32)),
+        Coder(in_channels=16, channel_groups=2, topo_group_predictor=torch.zeros_like(pred))]).eval()
+    missing, unexpected = comb.load_state_dict(sd, strict=False)
+    assert not unexpected and not [m for m in missing if "._" not in m and not m.startswith("_")], (missing, unexpected)
+    comb = comb.cuda()
+    comb.update_state()
+    y, prior = torch.from_numpy(z["comb.y"]).cuda(), torch.from_numpy(z["comb.prior"]).cuda()
+    for sel in (0, 1):
+        bw = torch.eye(2)[sel].cuda()
+        data = comb.encode(y, prior=prior, blend_weight=bw)
+        yhat = comb.decode(z[f"comb.bytes{sel}"].tobytes(), prior=prior, blend_weight=bw)
+        assert float((yhat.cpu() - torch.from_numpy(z[f"comb.yhat{sel}"])).abs().max()) < 1e-3, sel
+        assert data == z[f"comb.bytes{sel}"].tobytes() or abs(len(data) - z[f"comb.bytes{sel}"].size) <= 8, sel
+        print(f"combined sel {sel}: identical={data == z[f'comb.bytes{sel}'].tobytes()}")
