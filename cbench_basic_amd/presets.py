@@ -53,21 +53,53 @@ def topogroup_ar_codec(method="checkerboard", N=128, M=192, channel_groups=1, ex
 BASIC_WIDTHS = [48, 72, 96, 144, 192]
 
 
-def basic_codec(widths=BASIC_WIDTHS, M=192, num_complex_levels=8, search_dataset=None):
+def basic_codec(widths=BASIC_WIDTHS, M=192, num_complex_levels=8, search_dataset=None, combined_entropy_coder=False):
     """BaSIC "hyperprior-ar-sc-slimmable-full-dynamic" (configs/presets/lossy_latent_graph_scalable_ar_models.py:
     73-197): slimmable g_a/g_s, MS-slimmable h_a/h_s, 192-ch EntropyBottleneck, scanline AR y-coder with the
     masked-conv context model, four slim controller nodes selected per complexity level.
 
     ``search_dataset`` (iterable of image batches) = the "...-greedy-search-8level" variant (:733-757): the levels are
     found by ``post_training_process`` (once weights are loaded and the codec sits on the GPU); without it a fixed
-    monotone ladder of controller settings is installed."""
-    from .modules.prior_model.prior_coder.pgm_coder import (GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder,
+    monotone ladder of controller settings is installed.
+
+    ``combined_entropy_coder`` = the "...-combined-dynamic-entropy-coder" variant (:198-372): the y-coder is a bank
+    {scanline AR, 8-, 6-, 4-, 2-stage grouped coders with learned topo groups} selected by a fifth controller node
+    ``pgmy`` (blend_weight); the learned groups are the coders' ``topo_group_predictor_cache`` buffers (random logits
+    until a checkpoint is loaded)."""
+    from .modules.prior_model.prior_coder.pgm_coder import (CombinedNNTrainablePGMPriorCoder,
+                                                            GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder,
                                                             TopoGroupDynamicMaskConv2dContextModel)
     from .nn.layers.param_generator import IndexSelectParameterGeneratorWrapper, NNParameterGenerator
     from .nn.layers.pgm_layers import (HyperpriorAnalysisSlimmableConv2dPGMModel, HyperpriorSynthesisSlimmableConv2dPGMModel,
                                        MeanScaleHyperpriorHyperAnalysisSlimmableConv2dPGMModel,
                                        MeanScaleHyperpriorHyperSynthesisSlimmableConv2dPGMModel)
     n = len(widths)
+
+    def ar_coder(**kw):
+        return GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(
+            in_channels=M, topo_group_context_model=TopoGroupDynamicMaskConv2dContextModel(in_channels=M, out_channels=2 * M), **kw)
+
+    nodes = dict(pgmxy=None, pgmyx=None, pgmyz=None, pgmzy=None)
+    controllers = ["pgmxy", "pgmyz", "pgmzy", "pgmyx"]
+    y_mapping = {"z": "prior"}
+    if combined_entropy_coder:
+        g = torch.Generator().manual_seed(1234)
+        logits = lambda G, L: torch.randn(1, G * L, 2, 2, generator=g)   # predictor output: out_channels = G * L, 2 x 2 patch
+        y_coder = CombinedNNTrainablePGMPriorCoder([
+            ar_coder(default_topo_group_method="scanline"),
+            ar_coder(channel_groups=4, topo_group_predictor=logits(4, 8)),    # 8-stage (:270-289)
+            ar_coder(channel_groups=4, topo_group_predictor=logits(4, 6)),    # 6-stage
+            ar_coder(topo_group_predictor=logits(1, 16)),                      # 4-stage (channel_groups 1, 16 logits)
+            ar_coder(channel_groups=2, param_merger_expand_bottleneck=True, topo_group_predictor=logits(2, 2)),  # 2-stage
+        ], training_use_max_capacity=True)
+        nb = len(y_coder.coders)
+        nodes["pgmy"] = IndexSelectParameterGeneratorWrapper(
+            batched_generator=NNParameterGenerator(shape=(nb, nb), init_method="value", init_value=torch.eye(nb), fix_params=True),
+            fix_for_inference=True)
+        controllers.append("pgmy")
+        y_mapping = {"pgmy": "blend_weight", "z": "prior"}
+    else:
+        y_coder = ar_coder(default_topo_group_method="scanline")
 
     def slim_node():
         return IndexSelectParameterGeneratorWrapper(
@@ -76,14 +108,12 @@ def basic_codec(widths=BASIC_WIDTHS, M=192, num_complex_levels=8, search_dataset
             fix_for_inference=True)
 
     ec = LatentGraphicalANSEntropyCoder(
-        node_generator_dict=dict(pgmxy=slim_node(), pgmyx=slim_node(), pgmyz=slim_node(), pgmzy=slim_node()),
+        node_generator_dict={k: (v if v is not None else slim_node()) for k, v in nodes.items()},
         use_lossy_compression=True, lossy_compression_lambda_rd=145.2225,
         latent_node_inference_topo_order=["x", "y", "z"],
         latent_node_generative_topo_order=["z", "y", "x"],
         latent_node_entropy_coder_dict=dict(
-            y=GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(
-                in_channels=M, default_topo_group_method="scanline",
-                topo_group_context_model=TopoGroupDynamicMaskConv2dContextModel(in_channels=M, out_channels=2 * M)),
+            y=y_coder,
             z=CompressAIEntropyBottleneckPriorCoder(entropy_bottleneck_channels=M, use_inner_aux_opt=True),
         ),
         latent_inference_dict=dict(
@@ -93,21 +123,25 @@ def basic_codec(widths=BASIC_WIDTHS, M=192, num_complex_levels=8, search_dataset
             z_y=MeanScaleHyperpriorHyperSynthesisSlimmableConv2dPGMModel(in_channels=M, out_channels=2 * M, mid_channels_list=widths),
             y_x=HyperpriorSynthesisSlimmableConv2dPGMModel(in_channels=M, out_channels=3, mid_channels_list=widths)),
         latent_inference_input_mapping=dict(x_y={"pgmxy": "pgm"}, y_z={"pgmyz": "pgm"}),
-        latent_generative_input_mapping=dict(y_x={"pgmyx": "pgm"}, z_y={"pgmzy": "pgm"}, y={"z": "prior"}),
+        latent_generative_input_mapping=dict(y_x={"pgmyx": "pgm"}, z_y={"pgmzy": "pgm"}, y=y_mapping),
         complexity_level_greedy_search=True, complexity_level_greedy_search_num_levels=num_complex_levels,
         complexity_level_greedy_search_dataset=search_dataset, complexity_level_greedy_search_dataset_cached=True,
-        complexity_level_controller_nodes=["pgmxy", "pgmyz", "pgmzy", "pgmyx"],
+        complexity_level_controller_nodes=controllers,
     )
     if search_dataset is None:
         # Searched levels need trained weights + a dataset; without them install a fixed monotone ladder of
         # controller indices (index 0 = widest, n-1 = narrowest).
         ladder = basic_default_ladder(n, num_complex_levels)
+        if combined_entropy_coder:  # entropy-coder stage count falls with the level too: scanline ... 2-stage
+            for i, lvl in enumerate(ladder):
+                lvl["pgmy"] = round(i * (nb - 1) / max(1, num_complex_levels - 1))
         ec.set_complexity_level_params([{k: ec.node_generators[k](index=i) for k, i in lvl.items()} for lvl in ladder])
     return GeneralCodec(entropy_coder=ec)
 
 
 def basic_default_ladder(n_widths, num_levels):
-    """num_levels index tuples from all-narrow to all-wide, widening one controller at a time."""
+    """num_levels index tuples; level 0 = all-wide (most complex, the reference's convention for searched levels,
+    latent_graph.py:1527), last level = all-narrow, narrowing one controller at a time in between."""
     names = ["pgmyx", "pgmxy", "pgmzy", "pgmyz"]
     cur = {k: n_widths - 1 for k in names}
     steps = [dict(cur)]
@@ -117,7 +151,7 @@ def basic_default_ladder(n_widths, num_levels):
                 cur[k] -= 1
                 steps.append(dict(cur))
     pick = [round(i * (len(steps) - 1) / max(1, num_levels - 1)) for i in range(num_levels)]
-    return [steps[i] for i in pick]
+    return [dict(steps[i]) for i in reversed(pick)]
 
 
 def seed_synthetic_weights(codec, seed=0, y_std=0.5):

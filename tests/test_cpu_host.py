@@ -135,7 +135,7 @@ def test_default_ladder_and_node_generators():
     from cbench_basic_amd.presets import basic_default_ladder
     from cbench_basic_amd.nn.layers.param_generator import IndexSelectParameterGeneratorWrapper, NNParameterGenerator
     lad = basic_default_ladder(5, 8)
-    assert len(lad) == 8 and lad[0] == dict(pgmyx=4, pgmxy=4, pgmzy=4, pgmyz=4) and all(v == 0 for v in lad[-1].values())
+    assert len(lad) == 8 and lad[-1] == dict(pgmyx=4, pgmxy=4, pgmzy=4, pgmyz=4) and all(v == 0 for v in lad[0].values())
     gen = IndexSelectParameterGeneratorWrapper(
         NNParameterGenerator((5, 1, 1, 5), init_method="value", init_value=torch.eye(5).flip(-1).unsqueeze(1).unsqueeze(1), fix_params=True),
         fix_for_inference=True).eval()

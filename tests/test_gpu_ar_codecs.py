@@ -171,3 +171,44 @@ def test_basic_complexity_level_search():
     fresh.set_complex_level(1)
     codec.set_complex_level(1)
     assert fresh.compress(x) == codec.compress(x)
+
+
+def test_basic_combined_entropy_coder_levels():
+    """BaSIC "combined dynamic entropy coder" graph (lossy_latent_graph_scalable_ar_models.py:198-372): controller node
+    pgmy picks the y-coder (scanline AR ... 2-stage learned groups); every choice is byte-checked against the CPU oracle
+    with the same sub-coder weights and the same learned-group cache."""
+    from cbench_basic_amd.presets import basic_codec
+    from oracle.codec_oracle import BasicCodecOracle, psnr
+    from oracle.pgm_oracle import TopoGroupGaussianOracle
+    widths, M = [24, 48], 48  # merger widths 160 / 128 divide into 4 channel groups
+    codec = _rand_params(basic_codec(widths=widths, M=M, num_complex_levels=5, combined_entropy_coder=True), 13).eval()
+    ec = codec.entropy_coder
+    sd = ec.state_dict()
+    oracle = BasicCodecOracle(sd, widths, M=M)
+    codec = codec.cuda()
+    codec.update_state()
+    torch.manual_seed(8)
+    x = torch.rand(1, 3, 64, 128)
+    cfgs = [dict(method="scanline"), dict(G=4), dict(G=4), dict(G=1), dict(G=2, expand=True)]
+    seen = set()
+    for level in range(5):
+        codec.set_complex_level(level)
+        params = ec._complexity_param_all_levels[level]()
+        sel = int(params["pgmy"].argmax().item())
+        seen.add(sel)
+        pre = f"latent_node_entropy_coders.y.coders.{sel}."
+        sub = {k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)}
+        c = cfgs[sel]
+        oracle.y = TopoGroupGaussianOracle(sub, M, c.get("G", 1), c.get("method", "none"), c.get("expand", False), context_model=True,
+                                           pgm=sub.get("topo_group_predictor_cache"))
+        # one-hot position = width level (the controller's eye.flip rows: index i -> level n-1-i)
+        oracle.set_levels(xy=int(params["pgmxy"].reshape(-1).argmax()), yz=int(params["pgmyz"].reshape(-1).argmax()),
+                          zy=int(params["pgmzy"].reshape(-1).argmax()), yx=int(params["pgmyx"].reshape(-1).argmax()))
+        data = codec.compress(x)
+        ref = oracle.compress(x)
+        xhat = codec.decompress(data).cpu()
+        print(f"level {level} (y-coder {sel}): {len(data)} B vs oracle {len(ref)} B identical={data == ref}")
+        assert abs(len(data) - len(ref)) <= 16
+        assert float((oracle.decompress(data) - xhat).abs().max()) < 1e-3
+        assert float((psnr(xhat, x) - psnr(oracle.decompress(ref), x)).abs().max()) < 0.01
+    assert seen == {0, 1, 2, 3, 4}
