@@ -33,3 +33,21 @@ if which in ("all", "basic"):
     for lvl in (0, 7):
         c.set_complex_level(lvl)
         run(f"BaSIC scanline level {lvl}", c, 64)
+if which in ("all", "combined"):
+    c = prep(basic_codec(combined_entropy_coder=True))
+    for lvl in range(8):
+        c.set_complex_level(lvl)
+        sel = int(c.entropy_coder._complexity_param_all_levels[lvl]()["pgmy"].argmax())
+        run(f"BaSIC combined level {lvl} (y-coder {sel})", c, 64)
+if which in ("all", "search"):
+    # cost of ONE controller setting of the complexity search on a Kodak-shaped set (24 x 3x512x768, batch 1);
+    # the full product search of the preset evaluates 5^4 = 625 of them
+    c = prep(basic_codec())
+    ec = c.entropy_coder
+    data = [torch.rand(1, 3, 512, 768, generator=torch.Generator().manual_seed(i)) for i in range(24)]
+    setting = {n: ec.node_generators[n](0) for n in ec.complexity_level_controller_nodes}
+    ec._test_dataset_complexity_performance(data[:2], **setting)
+    torch.cuda.synchronize(); t0 = time.time()
+    flops, loss = ec._test_dataset_complexity_performance(data, **setting)
+    torch.cuda.synchronize(); dt = time.time() - t0
+    print(f"complexity search: one setting over 24 Kodak-shaped images {dt*1e3:.1f} ms (FLOPs/dim {flops:.1f}, loss/dim {loss:.4f}); x625 = {dt*625:.0f} s")
