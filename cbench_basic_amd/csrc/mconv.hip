@@ -14,14 +14,20 @@
 // slab is skipped when its mask is empty for all 32 positions of the wave -- for causal
 // patterns that removes most of the K loop.
 //
-// Mapping: one workgroup (4 wavefronts) = one 32-row tile of ONE output channel group x 32 listed positions;
-// the K loop of every unmasked (tap, input group) slab is split over the 4 waves and unrolled so that several
-// fragment loads are in flight per L2 round trip (tiny launches -- scanline groups -- are latency bound).
-// A fragments are coalesced 128-byte rows of the packed weights [tap][ci][co]; B fragments are
-// gathered from x with the mask applied as a select (so masked garbage, even NaN, never enters
-// the sum -- the reference multiplies by 0 instead, which only differs for non-finite data).
+// Mapping, large launches (masked_conv_pos_kernel<1, MT>): one wavefront = MT 32-row tiles of ONE output channel
+// group x 32 listed positions.  The B fragment (gathered activations, mask applied) is loaded once and feeds MT MFMAs,
+// and the activations are re-read Cout / (32 MT) times instead of Cout / 32 times -- with one tile per wave the widest
+// merger layer (1536 -> 1536 on 32k positions) moved 9.6 GB per launch and ran at 0.37 of the MFMA peak.  The weights
+// are packed so that a lane's MT A values are adjacent: [tap][ci][chunk][32 rows][MT] (one 8- / 16-byte load for MT 2 / 4).
+// Tiny launches (a scanline group is one position per image) are latency bound: masked_conv_pos_kernel<4, 1> gives a
+// tile to one workgroup of 4 waves which split the K loop and sum through LDS.
+// Every output element accumulates the same products in the same order for every MT, and the variant is a function of
+// the plan and the position count only, so encoder and decoder agree bit for bit (the split-K variant sums its four
+// K-slices in a fixed order, which rounds differently from the single-wave sum).  B fragments are gathered from x with the mask applied as a select (so masked
+// garbage, even NaN, never enters the sum -- the reference multiplies by 0, which only differs for non-finite data).
 #include "common.h"
 
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -43,23 +49,46 @@ struct MaskedLaunch {
     int64_t n_pos;
     int batch, cin, cout, coutp, h, w_, gi, go, gs_in, gs_out, tiles_per_group;
     int out_total, out_off, ntaps, pad, ksize, allow_same, act;
+    int mt;                // pack factor of w: row r of a group sits at (r / (32 mt)) * 32 mt + (r % 32) * mt + (r / 32) % mt
 };
 
 constexpr int kUnroll = 4;  // channel pairs whose loads are issued together (one L2 round trip per 4 MFMAs)
 
 // kWaves > 1: K is split over the waves of a workgroup and the partial tiles are summed through LDS -- for tiny
 // launches (a scanline group is 1 position per image) where one wave per tile would leave the chip idle.
-template <int kWaves>
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// a lane's MT adjacent A values (8- / 16-byte aligned for MT = 2 / 4 by construction of the packing)
+template <int MT> __device__ inline void load_a(const float *p, bool ok, float (&a)[MT])
+{
+    if (MT == 4) {
+        const f32x4 v = ok ? *reinterpret_cast<const f32x4 *>(p) : f32x4(0.f);
+        a[0] = v[0]; a[1 % MT] = v[1]; a[2 % MT] = v[2]; a[3 % MT] = v[3];
+    } else if (MT == 2) {
+        const f32x2 v = ok ? *reinterpret_cast<const f32x2 *>(p) : f32x2(0.f);
+        a[0] = v[0]; a[1 % MT] = v[1];
+    } else {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) a[m] = ok ? p[m] : 0.f;
+    }
+}
+
+// kWaves > 1 (MT == 1): K is split over the waves of a workgroup and the partial tiles are summed through LDS -- for tiny
+// launches (a scanline group is 1 position per image) where one wave per tile would leave the chip idle.
+// kWaves == 1: one wave computes MT row tiles (the weights' pack factor g.mt == MT).
+template <int kWaves, int MT>
 __global__ __launch_bounds__(64 * kWaves) void masked_conv_pos_kernel(const MaskedLaunch g)
 {
+    static_assert(kWaves == 1 || MT == 1, "split-K variant handles one tile per workgroup");
     __shared__ float partial[kWaves > 1 ? kWaves - 1 : 1][16][64];
     const int tid = threadIdx.x, wave = tid >> 6;
     const int lane = tid & 63, col = lane & 31, khalf = lane >> 5;
-    const int tile = blockIdx.y;
-    const int grp_o = tile / g.tiles_per_group, ti = tile - grp_o * g.tiles_per_group;
-    const int row_in_group = ti * 32 + col;                 // A-fragment row of this lane
-    const bool row_ok = row_in_group < g.gs_out;
-    const int co_a = grp_o * g.gs_out + row_in_group;       // output channel of the A row
+    const int chunks_per_group = g.tiles_per_group / MT;       // host guarantees divisibility when MT > 1
+    const int grp_o = blockIdx.y / chunks_per_group, ti0 = (blockIdx.y - grp_o * chunks_per_group) * MT;
+    const bool row_ok = ti0 * 32 + col < g.gs_out || MT > 1;  // MT > 1 only with whole tiles (gs_out % (32 MT) == 0)
+    // packed position of this lane's A value(s): see MaskedLaunch::mt
+    const int a_off = grp_o * g.gs_out + (ti0 / g.mt) * 32 * g.mt + col * g.mt + (ti0 % g.mt);
 
     const int64_t pj = static_cast<int64_t>(blockIdx.x) * 32 + col;
     const bool pos_ok = pj < g.n_pos;
@@ -75,9 +104,11 @@ __global__ __launch_bounds__(64 * kWaves) void masked_conv_pos_kernel(const Mask
     const int32_t centre = pos_ok ? g.topo_out[grp_o * hw + py * g.w_ + px] : 0;
     const float *xb = g.x + static_cast<int64_t>(b) * g.cin * hw;
 
-    f32x16 acc;
+    f32x16 acc[MT];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
 
     for (int t = 0; t < g.ntaps; ++t) {
         const int dy = t / g.ksize - g.pad, dx = t % g.ksize - g.pad;
@@ -92,19 +123,22 @@ __global__ __launch_bounds__(64 * kWaves) void masked_conv_pos_kernel(const Mask
             }
             if (__ballot(open) == 0ull) continue;  // wave-uniform skip of an all-masked slab (same in every wave)
             const int c_beg = gin * g.gs_in, c_end = c_beg + g.gs_in;
-            const float *wt = g.w + (static_cast<int64_t>(t) * g.cin) * g.coutp + co_a;
+            const float *wt = g.w + (static_cast<int64_t>(t) * g.cin) * g.coutp + a_off;
             // this wave's share of the slab: channel pairs wave, wave + kWaves, ...; kUnroll pairs per round trip
             for (int c = c_beg + 2 * wave; c < c_end; c += 2 * kWaves * kUnroll) {
-                float af[kUnroll], bf[kUnroll];
+                float af[kUnroll][MT], bf[kUnroll];
 #pragma unroll
                 for (int u = 0; u < kUnroll; ++u) {
                     const int ci = c + u * 2 * kWaves + khalf;
                     const bool ci_ok = ci < c_end;
-                    af[u] = (row_ok && ci_ok) ? wt[static_cast<int64_t>(ci) * g.coutp] : 0.f;
+                    load_a<MT>(wt + static_cast<int64_t>(ci) * g.coutp, row_ok && ci_ok, af[u]);
                     bf[u] = (open && ci_ok) ? xb[static_cast<int64_t>(ci) * hw + noff] : 0.f;
                 }
 #pragma unroll
-                for (int u = 0; u < kUnroll; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[u], bf[u], acc, 0, 0, 0);
+                for (int u = 0; u < kUnroll; ++u)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+                        acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[u][m], bf[u], acc[m], 0, 0, 0);
             }
         }
     }
@@ -113,7 +147,7 @@ __global__ __launch_bounds__(64 * kWaves) void masked_conv_pos_kernel(const Mask
     if (kWaves > 1) {
         if (wave > 0) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) partial[wave - 1][r][lane] = acc[r];
+            for (int r = 0; r < 16; ++r) partial[wave - 1][r][lane] = acc[0][r];
         }
         __syncthreads();
     }
@@ -121,20 +155,22 @@ __global__ __launch_bounds__(64 * kWaves) void masked_conv_pos_kernel(const Mask
 #pragma unroll
         for (int w = 0; w < kWaves - 1; ++w)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] += partial[w][r][lane];
+            for (int r = 0; r < 16; ++r) acc[0][r] += partial[w][r][lane];
         if (pos_ok) {
             float *yb = g.y + (static_cast<int64_t>(b) * g.out_total + g.out_off) * hw + py * g.w_ + px;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rg = ti * 32 + 8 * (r >> 2) + 4 * khalf + (r & 3);
-                if (rg < g.gs_out) {
-                    const int co = grp_o * g.gs_out + rg;
-                    float v = acc[r] + g.bias[co];
-                    if (g.act == BASIC_ACT_LEAKY_RELU) v = v > 0.f ? v : 0.01f * v;
-                    else if (g.act == BASIC_ACT_RELU) v = v > 0.f ? v : 0.f;
-                    yb[static_cast<int64_t>(co) * hw] = v;
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rg = (ti0 + m) * 32 + 8 * (r >> 2) + 4 * khalf + (r & 3);
+                    if (rg < g.gs_out) {
+                        const int co = grp_o * g.gs_out + rg;
+                        float v = acc[m][r] + g.bias[co];
+                        if (g.act == BASIC_ACT_LEAKY_RELU) v = v > 0.f ? v : 0.01f * v;
+                        else if (g.act == BASIC_ACT_RELU) v = v > 0.f ? v : 0.f;
+                        yb[static_cast<int64_t>(co) * hw] = v;
+                    }
                 }
-            }
         }
     }
 }
@@ -143,6 +179,8 @@ __global__ __launch_bounds__(64 * kWaves) void masked_conv_pos_kernel(const Mask
 
 struct basic_mconv_plan {
     int cin = 0, cout = 0, coutp = 0, ksize = 1, gi = 1, go = 1, allow_same = 0, act = 0;
+    int mt = 1;  // row tiles per wave of the large-launch kernel = pack factor of d_w
+    float *d_w1 = nullptr;  // plain [tap][ci][co] copy for the split-K kernel when mt > 1 (coalesced 128-byte A rows)
     float *d_w = nullptr, *d_bias = nullptr;
 };
 
@@ -150,6 +188,7 @@ extern "C" void basic_mconv_plan_destroy(basic_mconv_plan *p)
 {
     if (!p) return;
     if (p->d_w) (void)hipFree(p->d_w);
+    if (p->d_w1) (void)hipFree(p->d_w1);
     if (p->d_bias) (void)hipFree(p->d_bias);
     delete p;
 }
@@ -171,14 +210,33 @@ extern "C" int basic_mconv_plan_create(const float *weight, const float *bias, i
     p->cin = cin; p->cout = cout; p->coutp = (cout + 3) / 4 * 4; p->ksize = ksize;
     p->gi = in_groups; p->go = out_groups; p->allow_same = allow_same_topogroup ? 1 : 0; p->act = activation;
     const int ntaps = ksize * ksize;
+    const int gs_out = cout / out_groups;
+    p->mt = 1;                                                   // row tiles per wave: whole 32-row tiles only
+    if (gs_out % 32 == 0) {
+        const int tiles = gs_out / 32;
+        p->mt = tiles <= 5 ? tiles : tiles % 4 == 0 ? 4 : tiles % 3 == 0 ? 3 : tiles % 5 == 0 ? 5 : tiles % 2 == 0 ? 2 : 1;
+    }
+    if (const char *e = std::getenv("BASIC_MCONV_MAX_MT")) {  // tests: one tile per wave as the comparison point
+        if (p->mt > std::atoi(e)) p->mt = 1;
+    }
+    const int span = 32 * p->mt;
     std::vector<float> wp(static_cast<size_t>(ntaps) * cin * p->coutp, 0.f), hb(p->coutp, 0.f);
-    for (int o = 0; o < cout; ++o)
+    std::vector<float> w1(p->mt > 1 ? wp.size() : 0, 0.f);
+    for (int o = 0; o < cout; ++o) {
+        const int grp = o / gs_out, r = o - grp * gs_out;
+        const int packed = grp * gs_out + (r / span) * span + (r % 32) * p->mt + (r / 32) % p->mt;
         for (int c = 0; c < cin; ++c)
-            for (int t = 0; t < ntaps; ++t)
-                wp[(static_cast<size_t>(t) * cin + c) * p->coutp + o] = weight[(static_cast<size_t>(o) * cin + c) * ntaps + t];
+            for (int t = 0; t < ntaps; ++t) {
+                const float v = weight[(static_cast<size_t>(o) * cin + c) * ntaps + t];
+                wp[(static_cast<size_t>(t) * cin + c) * p->coutp + packed] = v;
+                if (p->mt > 1) w1[(static_cast<size_t>(t) * cin + c) * p->coutp + o] = v;
+            }
+    }
     if (bias) std::memcpy(hb.data(), bias, sizeof(float) * cout);
     hipError_t e = hipMalloc(&p->d_w, wp.size() * sizeof(float));
     if (e == hipSuccess) e = hipMemcpy(p->d_w, wp.data(), wp.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess && p->mt > 1) e = hipMalloc(&p->d_w1, w1.size() * sizeof(float));
+    if (e == hipSuccess && p->mt > 1) e = hipMemcpy(p->d_w1, w1.data(), w1.size() * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc(&p->d_bias, hb.size() * sizeof(float));
     if (e == hipSuccess) e = hipMemcpy(p->d_bias, hb.data(), hb.size() * sizeof(float), hipMemcpyHostToDevice);
     if (e != hipSuccess) { basic_mconv_plan_destroy(p); return hip_fail(e, "mconv_plan_create", __FILE__, __LINE__); }
@@ -204,12 +262,27 @@ extern "C" int basic_mconv_forward_pos_dev(const basic_mconv_plan *p, const floa
     g.tiles_per_group = (g.gs_out + 31) / 32;
     g.out_total = out_channels_total; g.out_off = out_channel_offset;
     g.ntaps = p->ksize * p->ksize; g.pad = p->ksize / 2; g.ksize = p->ksize; g.allow_same = p->allow_same; g.act = p->act;
-    const dim3 grid(static_cast<unsigned>((n_pos + 31) / 32), static_cast<unsigned>(g.tiles_per_group * g.go));
-    // few tiles -> split K over 4 waves per tile; many tiles -> one wave per tile already fills the chip
-    if (static_cast<int64_t>(grid.x) * grid.y < 4096)
-        hipLaunchKernelGGL(masked_conv_pos_kernel<4>, grid, dim3(256), 0, as_stream(hip_stream), g);
+    g.mt = p->mt;
+    const unsigned ptiles = static_cast<unsigned>((n_pos + 31) / 32), rtiles = static_cast<unsigned>(g.tiles_per_group * g.go);
+    hipStream_t st = as_stream(hip_stream);
+    // few tiles -> split K over 4 waves per tile; many tiles -> one wave per MT row tiles already fills the chip
+    // (BASIC_MCONV_SPLITK_BELOW moves the switch-over: tests drive both variants over the same inputs)
+    int64_t split_below = 4096;
+    if (const char *e = std::getenv("BASIC_MCONV_SPLITK_BELOW")) split_below = std::atoll(e);
+    if (static_cast<int64_t>(ptiles) * rtiles < split_below) {
+        if (p->mt > 1) { g.w = p->d_w1; g.mt = 1; }
+        hipLaunchKernelGGL((masked_conv_pos_kernel<4, 1>), dim3(ptiles, rtiles), dim3(256), 0, st, g);
+    }
+    else if (p->mt == 5)
+        hipLaunchKernelGGL((masked_conv_pos_kernel<1, 5>), dim3(ptiles, rtiles / 5), dim3(64), 0, st, g);
+    else if (p->mt == 4)
+        hipLaunchKernelGGL((masked_conv_pos_kernel<1, 4>), dim3(ptiles, rtiles / 4), dim3(64), 0, st, g);
+    else if (p->mt == 3)
+        hipLaunchKernelGGL((masked_conv_pos_kernel<1, 3>), dim3(ptiles, rtiles / 3), dim3(64), 0, st, g);
+    else if (p->mt == 2)
+        hipLaunchKernelGGL((masked_conv_pos_kernel<1, 2>), dim3(ptiles, rtiles / 2), dim3(64), 0, st, g);
     else
-        hipLaunchKernelGGL(masked_conv_pos_kernel<1>, grid, dim3(64), 0, as_stream(hip_stream), g);
+        hipLaunchKernelGGL((masked_conv_pos_kernel<1, 1>), dim3(ptiles, rtiles), dim3(64), 0, st, g);
     BASIC_HIP_TRY(hipGetLastError());
     return BASIC_OK;
 }

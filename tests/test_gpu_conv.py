@@ -181,12 +181,17 @@ def test_masked_conv_positions(cfg):
 
 @pytest.mark.parametrize("seed", range(40))
 def test_masked_conv_fuzz(seed):
-    """Random channel counts / group structures / map sizes / position lists for the topo-group masked conv
-    (both the one-wave and the split-K variants are reached through the position count)."""
+    """Random channel counts / group structures / map sizes / position lists for the topo-group masked conv.  Every
+    case runs through BOTH launch shapes (split-K workgroups for tiny launches, one wave per 1..5 row tiles for large
+    ones; BASIC_MCONV_SPLITK_BELOW moves the switch-over); the several-tiles-per-wave variants must agree bit for bit
+    with the one-tile-per-wave kernel (plan built under BASIC_MCONV_MAX_MT=1)."""
+    import os
     from cbench_basic_amd.nn import kernels as K
     rng = np.random.default_rng(900 + seed)
     gi, go = int(rng.choice([1, 2, 3, 4, 6])), int(rng.choice([1, 2, 3, 4, 6]))
     cin, cout = gi * int(rng.integers(1, 40)), go * int(rng.integers(1, 40))
+    if seed % 2:  # whole 32-row tiles per group: 1..6 tiles -> the 1/2/3/4/5-tiles-per-wave variants
+        cout = go * 32 * int(rng.integers(1, 7))
     k = int(rng.choice([1, 3, 5]))
     same = bool(rng.integers(0, 2))
     B, H, W = int(rng.integers(1, 4)), int(rng.integers(2, 20)), int(rng.integers(2, 20))
@@ -198,21 +203,34 @@ def test_masked_conv_fuzz(seed):
     topo_out = torch.randint(0, 5, (go, H, W), generator=g)
     ref = _masked_conv_ref(x, w, b, topo_in, topo_out, same)
     plan = K.MaskedConvPlan(w, b, gi, go, same)
+    os.environ["BASIC_MCONV_MAX_MT"] = "1"
+    try:
+        plan_mt1 = K.MaskedConvPlan(w, b, gi, go, same)
+    finally:
+        del os.environ["BASIC_MCONV_MAX_MT"]
     npos = int(rng.integers(1, B * H * W + 1))
     sel = torch.randperm(B * H * W, generator=g)[:npos].sort().values.int()
     off = int(rng.choice([0, 3]))
-    out = torch.full((B, cout + off, H, W), -7.0).cuda()
-    plan(x.cuda(), topo_in.int().cuda(), topo_out.int().cuda(), sel.cuda(), out, out_offset=off)
-    torch.cuda.synchronize()
-    out = out.cpu()
+    outs = []
+    for pl, split_below in ((plan, "0"), (plan_mt1, "0"), (plan, str(1 << 40))):
+        os.environ["BASIC_MCONV_SPLITK_BELOW"] = split_below
+        try:
+            out = torch.full((B, cout + off, H, W), -7.0).cuda()
+            pl(x.cuda(), topo_in.int().cuda(), topo_out.int().cuda(), sel.cuda(), out, out_offset=off)
+            torch.cuda.synchronize()
+        finally:
+            del os.environ["BASIC_MCONV_SPLITK_BELOW"]
+        outs.append(out.cpu())
+    assert torch.equal(outs[0], outs[1]), "tiles-per-wave variants disagree"
     mask = torch.zeros(B * H * W, dtype=torch.bool)
     mask[sel.long()] = True
     mask = mask.reshape(B, 1, H, W)
-    got = out[:, off:]
-    assert torch.all(out[:, :off] == -7.0)
-    assert torch.all(got[(~mask).expand_as(got)] == -7.0), "positions outside the list were touched"
-    err = ((got - ref).abs() * mask).max()
-    assert err <= TOL * max(1.0, float(ref.abs().max())), float(err)
+    for out in (outs[0], outs[2]):   # large-launch variant, split-K variant
+        got = out[:, off:]
+        assert torch.all(out[:, :off] == -7.0)
+        assert torch.all(got[(~mask).expand_as(got)] == -7.0), "positions outside the list were touched"
+        err = ((got - ref).abs() * mask).max()
+        assert err <= TOL * max(1.0, float(ref.abs().max())), float(err)
 
 
 def test_entropy_param_kernels():
