@@ -27,6 +27,8 @@
 // garbage, even NaN, never enters the sum -- the reference multiplies by 0, which only differs for non-finite data).
 #include "common.h"
 
+#include <climits>
+#include <cstdint>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -49,9 +51,12 @@ struct MaskedLaunch {
     int64_t n_pos;
     int batch, cin, cout, coutp, h, w_, gi, go, gs_in, gs_out, tiles_per_group;
     int out_total, out_off, ntaps, pad, ksize, allow_same, act;
+    int step;              // coding step (topo group being coded), or kNoStep: see the skip rule in the kernel
+    const int32_t *first;  // [H][W] first step that visits a position (min over channel groups), or nullptr
     int mt;                // pack factor of w: row r of a group sits at (r / (32 mt)) * 32 mt + (r % 32) * mt + (r / 32) % mt
 };
 
+constexpr int kNoStep = INT32_MIN;
 constexpr int kUnroll = 4;  // channel pairs whose loads are issued together (one L2 round trip per 4 MFMAs)
 
 // kWaves > 1: K is split over the waves of a workgroup and the partial tiles are summed through LDS -- for tiny
@@ -103,6 +108,17 @@ __global__ __launch_bounds__(64 * kWaves) void masked_conv_pos_kernel(const Mask
     }
     const int32_t centre = pos_ok ? g.topo_out[grp_o * hw + py * g.w_ + px] : 0;
     const float *xb = g.x + static_cast<int64_t>(b) * g.cin * hw;
+
+    // Step rule (coding loop): the value of (output group, position) only depends on elements coded before ITS step
+    // (mask < / <=), so what an earlier step wrote is still exact and what a later step needs is computed then.  A tile
+    // is therefore evaluated only if some position has this output group in the current step -- or, for groups that
+    // carry no topo id (-1: the prior half of the merger's hidden layers), at the first step that visits the position.
+    // With G channel groups this removes (G-1)/G of the work of channel-wise schedules.  Wave-uniform, and the same in
+    // all waves of a split-K workgroup (same positions, same group).
+    if (g.step != kNoStep) {
+        const bool need = pos_ok && (centre == g.step || (centre < 0 && g.first[py * g.w_ + px] == g.step));
+        if (__ballot(need) == 0ull) return;
+    }
 
     f32x16 acc[MT];
 #pragma unroll
@@ -244,10 +260,32 @@ extern "C" int basic_mconv_plan_create(const float *weight, const float *bias, i
     return BASIC_OK;
 }
 
+static int mconv_forward(const basic_mconv_plan *p, const float *d_x, const int32_t *d_topo_in, const int32_t *d_topo_out,
+                         int batch, int h, int w, const int32_t *d_pos, int64_t n_pos, float *d_y, int out_channels_total,
+                         int out_channel_offset, int step, const int32_t *d_first, void *hip_stream);
+
 extern "C" int basic_mconv_forward_pos_dev(const basic_mconv_plan *p, const float *d_x, const int32_t *d_topo_in,
                                            const int32_t *d_topo_out, int batch, int h, int w, const int32_t *d_pos,
                                            int64_t n_pos, float *d_y, int out_channels_total, int out_channel_offset,
                                            void *hip_stream)
+{
+    return mconv_forward(p, d_x, d_topo_in, d_topo_out, batch, h, w, d_pos, n_pos, d_y, out_channels_total, out_channel_offset,
+                         kNoStep, nullptr, hip_stream);
+}
+
+extern "C" int basic_mconv_forward_step_dev(const basic_mconv_plan *p, const float *d_x, const int32_t *d_topo_in,
+                                            const int32_t *d_topo_out, int batch, int h, int w, const int32_t *d_pos,
+                                            int64_t n_pos, float *d_y, int out_channels_total, int out_channel_offset,
+                                            int step, const int32_t *d_first_step, void *hip_stream)
+{
+    BASIC_REQUIRE(d_first_step && step != kNoStep, "mconv_forward_step: first-step map and a step are required");
+    return mconv_forward(p, d_x, d_topo_in, d_topo_out, batch, h, w, d_pos, n_pos, d_y, out_channels_total, out_channel_offset,
+                         step, d_first_step, hip_stream);
+}
+
+static int mconv_forward(const basic_mconv_plan *p, const float *d_x, const int32_t *d_topo_in, const int32_t *d_topo_out,
+                         int batch, int h, int w, const int32_t *d_pos, int64_t n_pos, float *d_y, int out_channels_total,
+                         int out_channel_offset, int step, const int32_t *d_first, void *hip_stream)
 {
     BASIC_REQUIRE(p && d_x && d_topo_in && d_topo_out && d_pos && d_y && batch >= 1 && h >= 1 && w >= 1 && n_pos >= 0,
                   "mconv_forward_pos: bad argument");
@@ -262,7 +300,7 @@ extern "C" int basic_mconv_forward_pos_dev(const basic_mconv_plan *p, const floa
     g.tiles_per_group = (g.gs_out + 31) / 32;
     g.out_total = out_channels_total; g.out_off = out_channel_offset;
     g.ntaps = p->ksize * p->ksize; g.pad = p->ksize / 2; g.ksize = p->ksize; g.allow_same = p->allow_same; g.act = p->act;
-    g.mt = p->mt;
+    g.mt = p->mt; g.step = step; g.first = d_first;
     const unsigned ptiles = static_cast<unsigned>((n_pos + 31) / 32), rtiles = static_cast<unsigned>(g.tiles_per_group * g.go);
     hipStream_t st = as_stream(hip_stream);
     // few tiles -> split K over 4 waves per tile; many tiles -> one wave per MT row tiles already fills the chip

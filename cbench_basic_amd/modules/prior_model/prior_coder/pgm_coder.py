@@ -144,6 +144,8 @@ class _GroupPlan:
         full = np.repeat(topo, per, axis=0).reshape(-1)          # post-repeat, :1770
         self.topo_dev = torch.from_numpy(topo.astype(np.int32)).to(device).contiguous()
         self.topo_cat_dev = torch.cat([self.topo_dev, torch.full_like(self.topo_dev, -1)], 0).contiguous()
+        # first step that visits a position (all channel groups): when the id-less (-1) merger groups are evaluated
+        self.first_dev = torch.from_numpy(topo.min(axis=0).astype(np.int32)).to(device).contiguous()
         self.groups = []
         base = 0
         for g in range(int(topo.max()) + 1):
@@ -348,21 +350,25 @@ class GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(HotPathModule):
         return ws
 
     def _context(self, ws, plan, g, B, prior):
-        return self._context_at(ws, plan, plan.positions(g, B, self.device), prior)
+        """Parameters of coding step g.  The workspace persists over the steps of one encode / decode call, so each
+        masked layer only evaluates the (channel group, position) pairs that belong to step g (csrc/mconv.hip, step
+        rule); the reference recomputes every group at every step (pgm_coder.py:922-924)."""
+        return self._context_at(ws, plan, plan.positions(g, B, self.device), prior, step=g)
 
-    def _context_at(self, ws, plan, pos, prior):
+    def _context_at(self, ws, plan, pos, prior, step=None):
         topo = dict(pgm=plan.topo_dev, cat=plan.topo_cat_dev)
         merger = self._layers.get("m")
+        sk = dict(step=step, first_step=plan.first_dev) if step is not None else {}
         if merger is None:
-            self._layers["ctx"](ws["ybuf"], topo["pgm"], topo["pgm"], pos, ws["ctx"])
+            self._layers["ctx"](ws["ybuf"], topo["pgm"], topo["pgm"], pos, ws["ctx"], **sk)
             # no merger: params = ctx + prior (pgm_coder.py:1634-1636); elementwise add on the full map is
             # cheap plumbing and only the group's positions are read afterwards
             ws["params"] = ws["ctx"] + prior if prior is not None else ws["ctx"]
             return ws["params"]
-        self._layers["ctx"](ws["ybuf"], topo["pgm"], topo["pgm"], pos, ws["cat"], out_offset=0)
+        self._layers["ctx"](ws["ybuf"], topo["pgm"], topo["pgm"], pos, ws["cat"], out_offset=0, **sk)
         x = ws["cat"]
         for (pl, tin, tout), out in zip(merger, ws["hidden"]):
-            pl(x, topo[tin], topo[tout], pos, out)
+            pl(x, topo[tin], topo[tout], pos, out, **sk)
             x = out
         return ws["params"]
 
@@ -456,8 +462,9 @@ class GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(HotPathModule):
         sym, idx, _, plan = self._run_encode(input, prior, pgm)
         n = plan.per_image
         if self._per_image(B):
-            strings = self._tables.encode_batch_to_bytes(sym.reshape(-1), idx.reshape(-1), n)
-            body = struct.pack("<I", B) + struct.pack("<%dI" % B, *[len(s) for s in strings]) + b"".join(strings)
+            host, off = self._tables.encode_batch_end(self._tables.encode_batch_begin(sym.reshape(-1), idx.reshape(-1), n))
+            lens = (np.diff(off) * 4).astype("<u4")
+            body = b"".join([struct.pack("<I", B), lens.tobytes(), memoryview(host[: int(off[-1])])])   # one copy of the words
         else:
             # reference order for a batch: group-major over ALL images (data[mask] spans the batch, :898-900)
             if B > 1:
@@ -494,23 +501,23 @@ class GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(HotPathModule):
         if per_image:
             (nb,) = struct.unpack("<I", body[:4])
             assert nb == B
-            lens = struct.unpack("<%dI" % B, body[4:4 + 4 * B])
-            cur, strings = 4 + 4 * B, []
-            for Ls in lens:
-                strings.append(body[cur:cur + Ls])
-                cur += Ls
+            lens = np.frombuffer(body, dtype="<u4", count=B, offset=4).astype(np.int64)
+            payload = 4 + 4 * B
         else:
-            strings = [body]
-        ns = len(strings)
-        for s in strings:
-            if len(s) < 8 or len(s) % 4:
-                raise ValueError("rANS stream must hold >= 2 whole 32-bit words")
-        woff = np.concatenate([[0], np.cumsum([len(s) // 4 for s in strings])]).astype(np.int64)
+            lens, payload = np.array([len(body)], dtype=np.int64), 0
+        if (lens < 8).any() or (lens % 4).any() or payload + int(lens.sum()) > len(body):
+            raise ValueError("rANS stream must hold >= 2 whole 32-bit words")
+        woff = np.concatenate([[0], np.cumsum(lens // 4)]).astype(np.int64)
         dev = self.device
-        words_np = np.frombuffer(b"".join(strings), dtype=np.int32)
+        # the streams lie back to back in the body: one copy into the pinned staging buffer, DMA from there
+        stage = self._tables._stage_in(int(woff[-1]))
+        stage.numpy()[:] = np.frombuffer(body, dtype=np.int32, count=int(woff[-1]), offset=payload)
+        words_np = stage.numpy()
         use_graph = len(plan.groups) >= self.GRAPH_MIN_GROUPS and getattr(self, "use_hip_graphs", True) and per_image
         if not use_graph:
-            d_words = torch.from_numpy(words_np.copy()).to(dev)
+            d_words = stage.to(dev, non_blocking=True)
+            self._tables._pin_in_event = torch.cuda.Event()
+            self._tables._pin_in_event.record(torch.cuda.current_stream(dev))
             d_woff = torch.from_numpy(woff).to(dev)
             return self._run_decode_impl(d_words, d_woff, prior, B, H, W, per_image, plan)
         # static buffers: per-image streams never exceed the encoder's slot bound plus slack
@@ -521,7 +528,7 @@ class GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(HotPathModule):
             sw = torch.zeros((cap,), device=dev, dtype=torch.int32)
             so = torch.zeros((B + 1,), device=dev, dtype=torch.int64)
             sp = torch.empty_like(prior) if prior is not None else None
-            sw[: words_np.size].copy_(torch.from_numpy(words_np.copy()))
+            sw[: words_np.size].copy_(stage)
             so.copy_(torch.from_numpy(woff))
             if sp is not None:
                 sp.copy_(prior)
@@ -534,7 +541,9 @@ class GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(HotPathModule):
         graph, sw, so, sp, out = entry
         if words_np.size > cap:
             raise ValueError("encoded stream larger than the decoder's static buffer")
-        sw[: words_np.size].copy_(torch.from_numpy(words_np.copy()), non_blocking=False)
+        sw[: words_np.size].copy_(stage, non_blocking=True)
+        self._tables._pin_in_event = torch.cuda.Event()
+        self._tables._pin_in_event.record(torch.cuda.current_stream(dev))
         so.copy_(torch.from_numpy(woff))
         if sp is not None:
             sp.copy_(prior)

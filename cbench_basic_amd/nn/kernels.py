@@ -105,11 +105,19 @@ class MaskedConvPlan:
             except Exception:
                 pass
 
-    def __call__(self, x, topo_in, topo_out, pos, out, out_offset=0):
+    def __call__(self, x, topo_in, topo_out, pos, out, out_offset=0, step=None, first_step=None):
+        """step / first_step: the coding-loop variant (basic_mconv_forward_step_dev) that only evaluates the
+        (output group, position) pairs of the current step."""
         x = _dev(x, torch.float32)
         B, C, H, W = x.shape
         topo_in, topo_out, pos = _dev(topo_in, torch.int32), _dev(topo_out, torch.int32), _dev(pos, torch.int32)
         out = _dev(out, torch.float32)
+        if step is not None:
+            first_step = _dev(first_step, torch.int32)
+            _lib.check(_lib.lib().basic_mconv_forward_step_dev(self._h, x.data_ptr(), topo_in.data_ptr(), topo_out.data_ptr(), B, H, W,
+                                                               pos.data_ptr(), pos.numel(), out.data_ptr(), out.shape[1],
+                                                               int(out_offset), int(step), first_step.data_ptr(), _stream()))
+            return out
         _lib.check(_lib.lib().basic_mconv_forward_pos_dev(self._h, x.data_ptr(), topo_in.data_ptr(), topo_out.data_ptr(), B, H, W,
                                                           pos.data_ptr(), pos.numel(), out.data_ptr(), out.shape[1], int(out_offset),
                                                           _stream()))

@@ -233,6 +233,16 @@ int basic_mconv_forward_pos_dev(const basic_mconv_plan *p, const float *d_x, con
                                 const int32_t *d_topo_out, int batch, int h, int w, const int32_t *d_pos,
                                 int64_t n_pos, float *d_y, int out_channels_total, int out_channel_offset,
                                 void *hip_stream);
+/* The same operator inside the group-sequential coding loop (pgm_coder.py:921-941 / :958-978), where d_y persists
+ * across the steps of one encode / decode: only (output group, position) pairs whose topo id equals `step` are
+ * evaluated -- plus groups without a topo id (-1) at the first step that visits the position (d_first_step int32
+ * [H][W] = min over channel groups of the topo ids).  Everything else in d_y is either already exact (earlier steps;
+ * the mask makes a value depend only on elements coded before its own step) or not needed yet.  The reference
+ * recomputes the full map at every step instead. */
+int basic_mconv_forward_step_dev(const basic_mconv_plan *p, const float *d_x, const int32_t *d_topo_in,
+                                 const int32_t *d_topo_out, int batch, int h, int w, const int32_t *d_pos,
+                                 int64_t n_pos, float *d_y, int out_channels_total, int out_channel_offset,
+                                 int step, const int32_t *d_first_step, void *hip_stream);
 void basic_mconv_plan_destroy(basic_mconv_plan *p);
 
 /* ======================================================================================
