@@ -53,6 +53,10 @@ struct MaskedLaunch {
     int out_total, out_off, ntaps, pad, ksize, allow_same, act;
     int step;              // coding step (topo group being coded), or kNoStep: see the skip rule in the kernel
     const int32_t *first;  // [H][W] first step that visits a position (min over channel groups), or nullptr
+    // cross-workgroup split-K (smallest launches): gridDim.z = tap_slices * pair_slices K-slices per tile, each
+    // writes its partial tile to scratch[(tile * slices + slice)][16][64]; masked_conv_reduce_kernel sums them
+    float *scratch;
+    int tap_slices, pair_slices;
     int mt;                // pack factor of w: row r of a group sits at (r / (32 mt)) * 32 mt + (r % 32) * mt + (r / 32) % mt
 };
 
@@ -126,7 +130,13 @@ __global__ __launch_bounds__(64 * kWaves) void masked_conv_pos_kernel(const Mask
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
 
+    // K-slice of this workgroup (blockIdx.z) and of this wave inside it: taps t = tap_slice (mod tap_slices), channel
+    // pairs vwave, vwave + nvwaves, ... of every slab
+    const int tap_slice = blockIdx.z % g.tap_slices, vwave = (blockIdx.z / g.tap_slices) * kWaves + wave;
+    const int nvwaves = g.pair_slices * kWaves;
+
     for (int t = 0; t < g.ntaps; ++t) {
+        if (t % g.tap_slices != tap_slice) continue;
         const int dy = t / g.ksize - g.pad, dx = t % g.ksize - g.pad;
         const int yy = py + dy, xx = px + dx;
         const bool inside = pos_ok && yy >= 0 && yy < g.h && xx >= 0 && xx < g.w_;
@@ -140,12 +150,12 @@ __global__ __launch_bounds__(64 * kWaves) void masked_conv_pos_kernel(const Mask
             if (__ballot(open) == 0ull) continue;  // wave-uniform skip of an all-masked slab (same in every wave)
             const int c_beg = gin * g.gs_in, c_end = c_beg + g.gs_in;
             const float *wt = g.w + (static_cast<int64_t>(t) * g.cin) * g.coutp + a_off;
-            // this wave's share of the slab: channel pairs wave, wave + kWaves, ...; kUnroll pairs per round trip
-            for (int c = c_beg + 2 * wave; c < c_end; c += 2 * kWaves * kUnroll) {
+            // this wave's share of the slab: channel pairs vwave, vwave + nvwaves, ...; kUnroll pairs per round trip
+            for (int c = c_beg + 2 * vwave; c < c_end; c += 2 * nvwaves * kUnroll) {
                 float af[kUnroll][MT], bf[kUnroll];
 #pragma unroll
                 for (int u = 0; u < kUnroll; ++u) {
-                    const int ci = c + u * 2 * kWaves + khalf;
+                    const int ci = c + u * 2 * nvwaves + khalf;
                     const bool ci_ok = ci < c_end;
                     load_a<MT>(wt + static_cast<int64_t>(ci) * g.coutp, row_ok && ci_ok, af[u]);
                     bf[u] = (open && ci_ok) ? xb[static_cast<int64_t>(ci) * hw + noff] : 0.f;
@@ -172,6 +182,13 @@ __global__ __launch_bounds__(64 * kWaves) void masked_conv_pos_kernel(const Mask
         for (int w = 0; w < kWaves - 1; ++w)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[0][r] += partial[w][r][lane];
+        if (g.scratch) {  // one K-slice of several: hand the partial tile to masked_conv_reduce_kernel
+            const int64_t tile = static_cast<int64_t>(blockIdx.y) * gridDim.x + blockIdx.x;
+            float *dst = g.scratch + ((tile * gridDim.z + blockIdx.z) * 16) * 64 + lane;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dst[r * 64] = acc[0][r];
+            return;
+        }
         if (pos_ok) {
             float *yb = g.y + (static_cast<int64_t>(b) * g.out_total + g.out_off) * hw + py * g.w_ + px;
 #pragma unroll
@@ -191,11 +208,67 @@ __global__ __launch_bounds__(64 * kWaves) void masked_conv_pos_kernel(const Mask
     }
 }
 
+// Second half of the cross-workgroup split-K: one workgroup per tile, wave w owns accumulator rows 4w .. 4w+3 of every
+// lane; all K-slices' values of a row are loaded together (at most 16 x 4 loads in flight) and summed in slice order
+// (deterministic); then bias, activation and store -- the epilogue of masked_conv_pos_kernel<*, 1>.
+__global__ __launch_bounds__(256) void masked_conv_reduce_kernel(const MaskedLaunch g, int slices)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 31, khalf = lane >> 5;
+    const int grp_o = blockIdx.y / g.tiles_per_group, ti = blockIdx.y - grp_o * g.tiles_per_group;
+    const int64_t pj = static_cast<int64_t>(blockIdx.x) * 32 + col;
+    const bool pos_ok = pj < g.n_pos;
+    const int hw = g.h * g.w_;
+    int b = 0, py = 0, px = 0;
+    if (pos_ok) {
+        const int32_t f = g.pos[pj];
+        b = f / hw;
+        const int p = f - b * hw;
+        py = p / g.w_;
+        px = p - py * g.w_;
+    }
+    if (g.step != kNoStep) {  // same rule as the partial kernel: skipped tiles have no partials
+        const int32_t centre = pos_ok ? g.topo_out[grp_o * hw + py * g.w_ + px] : 0;
+        const bool need = pos_ok && (centre == g.step || (centre < 0 && g.first[py * g.w_ + px] == g.step));
+        if (__ballot(need) == 0ull) return;
+    }
+    const int64_t tile = static_cast<int64_t>(blockIdx.y) * gridDim.x + blockIdx.x;
+    const float *src = g.scratch + (tile * slices * 16 + 4 * wave) * 64 + lane;
+    constexpr int kMaxSlices = 16;
+    float v[kMaxSlices][4];
+#pragma unroll
+    for (int s = 0; s < kMaxSlices; ++s)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[s][q] = s < slices ? src[(s * 16 + q) * 64] : 0.f;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < kMaxSlices; ++s)
+        if (s < slices) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] += v[s][q];
+        }
+    if (!pos_ok) return;
+    float *yb = g.y + (static_cast<int64_t>(b) * g.out_total + g.out_off) * hw + py * g.w_ + px;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int rg = ti * 32 + 8 * wave + 4 * khalf + q;
+        if (rg < g.gs_out) {
+            const int co = grp_o * g.gs_out + rg;
+            float o = acc[q] + g.bias[co];
+            if (g.act == BASIC_ACT_LEAKY_RELU) o = o > 0.f ? o : 0.01f * o;
+            else if (g.act == BASIC_ACT_RELU) o = o > 0.f ? o : 0.f;
+            yb[static_cast<int64_t>(co) * hw] = o;
+        }
+    }
+}
+
+constexpr int kScratchTiles = 1024;  // partial tiles (4 KB each) a plan can hold: tiles x K-slices of the smallest launches
+
 }  // namespace
 
 struct basic_mconv_plan {
     int cin = 0, cout = 0, coutp = 0, ksize = 1, gi = 1, go = 1, allow_same = 0, act = 0;
     int mt = 1;  // row tiles per wave of the large-launch kernel = pack factor of d_w
+    float *d_scratch = nullptr;  // K-slice partial tiles of the cross-workgroup split-K (one stream per plan at a time)
     float *d_w1 = nullptr;  // plain [tap][ci][co] copy for the split-K kernel when mt > 1 (coalesced 128-byte A rows)
     float *d_w = nullptr, *d_bias = nullptr;
 };
@@ -205,6 +278,7 @@ extern "C" void basic_mconv_plan_destroy(basic_mconv_plan *p)
     if (!p) return;
     if (p->d_w) (void)hipFree(p->d_w);
     if (p->d_w1) (void)hipFree(p->d_w1);
+    if (p->d_scratch) (void)hipFree(p->d_scratch);
     if (p->d_bias) (void)hipFree(p->d_bias);
     delete p;
 }
@@ -253,6 +327,7 @@ extern "C" int basic_mconv_plan_create(const float *weight, const float *bias, i
     if (e == hipSuccess) e = hipMemcpy(p->d_w, wp.data(), wp.size() * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess && p->mt > 1) e = hipMalloc(&p->d_w1, w1.size() * sizeof(float));
     if (e == hipSuccess && p->mt > 1) e = hipMemcpy(p->d_w1, w1.data(), w1.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc(&p->d_scratch, static_cast<size_t>(kScratchTiles) * 16 * 64 * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(&p->d_bias, hb.size() * sizeof(float));
     if (e == hipSuccess) e = hipMemcpy(p->d_bias, hb.data(), hb.size() * sizeof(float), hipMemcpyHostToDevice);
     if (e != hipSuccess) { basic_mconv_plan_destroy(p); return hip_fail(e, "mconv_plan_create", __FILE__, __LINE__); }
@@ -301,15 +376,34 @@ static int mconv_forward(const basic_mconv_plan *p, const float *d_x, const int3
     g.out_total = out_channels_total; g.out_off = out_channel_offset;
     g.ntaps = p->ksize * p->ksize; g.pad = p->ksize / 2; g.ksize = p->ksize; g.allow_same = p->allow_same; g.act = p->act;
     g.mt = p->mt; g.step = step; g.first = d_first;
+    g.scratch = nullptr; g.tap_slices = 1; g.pair_slices = 1;
     const unsigned ptiles = static_cast<unsigned>((n_pos + 31) / 32), rtiles = static_cast<unsigned>(g.tiles_per_group * g.go);
     hipStream_t st = as_stream(hip_stream);
     // few tiles -> split K over 4 waves per tile; many tiles -> one wave per MT row tiles already fills the chip
     // (BASIC_MCONV_SPLITK_BELOW moves the switch-over: tests drive both variants over the same inputs)
     int64_t split_below = 4096;
     if (const char *e = std::getenv("BASIC_MCONV_SPLITK_BELOW")) split_below = std::atoll(e);
-    if (static_cast<int64_t>(ptiles) * rtiles < split_below) {
+    const int64_t tiles = static_cast<int64_t>(ptiles) * rtiles;
+    int64_t cross_below = 256;   // fewer tiles than this: K is also split over workgroups (BASIC_MCONV_CROSS_BELOW)
+    if (const char *e = std::getenv("BASIC_MCONV_CROSS_BELOW")) cross_below = std::atoll(e);
+    if (tiles < split_below) {
         if (p->mt > 1) { g.w = p->d_w1; g.mt = 1; }
-        hipLaunchKernelGGL((masked_conv_pos_kernel<4, 1>), dim3(ptiles, rtiles), dim3(256), 0, st, g);
+        int slices = 1;
+        if (tiles < cross_below) {
+            // ~512 workgroups in flight; the per-wave K loop of a scanline step drops from ~70 to ~5 load round trips
+            while (slices < 16 && tiles * slices * 2 <= 512 && tiles * slices * 2 <= kScratchTiles) slices *= 2;
+            // a slab must keep at least one channel pair per wave
+            while (slices > 1 && (slices / (g.ntaps > 1 ? (slices < 4 ? slices : 4) : 1)) * 4 * 2 > g.gs_in) slices /= 2;
+        }
+        if (slices > 1) {
+            g.tap_slices = g.ntaps > 1 ? (slices < 4 ? slices : 4) : 1;
+            g.pair_slices = slices / g.tap_slices;
+            g.scratch = p->d_scratch;
+            hipLaunchKernelGGL((masked_conv_pos_kernel<4, 1>), dim3(ptiles, rtiles, slices), dim3(256), 0, st, g);
+            hipLaunchKernelGGL(masked_conv_reduce_kernel, dim3(ptiles, rtiles), dim3(256), 0, st, g, slices);
+        } else {
+            hipLaunchKernelGGL((masked_conv_pos_kernel<4, 1>), dim3(ptiles, rtiles), dim3(256), 0, st, g);
+        }
     }
     else if (p->mt == 5)
         hipLaunchKernelGGL((masked_conv_pos_kernel<1, 5>), dim3(ptiles, rtiles / 5), dim3(64), 0, st, g);

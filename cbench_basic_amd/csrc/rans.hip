@@ -845,14 +845,31 @@ __global__ __launch_bounds__(64) void rans_decode_fast_kernel(TablesDev T, const
                                                               const int64_t *__restrict__ seg, int32_t *out_symbols,
                                                               uint64_t *state, int64_t *pos_io, StridedSeg ss)
 {
-    extern __shared__ uint32_t img[];
+    extern __shared__ __attribute__((aligned(16))) uint32_t img[];
     const int stream = blockIdx.x;
     const int lane = threadIdx.x;
     const int64_t beg = seg ? seg[stream] : ss.first + stream * ss.stride;
     const int n = static_cast<int>(seg ? seg[stream + 1] - beg : ss.count);
     const int32_t *idx = indexes + beg;
     int32_t *out = out_symbols + beg;
-    for (int i = lane; i < T.image_words; i += 64) img[i] = T.image[i];
+    {   // table image -> LDS in 16-byte pieces, eight loads in flight per lane (the image is a multiple of 16 bytes, rows
+        // are 16-byte aligned): a 150 KB image costs ~5 us instead of ~25, which matters when the AR loop calls this
+        // kernel once per topo group for a few hundred symbols per stream
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 *src = reinterpret_cast<const u32x4 *>(T.image);
+        u32x4 *dst = reinterpret_cast<u32x4 *>(img);
+        const int pieces = T.image_words >> 2;
+        int i = lane;
+        for (; i + 7 * 64 < pieces; i += 8 * 64) {
+            u32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = src[i + u * 64];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) dst[i + u * 64] = v[u];
+        }
+        for (; i < pieces; i += 64) dst[i] = src[i];
+        for (int j = (pieces << 2) + lane; j < T.image_words; j += 64) img[j] = T.image[j];
+    }
     __syncthreads();
 
     const uint32_t *words = words_all + word_off[stream];

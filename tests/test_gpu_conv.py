@@ -182,8 +182,8 @@ def test_masked_conv_positions(cfg):
 @pytest.mark.parametrize("seed", range(40))
 def test_masked_conv_fuzz(seed):
     """Random channel counts / group structures / map sizes / position lists for the topo-group masked conv.  Every
-    case runs through BOTH launch shapes (split-K workgroups for tiny launches, one wave per 1..5 row tiles for large
-    ones; BASIC_MCONV_SPLITK_BELOW moves the switch-over); the several-tiles-per-wave variants must agree bit for bit
+    case runs through ALL launch shapes (K split across workgroups / inside a workgroup for tiny launches, one wave per
+    1..5 row tiles for large ones; BASIC_MCONV_SPLITK_BELOW / _CROSS_BELOW move the switch-overs); the several-tiles-per-wave variants must agree bit for bit
     with the one-tile-per-wave kernel (plan built under BASIC_MCONV_MAX_MT=1)."""
     import os
     from cbench_basic_amd.nn import kernels as K
@@ -212,20 +212,22 @@ def test_masked_conv_fuzz(seed):
     sel = torch.randperm(B * H * W, generator=g)[:npos].sort().values.int()
     off = int(rng.choice([0, 3]))
     outs = []
-    for pl, split_below in ((plan, "0"), (plan_mt1, "0"), (plan, str(1 << 40))):
-        os.environ["BASIC_MCONV_SPLITK_BELOW"] = split_below
+    big = str(1 << 40)
+    # large-launch kernel (default pack / one tile per wave), split-K inside a workgroup, split-K across workgroups
+    for pl, split_below, cross_below in ((plan, "0", "0"), (plan_mt1, "0", "0"), (plan, big, "0"), (plan, big, big)):
+        os.environ["BASIC_MCONV_SPLITK_BELOW"], os.environ["BASIC_MCONV_CROSS_BELOW"] = split_below, cross_below
         try:
             out = torch.full((B, cout + off, H, W), -7.0).cuda()
             pl(x.cuda(), topo_in.int().cuda(), topo_out.int().cuda(), sel.cuda(), out, out_offset=off)
             torch.cuda.synchronize()
         finally:
-            del os.environ["BASIC_MCONV_SPLITK_BELOW"]
+            del os.environ["BASIC_MCONV_SPLITK_BELOW"], os.environ["BASIC_MCONV_CROSS_BELOW"]
         outs.append(out.cpu())
     assert torch.equal(outs[0], outs[1]), "tiles-per-wave variants disagree"
     mask = torch.zeros(B * H * W, dtype=torch.bool)
     mask[sel.long()] = True
     mask = mask.reshape(B, 1, H, W)
-    for out in (outs[0], outs[2]):   # large-launch variant, split-K variant
+    for out in (outs[0], outs[2], outs[3]):
         got = out[:, off:]
         assert torch.all(out[:, :off] == -7.0)
         assert torch.all(got[(~mask).expand_as(got)] == -7.0), "positions outside the list were touched"
