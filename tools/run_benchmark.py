@@ -27,6 +27,8 @@ def main():
     ap.add_argument("--images", default=None, help="folder of PNG/JPEG images")
     ap.add_argument("--synthetic", type=int, default=0, help="number of synthetic images (torch.manual_seed(i); rand)")
     ap.add_argument("--size", type=int, default=256, help="height = width of the synthetic images")
+    ap.add_argument("--height", type=int, default=None, help="synthetic image height (default --size)")
+    ap.add_argument("--width", type=int, default=None, help="synthetic image width (default --size)")
     ap.add_argument("--batch-size", type=int, default=1)
     ap.add_argument("--complexity-levels", type=int, nargs="*", default=[])
     ap.add_argument("--rate-levels", type=int, nargs="*", default=[])
@@ -34,6 +36,9 @@ def main():
     ap.add_argument("--complexity-search", action="store_true",
                     help="--codec basic: find the complexity levels with the greedy search over the test images "
                          "(post_training_process) instead of the fixed ladder")
+    ap.add_argument("--warmup", action="store_true",
+                    help="code the first batch once before the timed run (plan building, table upload, graph capture are "
+                         "one-time costs; the reference's harness has no such step)")
     ap.add_argument("--out", required=True)
     args = ap.parse_args()
     if not torch.cuda.is_available():
@@ -45,7 +50,7 @@ def main():
     if args.images:
         ds = ImageFolderDataset(args.images)
     else:
-        ds = RandomImageDataset(num=args.synthetic or 8, size=(3, args.size, args.size))
+        ds = RandomImageDataset(num=args.synthetic or 8, size=(3, args.height or args.size, args.width or args.size))
     batches = list(batched(ds, args.batch_size))
     codec = dict(hyperprior=presets.hyperprior_codec,
                  basic=lambda: presets.basic_codec(search_dataset=batches if args.complexity_search else None),
@@ -59,6 +64,12 @@ def main():
     else:
         presets.seed_synthetic_weights(codec, seed=0)
     codec = codec.eval().to("cuda")
+    if args.warmup:
+        codec.update_state()
+        for lvl in (args.complexity_levels or [None]):
+            if lvl is not None:
+                codec.set_complex_level(lvl)
+            codec.decompress(codec.compress(batches[0].to("cuda")))
     bench = BasicLosslessCompressionBenchmark(codec, batches,
                                               distortion_metric=PytorchBatchedDistortion(),
                                               nn_codec_use_forward_pass=args.forward_pass,
