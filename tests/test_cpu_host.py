@@ -280,3 +280,27 @@ def test_complexity_level_search_matches_reference_golden():
 
     wrap = ParamDictModuleWrapper(dict(pgmxy=torch.eye(3)[1].reshape(1, 1, 3), nothing=None))
     assert list(wrap.state_dict()) == ["pgmxy"] and wrap()["nothing"] is None and wrap()["pgmxy"].argmax().item() == 1
+
+
+def test_supplied_topo_group_maps_host_logic():
+    """pgm= handling of the AR coder (trim / tile / argmax of logits, pgm_coder.py:1340-1380) against the oracle's
+    F.fold restatement, which tests/test_oracle_golden.py pins to the reference."""
+    import numpy as np
+    import torch
+    from cbench_basic_amd.modules.prior_model.prior_coder.pgm_coder import GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder as Coder
+    from oracle.pgm_oracle import topo_from_pgm
+    g = torch.Generator().manual_seed(3)
+    for case in range(24):
+        G = [1, 2, 4][case % 3]
+        coder = Coder(in_channels=16, channel_groups=G)
+        ph, pw = int(torch.randint(1, 5, (1,), generator=g)), int(torch.randint(1, 5, (1,), generator=g))
+        H, W = int(torch.randint(1, 11, (1,), generator=g)), int(torch.randint(1, 11, (1,), generator=g))
+        if case % 2:
+            pgm = torch.randn(1, G * 5, ph, pw, generator=g)
+        else:
+            pgm = torch.randint(0, 7, (1, G, ph, pw), generator=g)
+        got = coder._topo_from_pgm(pgm, H, W)
+        want = topo_from_pgm(pgm, G, H, W)[0].numpy()
+        assert got.shape == (G, H, W) and np.array_equal(got, want), (case, G, ph, pw, H, W)
+    with pytest.raises(ValueError):
+        Coder(in_channels=16, channel_groups=2)._topo_from_pgm(torch.zeros(1, 3, 2, 2, dtype=torch.long), 4, 4)
