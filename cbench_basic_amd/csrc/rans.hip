@@ -21,6 +21,7 @@
 #include <cmath>
 #include <cstring>
 #include <new>
+#include <type_traits>
 #include <vector>
 
 using namespace basic;
@@ -641,13 +642,21 @@ __global__ __launch_bounds__(64) void rans_encode_fast_kernel(TablesDev T, const
             x = bcast_u64(nx_, (J));                                                                           \
         } while (0)
         const int j_lo = hi >= 64 ? 0 : static_cast<int>(64 - hi);
-        int j = 63;
-        for (; j - 15 >= j_lo; j -= 16) {  // sixteen symbols per loop trip: the loop bookkeeping is issue slots too
 #define BASIC_ENC_STEP4(J) BASIC_ENC_STEP(J); BASIC_ENC_STEP((J) - 1); BASIC_ENC_STEP((J) - 2); BASIC_ENC_STEP((J) - 3)
-            BASIC_ENC_STEP4(j); BASIC_ENC_STEP4(j - 4); BASIC_ENC_STEP4(j - 8); BASIC_ENC_STEP4(j - 12);
-#undef BASIC_ENC_STEP4
+#define BASIC_ENC_STEP16(J) BASIC_ENC_STEP4(J); BASIC_ENC_STEP4((J) - 4); BASIC_ENC_STEP4((J) - 8); BASIC_ENC_STEP4((J) - 12)
+        if (j_lo == 0) {
+            // a full chunk, fully unrolled: the lane ids of the broadcasts are immediates (one scalar instruction fewer
+            // per symbol than the run-time loop below)
+            BASIC_ENC_STEP16(63); BASIC_ENC_STEP16(47); BASIC_ENC_STEP16(31); BASIC_ENC_STEP16(15);
+        } else {
+            int j = 63;
+            for (; j - 15 >= j_lo; j -= 16) {  // sixteen symbols per loop trip: the loop bookkeeping is issue slots too
+                BASIC_ENC_STEP16(j);
+            }
+            for (; j >= j_lo; --j) BASIC_ENC_STEP(j);
         }
-        for (; j >= j_lo; --j) BASIC_ENC_STEP(j);
+#undef BASIC_ENC_STEP16
+#undef BASIC_ENC_STEP4
 #undef BASIC_ENC_STEP
         cur = nxt;
         i2 = i3; row2 = row3; s2 = s3;
@@ -837,6 +846,15 @@ __global__ __launch_bounds__(64) void rans_decode_kernel(TablesDev T, ArDev ar, 
 //     so it is read from LDS two symbols ahead with one broadcast + one add + one ds_read;
 //   * offsets are added lane-parallel after the chunk; row size / image offset travel in one packed word;
 //   * stream words are handed out from a 64-word register cache with 32-bit cursors.
+// compile-time loop over J = kBegin, kBegin + 2, ... < kEnd
+template <int kBegin, int kEnd, class F> __device__ __forceinline__ void static_pairs(F &&f)
+{
+    if constexpr (kBegin < kEnd) {
+        f(std::integral_constant<int, kBegin>{});
+        static_pairs<kBegin + 2, kEnd>(f);
+    }
+}
+
 // Per narrow-row symbol the chain is: mask, compare, ballot, two lane broadcasts, 64-bit multiply-add,
 // (rare) renormalisation.
 __global__ __launch_bounds__(64) void rans_decode_fast_kernel(TablesDev T, const uint32_t *__restrict__ words_all,
@@ -935,7 +953,9 @@ __global__ __launch_bounds__(64) void rans_decode_fast_kernel(TablesDev T, const
             const uint32_t m = bcast_u32(meta_l, jj);
             e = *reinterpret_cast<const f32x4u *>(reinterpret_cast<const char *>(img) + m + lane * 16);
         };
-        auto decode_one = [&](int j, const f32x4u &e) {
+        auto decode_one = [&](auto jc, const f32x4u &e) {   // jc: int, or std::integral_constant (lane ids become immediates)
+            const int j = jc;
+            int32_t &res = result;  // named outside the if-constexpr below (generic lambda: implicit capture needs an odr-use)
             const uint32_t cf = static_cast<uint32_t>(x) & mask;
             const uint64_t t = x >> prec;
             // x = freq * (x >> prec) + (cf - start)   (rans64.h:128-142), per lane for its own symbol
@@ -983,13 +1003,29 @@ __global__ __launch_bounds__(64) void rans_decode_fast_kernel(TablesDev T, const
                 }
                 first = sym + 1;
             }
-            // result[lane j] = first (one scalar operand per VALU instruction on gfx9: the lane select goes through m0)
-            asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(result) : "s"(first), "s"(j) : "m0");
+            // result[lane j] = first (one scalar operand per VALU instruction on gfx9: a run-time lane select goes through m0)
+            if constexpr (std::is_integral<decltype(jc)>::value)
+                asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(res) : "s"(first), "s"(j) : "m0");
+            else
+                asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(res) : "s"(first), "n"(decltype(jc)::value));
         };
 
         f32x4u ea, eb;
         fetch(0, ea);
         fetch(cnt > 1 ? 1 : 0, eb);
+        if (cnt == 64) {
+            // a full chunk, fully unrolled: every lane id (row-entry prefetch, result lane) is an immediate -- two scalar
+            // instructions fewer per symbol than the run-time loop below
+            static_pairs<0, 64>([&](auto jc) {
+                constexpr int J = decltype(jc)::value;
+                decode_one(std::integral_constant<int, J>{}, ea);
+                if constexpr (J + 2 < 64) fetch(J + 2, ea);
+                decode_one(std::integral_constant<int, J + 1>{}, eb);
+                if constexpr (J + 3 < 64) fetch(J + 3, eb);
+            });
+            if (i < n) out[i] = result - 1 + off_l;
+            continue;
+        }
         int j = 0;
         for (; j + 17 < cnt; j += 16) {  // sixteen symbols per loop trip, no clamping of the prefetch index in here
 #pragma unroll
