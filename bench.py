@@ -74,10 +74,17 @@ def measure_conv_kernels(codec, x, reps=3):
         one_pass()
     e1.record()
     torch.cuda.synchronize()
-    launches = 0
-    for m in (g_a, h_a, h_s, h_s, g_s):
+    # launches per pass, as the plans report them for these shapes (sub-pixel phases of the transposed convolutions,
+    # fused pairwise where the kernel allows it)
+    def count(m, t):
+        n, (b, _, h, w) = 0, t.shape
         for p in m.plans():
-            launches += (1 if p.cout <= 4 else 4) if p.transposed else 1
+            n += p.launches(b, h, w)
+            h, w = p.out_hw(h, w)
+        return n
+    y = g_a(x)
+    z = h_a(y)
+    launches = count(g_a, x) + count(h_a, y) + 2 * count(h_s, z) + count(g_s, y)
     return e0.elapsed_time(e1) / 1e3 / reps, launches
 
 
@@ -216,7 +223,7 @@ def main():
                         parallelism=f"image-sharded x{world}, RCCL all-reduce of metric sums + all-gather of per-image (bytes, PSNR)"),
             roofline=dict(bound="mfma", achieved=achieved, peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
                           frac=achieved / PEAK_FP32_MFMA_TFLOPS, traffic=traffic,
-                          kernel="conv_tap_mfma_kernel<MT,CK,KH,KW,WAVES> + first/last-layer kernels (the 38 transform launches of one encode+decode pass)",
+                          kernel="conv_tap_mfma_kernel<MT,CK,KH,KW,WAVES> + first/last-layer kernels (the transform launches of one encode+decode pass)",
                           flops_per_launch=flops_pass / launches, launches_per_pass=launches,
                           avg_launch_ms=conv_s / launches * 1e3, pass_ms=conv_s * 1e3,
                           dominant=None if args.no_dominant else measure_dominant_kernel(codec, x)),

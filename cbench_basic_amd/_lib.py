@@ -59,6 +59,7 @@ _SIGNATURES = {
     "basic_conv_forward_dev": (_I, [_P, _P, _I, _I, _I, _P, _P]),
     "basic_conv_plan_destroy": (None, [_P]),
     "basic_conv_plan_flops": (_L, [_P, _I, _I, _I]),
+    "basic_conv_plan_launches": (_I, [_P, _I, _I, _I]),
     "basic_mconv_plan_create": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "basic_mconv_forward_pos_dev": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _L, _P, _I, _I, _P]),
     "basic_mconv_forward_step_dev": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _L, _P, _I, _I, _I, _P, _P]),

@@ -56,6 +56,8 @@ constexpr int kTilePos = 128;  // output positions per workgroup
 constexpr int kPSlots = 12;             // patch elements per thread and stage (patch <= 3072 floats) ...
 constexpr int kPSlotsNarrow = 24;       // ... and for launches of <= 2 M-tiles, which have the registers for more descriptors
 constexpr int patch_slots(int mt) { return mt <= 2 ? kPSlotsNarrow : kPSlots; }
+constexpr int kPSlotsFused = 6;         // ... and for the fused column-phase launches, which carry two accumulator sets
+constexpr int kFusedCK = 4;             // their channels per stage (15 / 10 taps: two 4-wave workgroups per CU still fit)
 constexpr int kMaxCoutPerLaunch = 192;  // 6 accumulator tiles per wave
 constexpr int kSplitBelowBlocks = 384;   // position grids smaller than this use the 32-channel-slice variant
 
@@ -120,13 +122,20 @@ constexpr int mtile_pitch(int mt) { return mt <= 1 ? 1 : (mt <= 2 ? 2 : (mt <= 4
 // patch) and the whole stage is unrolled with compile-time LDS offsets; KH = 0: runtime tap table.
 // WAVES = 4: 128 positions per workgroup, two workgroups per CU (MT <= 4); WAVES = 8: 256 positions, one
 // workgroup per CU with twice the LDS per stage -- half as many barriers and weight DMAs per MFMA.
-template <int MT, int kCK, int KH, int KW, int WAVES>
+// KWB > 0: FUSED column phases of a stride-2 transposed convolution.  The launch computes the two output columns
+// ox = 2 mx (taps KH x KW, accumulators acc) and ox = 2 mx + 1 (taps KH x KWB at patch columns shifted by KW - KWB,
+// accumulators acc2) of every m-grid position from ONE input patch and stores them as 8-byte pairs: whole sectors
+// instead of every other 4 bytes (a single phase writes half of each 32-byte sector; measured, the store tail of the
+// four separate phases of g_s layer 3 cost 1.9 ms against 0.2 ms for the stride-2 convolution of the same size).
+template <int MT, int kCK, int KH, int KW, int WAVES, int KWB = 0>
 __global__ __launch_bounds__(64 * WAVES, (MT <= 4 && WAVES == 4 ? 2 : 1)) void conv_tap_mfma_kernel(const TapLaunch g)
 {
     extern __shared__ float lds[];
     constexpr int kThreads = 64 * WAVES;   // shadows the 4-wave default of the host code
     constexpr int kWPiece = kThreads * 4;  // floats one 16-byte DMA instruction of the whole workgroup moves
-    constexpr int kPSlots = patch_slots(MT);
+    constexpr int kPSlots = KWB > 0 ? kPSlotsFused : patch_slots(MT);
+    constexpr int kTapsA = KH * KW, kTapsAll = KH * (KW + KWB);
+    static_assert(KWB == 0 || (KH > 0 && KWB <= KW && MT <= 4 && WAVES == 4), "fused phases: unrolled 4-wave launches of <= 4 tiles");
     constexpr int MTP = mtile_pitch(MT);  // A fragments of a lane sit MTP floats apart: [tap][ci][col][MTP]
     // output-channel slice of this block (small-grid launches spread Cout over blockIdx.y)
     const float *const wpack = g.wpack + blockIdx.y * g.split_wstride;
@@ -169,10 +178,14 @@ __global__ __launch_bounds__(64 * WAVES, (MT <= 4 && WAVES == 4 ? 2 : 1)) void c
     const int lane_a_base = (khalf * 32 + col) * MTP;
 
     f32x16 acc[MT];
+    f32x16 acc2[KWB > 0 ? MT : 1];  // second column phase (fused launches)
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+        for (int r = 0; r < 16; ++r) {
+            acc[m][r] = 0.f;
+            if (KWB > 0) acc2[m][r] = 0.f;
+        }
 
     const int patch_elems = TB * kCK * chan_stride;
     const int punit = g.patch4 ? 4 : 1;                       // floats per DMA lane
@@ -229,8 +242,8 @@ __global__ __launch_bounds__(64 * WAVES, (MT <= 4 && WAVES == 4 ? 2 : 1)) void c
     }
 
     constexpr int kStageTaps = (kCK == stage_channels(kMaxTaps, WAVES)) ? kMaxTaps : (kCK == stage_channels(kFewTaps, WAVES) ? kFewTaps : kVeryFewTaps);
-    constexpr int kWSlotsMax = (((KH > 0 ? KH * KW : kStageTaps) * kCK * 32 * MTP > 32 * 32 * MTP
-                                     ? (KH > 0 ? KH * KW : kStageTaps) * kCK * 32 * MTP : 32 * 32 * MTP) + kWPiece - 1) / kWPiece;
+    constexpr int kWSlotsMax = (((KH > 0 ? kTapsAll : kStageTaps) * kCK * 32 * MTP > 32 * 32 * MTP
+                                     ? (KH > 0 ? kTapsAll : kStageTaps) * kCK * 32 * MTP : 32 * 32 * MTP) + kWPiece - 1) / kWPiece;
 
 // DMA of stage S (weights + patch) into buffer BUF; advances the patch pointers to stage S+1.
 #define BASIC_ISSUE_STAGE(S, BUF)                                                                              \
@@ -281,7 +294,7 @@ __global__ __launch_bounds__(64 * WAVES, (MT <= 4 && WAVES == 4 ? 2 : 1)) void c
                 // wave-uniform row/channel term), so a step is one ds_read_b32 (B), one ds_read_b128 (A) and
                 // MT MFMAs.  The matrix pipe loses throughput to every other instruction the SIMD issues, so
                 // nothing else may sit between the MFMAs.
-                constexpr int kSteps = KH * KW * kPairs;
+                constexpr int kSteps = kTapsAll * kPairs;
                 const float *a_lane = wl + lane_a_base;
                 const float *b_lane = patch + lane_b_base;
                 fb[0] = b_lane[0];
@@ -291,12 +304,22 @@ __global__ __launch_bounds__(64 * WAVES, (MT <= 4 && WAVES == 4 ? 2 : 1)) void c
                     const int cur = st & 1, nxt = cur ^ 1;
                     const int sn = (st + 1 < kSteps) ? st + 1 : st;  // at the very end a harmless re-read
                     const int tn = sn / kPairs, cpn = sn % kPairs;
-                    fb[nxt] = b_lane[(tn / KW) * g.pwp + cpn * 2 * chan_stride + (tn % KW)];
+                    // patch row / column of tap tn: the first KH x KW taps are column phase 0, the KH x KWB after them
+                    // column phase 1, whose tap grid starts KW - KWB columns to the right
+                    const int trow = tn < kTapsA ? tn / KW : (tn - kTapsA) / (KWB > 0 ? KWB : 1);
+                    const int tcol = tn < kTapsA ? tn % KW : (tn - kTapsA) % (KWB > 0 ? KWB : 1) + (KW - KWB);
+                    fb[nxt] = b_lane[trow * g.pwp + cpn * 2 * chan_stride + tcol];
                     load_a<MTP>(a_lane + (tn * kCK + cpn * 2) * 32 * MTP, fa[nxt]);
                     __builtin_amdgcn_sched_barrier(0);
+                    if (KWB == 0 || st / kPairs < kTapsA) {
 #pragma unroll
-                    for (int m = 0; m < MT; ++m)
-                        acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][m], fb[cur], acc[m], 0, 0, 0);
+                        for (int m = 0; m < MT; ++m)
+                            acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][m], fb[cur], acc[m], 0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int m = 0; m < MT; ++m)
+                            acc2[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][m], fb[cur], acc2[m], 0, 0, 0);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             } else {
@@ -325,7 +348,8 @@ __global__ __launch_bounds__(64 * WAVES, (MT <= 4 && WAVES == 4 ? 2 : 1)) void c
         }
     }
 
-    // ---- epilogue: bias
+    // ---- epilogue: bias, GDN / IGDN -- on one accumulator set (twice for the fused column phases)
+    auto finish = [&](f32x16 (&acc)[MT], bool again) __attribute__((always_inline)) {
     // accumulator register r of tile m, lane (khalf, col): channel 32m + 8(r>>2) + 4 khalf + (r&3)
     if (bias) {
 #pragma unroll
@@ -354,6 +378,7 @@ __global__ __launch_bounds__(64 * WAVES, (MT <= 4 && WAVES == 4 ? 2 : 1)) void c
         _Pragma("unroll") for (int sl = 0; sl < (32 * 32 * MTP + kWPiece - 1) / kWPiece; ++sl)                 \
             __builtin_amdgcn_global_load_lds((glb_cvoid *)(src_ + sl * kWPiece), (lds_void *)(dst_ + sl * kWPiece + wave * 256), 16, 0, 0); \
     } while (0)
+        if (again) __syncthreads();  // every wave is done with the buffers the first pass read last
         BASIC_ISSUE_GAMMA(0);
 #pragma unroll
         for (int mk = 0; mk < MT; ++mk) {  // k rows 32mk .. 32mk+31
@@ -391,6 +416,9 @@ __global__ __launch_bounds__(64 * WAVES, (MT <= 4 && WAVES == 4 ? 2 : 1)) void c
                 }
             }
     }
+    };
+    finish(acc, false);
+    if constexpr (KWB > 0) finish(acc2, true);
 
     // ---- store
     const int my = my0 + ty, mx = mx0 + tx, b = b0 + tb;
@@ -403,7 +431,16 @@ __global__ __launch_bounds__(64 * WAVES, (MT <= 4 && WAVES == 4 ? 2 : 1)) void c
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = 32 * m + 8 * (r >> 2) + 4 * khalf + (r & 3);
-                if (co < cout_here) o[co * plane] = apply_act(acc[m][r], g.act);
+                if (co < cout_here) {
+                    if constexpr (KWB > 0) {  // columns ox, ox + 1 (ox even, rows 8-byte aligned: host-checked)
+                        f32x2 v2;
+                        v2[0] = apply_act(acc[m][r], g.act);
+                        v2[1] = apply_act(acc2[m][r], g.act);
+                        *reinterpret_cast<f32x2 *>(o + co * plane) = v2;
+                    } else {
+                        o[co * plane] = apply_act(acc[m][r], g.act);
+                    }
+                }
             }
     }
 }
@@ -860,6 +897,7 @@ struct Phase {
     int oy0 = 0, ox0 = 0;
     int ck = 2, cin_pad = 0;        // channels per LDS stage of this launch, cin rounded up to it
     int kh = 0, kw = 0;             // the taps form a dense kh x kw grid, tap t at (t / kw, t % kw)
+    int kwb = 0;                    // > 0: fused column phases -- kh x kwb more taps (output column ox0 + 1) follow the kh x kw
     int waves = 4;                  // wavefronts per workgroup of this launch (32 positions each)
     signed char dy[kMaxTaps], dx[kMaxTaps];
     float *d_wpack = nullptr;
@@ -870,6 +908,7 @@ struct Chunk {  // <= 192 output channels handled by one launch family
     int co0 = 0, cout = 0, coutp = 0, mt = 0;
     int nsplit = 1;  // > 1: cout is cut into nsplit slices of coutp channels over gridDim.y
     std::vector<Phase> phases;
+    std::vector<Phase> fused;  // stride-2 transposed convolutions: the column phases of each row phase as ONE launch (may be empty)
     float *d_bias = nullptr;
 };
 
@@ -890,6 +929,8 @@ extern "C" void basic_conv_plan_destroy(basic_conv_plan *p)
     for (auto *list : {&p->chunks, &p->split})
         for (auto &ch : *list) {
             for (auto &ph : ch.phases)
+                if (ph.d_wpack) (void)hipFree(ph.d_wpack);
+            for (auto &ph : ch.fused)
                 if (ph.d_wpack) (void)hipFree(ph.d_wpack);
             if (ch.d_bias) (void)hipFree(ch.d_bias);
         }
@@ -990,6 +1031,50 @@ int build_chunks(basic_conv_plan *p, const float *weight, const float *bias, int
                 ch.phases.push_back(ph);
                 if (rc) { out->push_back(ch); return rc; }
             }
+        // Fused column phases (see conv_tap_mfma_kernel, KWB): for every row phase py, the launch (py, px = 0) takes the
+        // taps of (py, px = 1) after its own.  Needs the second grid inside the first (same rows, columns shifted right
+        // by kw - kwb) -- true for the codec's k5 s2 p2 transposed convolutions -- and at most 4 accumulator tiles.
+        if (transposed && stride == 2 && !slice && ch.mt <= 4 && ch.phases.size() == 4) {
+            bool ok = true;
+            std::vector<Phase> fused;
+            for (int py = 0; py < 2 && ok; ++py) {
+                const Phase &a = ch.phases[py * 2], &b = ch.phases[py * 2 + 1];
+                ok = a.ntaps > 0 && b.ntaps > 0 && a.kh == b.kh && a.dymin == b.dymin && b.kw <= a.kw &&
+                     b.dxmin - a.dxmin == a.kw - b.kw && a.ox0 == 0 && b.ox0 == 1 && a.cin_pad % kFusedCK == 0 &&
+                     ((a.kh == 3 && a.kw == 3 && b.kw == 2) || (a.kh == 2 && a.kw == 3 && b.kw == 2));
+                if (!ok) break;
+                Phase f = a;
+                f.kwb = b.kw;
+                f.ntaps = a.ntaps + b.ntaps;
+                f.ck = kFusedCK;
+                f.waves = 4;
+                f.cin_pad = (ci_n + kFusedCK - 1) / kFusedCK * kFusedCK;
+                f.d_wpack = nullptr;
+                const int mtp = mtile_pitch(ch.mt);
+                f.split_wstride = static_cast<int64_t>(f.cin_pad) * f.ntaps * 32 * mtp;
+                std::vector<float> wp(static_cast<size_t>(f.split_wstride), 0.f);
+                // taps of a phase sit at grid position t = (dy - dymin) * kw + (dx - dxmin); recover (ky, kx) from the geometry
+                auto tap_weight = [&](int phase_px, int t, int kw_phase, int dymin_p, int dxmin_p, int c, int og) -> float {
+                    const int dyv = dymin_p + t / kw_phase, dxv = dxmin_p + t % kw_phase;
+                    const int ky = py + padding - dyv * stride, kx = phase_px + padding - dxv * stride;
+                    if (ky < 0 || ky >= ksize || kx < 0 || kx >= ksize) return 0.f;
+                    return weight[((static_cast<size_t>(c) * cout + og) * ksize + ky) * ksize + kx];
+                };
+                for (int c = 0; c < ci_n; ++c)
+                    for (int t = 0; t < f.ntaps; ++t)
+                        for (int o = 0; o < ch.cout; ++o) {
+                            const float w = t < a.ntaps ? tap_weight(0, t, a.kw, a.dymin, a.dxmin, c, co0 + o)
+                                                        : tap_weight(1, t - a.ntaps, b.kw, b.dymin, b.dxmin, c, co0 + o);
+                            wp[(((static_cast<size_t>(c / kFusedCK) * f.ntaps + t) * kFusedCK + (c % kFusedCK)) * 32 + o % 32) * mtp + o / 32] = w;
+                        }
+                wp.resize(wp.size() + 2048, 0.f);
+                const int rcf = upload(wp, &f.d_wpack);
+                fused.push_back(f);
+                if (rcf) { ok = false; }
+            }
+            if (ok) ch.fused = fused;
+            else for (auto &f : fused) if (f.d_wpack) (void)hipFree(f.d_wpack);
+        }
         std::vector<float> hb(static_cast<size_t>(ch.coutp) * ch.nsplit, 0.f);
         if (bias) std::memcpy(hb.data(), bias + co0, sizeof(float) * ch.cout);
         const int rc = upload(hb, &ch.d_bias);
@@ -1098,22 +1183,36 @@ extern "C" int64_t basic_conv_plan_flops(const basic_conv_plan *p, int batch, in
 
 namespace {
 
-template <int MT, int CK, int KH, int KW, int WAVES>
+template <int MT, int CK, int KH, int KW, int WAVES, int KWB = 0>
 int launch_one(const TapLaunch &g, int blocks, int nsplit, size_t lds_bytes, hipStream_t st)
 {
     static bool attr_set = false;
     if (!attr_set) {
-        BASIC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_tap_mfma_kernel<MT, CK, KH, KW, WAVES>),
+        BASIC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_tap_mfma_kernel<MT, CK, KH, KW, WAVES, KWB>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_tap_mfma_kernel<MT, CK, KH, KW, WAVES>), dim3(blocks, nsplit), dim3(64 * WAVES), lds_bytes, st, g);
+    hipLaunchKernelGGL((conv_tap_mfma_kernel<MT, CK, KH, KW, WAVES, KWB>), dim3(blocks, nsplit), dim3(64 * WAVES), lds_bytes, st, g);
     BASIC_HIP_TRY(hipGetLastError());
     return BASIC_OK;
 }
 
 // Unrolled instantiations for the tap grids of the codec's layers (5x5 and 3x3 convolutions, the four
 // sub-pixel phases of the 5x5 stride-2 transposed convolution); anything else takes the runtime tap table.
+template <int MT>
+int launch_fused(const TapLaunch &g, int kh, int kw, int kwb, int plan_ck, int plan_waves_, int blocks, size_t lds_bytes, hipStream_t st)
+{
+    BASIC_REQUIRE(plan_ck == kFusedCK && plan_waves_ == 4 && kw == 3 && kwb == 2 && (kh == 3 || kh == 2),
+                  "conv_forward: fused plan / kernel instantiation mismatch");
+    if constexpr (MT <= 4) {
+        if (kh == 3) return launch_one<MT, kFusedCK, 3, 3, 4, 2>(g, blocks, 1, lds_bytes, st);
+        return launch_one<MT, kFusedCK, 2, 3, 4, 2>(g, blocks, 1, lds_bytes, st);
+    } else {
+        set_error("conv_forward: fused phases need <= 4 accumulator tiles");
+        return BASIC_ERR_INVALID;
+    }
+}
+
 template <int MT>
 int launch_mt(const TapLaunch &g, int kh, int kw, int plan_ck, int plan_waves_, int blocks, int nsplit, size_t lds_bytes,
               hipStream_t st)
@@ -1144,6 +1243,40 @@ int pow2_ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
 }  // namespace
 
+namespace {
+// which launch list forward() walks for this input: 32-channel slices for small position grids, fused column phases when
+// the output rows allow 8-byte pair stores
+struct LaunchChoice { bool use_split, fuse_ok; int dbg; };
+LaunchChoice choose_launches(const basic_conv_plan *p, int batch, int oh, int ow, const void *d_out)
+{
+    const int64_t pos_blocks = (static_cast<int64_t>(batch) * ((oh + p->s_out - 1) / p->s_out) * ((ow + p->s_out - 1) / p->s_out) + kTilePos - 1) / kTilePos;
+    const char *dbg_env = getenv("BASIC_CONV_DEBUG");
+    // profiling ablations: 1 skip staging, 2 skip MFMA loop, 4 force slices, 8 forbid slices, 64 no persistent first layer,
+    // 128 no 16-byte patch pieces, 512 no fused column phases
+    const int dbg = dbg_env ? atoi(dbg_env) : 0;
+    LaunchChoice c;
+    c.dbg = dbg;
+    c.use_split = !p->split.empty() && !(dbg & 8) && (pos_blocks < kSplitBelowBlocks || (dbg & 4));
+    c.fuse_ok = !c.use_split && ow % 2 == 0 && (reinterpret_cast<uintptr_t>(d_out) & 7) == 0 && !(dbg & 512);
+    return c;
+}
+}  // namespace
+
+extern "C" int basic_conv_plan_launches(const basic_conv_plan *p, int batch, int in_h, int in_w)
+{
+    int oh = 0, ow = 0;
+    if (!p || batch < 1 || basic_conv_plan_out_hw(p, in_h, in_w, &oh, &ow)) return -1;
+    if (p->d_wsm) return 1;
+    const LaunchChoice c = choose_launches(p, batch, oh, ow, nullptr);
+    int n = 0;
+    for (const Chunk &ch : (c.use_split ? p->split : p->chunks))
+        for (const Phase &ph : ((c.fuse_ok && !ch.fused.empty()) ? ch.fused : ch.phases)) {
+            const int mh = (oh - ph.oy0 + p->s_out - 1) / p->s_out, mw = (ow - ph.ox0 + p->s_out - 1) / p->s_out;
+            if (mh > 0 && mw > 0) ++n;
+        }
+    return n;
+}
+
 extern "C" int basic_conv_forward_dev(const basic_conv_plan *p, const float *d_in, int batch, int in_h, int in_w,
                                       float *d_out, void *hip_stream)
 {
@@ -1165,13 +1298,13 @@ extern "C" int basic_conv_forward_dev(const basic_conv_plan *p, const float *d_i
         BASIC_HIP_TRY(hipGetLastError());
         return BASIC_OK;
     }
-    // small position grids: spread the output channels over gridDim.y instead of looping them inside a block
-    const int64_t pos_blocks = (static_cast<int64_t>(batch) * ((oh + p->s_out - 1) / p->s_out) * ((ow + p->s_out - 1) / p->s_out) + kTilePos - 1) / kTilePos;
-    const char *dbg_env = getenv("BASIC_CONV_DEBUG");
-    const int dbg = dbg_env ? atoi(dbg_env) : 0;  // profiling ablations: 1 skip staging, 2 skip MFMA loop, 4 force slices, 8 forbid slices
-    const bool use_split = !p->split.empty() && !(dbg & 8) && (pos_blocks < kSplitBelowBlocks || (dbg & 4));
+    // small position grids: spread the output channels over gridDim.y instead of looping them inside a block;
+    // fused column phases: even output width (both phases have the same m-grid) and 8-byte aligned rows for the pair stores
+    const LaunchChoice choice = choose_launches(p, batch, oh, ow, d_out);
+    const int dbg = choice.dbg;
+    const bool use_split = choice.use_split, fuse_ok = choice.fuse_ok;
     for (const Chunk &ch : (use_split ? p->split : p->chunks))
-    for (const Phase &ph : ch.phases) {
+    for (const Phase &ph : ((fuse_ok && !ch.fused.empty()) ? ch.fused : ch.phases)) {
         TapLaunch g{};
         g.in = d_in; g.out = d_out; g.wpack = ph.d_wpack; g.split_wstride = ph.split_wstride; g.bias = ch.d_bias; g.gammaT = p->d_gammaT; g.beta = p->d_beta;
         g.batch = batch; g.cin = p->cin; g.cin_pad = ph.ntaps ? ph.cin_pad : 0; g.cout = ch.cout; g.coutp = ch.coutp; g.out_ctotal = p->cout; g.co_base = ch.co0;
@@ -1210,13 +1343,14 @@ extern "C" int basic_conv_forward_dev(const basic_conv_plan *p, const float *d_i
             return sizeof(float) * (2 * static_cast<size_t>(wl_pad + patch_pad) + 32 + 2 * g.coutp);  // + tap table, bias, beta
         };
         // the patch must fit the gather descriptors and both stage buffers the LDS
-        while (tb > 1 && (patch_slots_needed(tb) > patch_slots(ch.mt) || lds_need(tb) > 160 * 1024)) tb >>= 1;
+        const int slots_avail = ph.kwb ? kPSlotsFused : patch_slots(ch.mt);
+        while (tb > 1 && (patch_slots_needed(tb) > slots_avail || lds_need(tb) > 160 * 1024)) tb >>= 1;
         g.tw_log = ilog2(tw); g.th_log = ilog2(th); g.tb_log = ilog2(tb);
         g.tiles_y = (g.mh + th - 1) / th;
         g.tiles_x = (g.mw + tw - 1) / tw;
         const int blocks = ((batch + tb - 1) / tb) * g.tiles_y * g.tiles_x;
         const size_t lds_bytes = lds_need(tb);
-        BASIC_REQUIRE(patch_slots_needed(tb) <= patch_slots(ch.mt), "conv_forward: input patch exceeds the gather descriptors");
+        BASIC_REQUIRE(patch_slots_needed(tb) <= slots_avail, "conv_forward: input patch exceeds the gather descriptors");
         BASIC_REQUIRE(static_cast<int64_t>(tb) * p->cin * in_h * in_w < (1ll << 29), "conv_forward: input tile too large");
         BASIC_REQUIRE(lds_bytes <= 160 * 1024, "conv_forward: LDS budget exceeded");
         hipStream_t st = as_stream(hip_stream);
@@ -1239,6 +1373,17 @@ extern "C" int basic_conv_forward_dev(const basic_conv_plan *p, const float *d_i
                 BASIC_HIP_TRY(hipGetLastError());
                 continue;
             }
+        }
+        if (ph.kwb) {
+            switch (ch.mt) {
+                case 1: rc = launch_fused<1>(g, ph.kh, ph.kw, ph.kwb, ph.ck, ph.waves, blocks, lds_bytes, st); break;
+                case 2: rc = launch_fused<2>(g, ph.kh, ph.kw, ph.kwb, ph.ck, ph.waves, blocks, lds_bytes, st); break;
+                case 3: rc = launch_fused<3>(g, ph.kh, ph.kw, ph.kwb, ph.ck, ph.waves, blocks, lds_bytes, st); break;
+                case 4: rc = launch_fused<4>(g, ph.kh, ph.kw, ph.kwb, ph.ck, ph.waves, blocks, lds_bytes, st); break;
+                default: set_error("conv_forward: fused phases need <= 4 accumulator tiles"); rc = BASIC_ERR_INVALID;
+            }
+            if (rc) return rc;
+            continue;
         }
         switch (ch.mt) {
             case 1: rc = launch_mt<1>(g, ph.kh, ph.kw, ph.ck, ph.waves, blocks, ch.nsplit, lds_bytes, st); break;

@@ -72,6 +72,10 @@ class ConvPlan:
     def flops(self, batch, h, w):
         return int(_lib.lib().basic_conv_plan_flops(self._h, int(batch), int(h), int(w)))
 
+    def launches(self, batch, h, w):
+        """Kernel launches of one forward call on a [batch, cin, h, w] input."""
+        return int(_lib.lib().basic_conv_plan_launches(self._h, int(batch), int(h), int(w)))
+
     def __call__(self, x, out=None):
         x = _dev(x, torch.float32)
         B, C, H, W = x.shape

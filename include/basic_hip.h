@@ -209,6 +209,9 @@ int basic_conv_forward_dev(const basic_conv_plan *p, const float *d_in, int batc
 void basic_conv_plan_destroy(basic_conv_plan *p);
 /* 2*MACs of one forward (conv + GDN), for roofline accounting. */
 int64_t basic_conv_plan_flops(const basic_conv_plan *p, int batch, int in_h, int in_w);
+/* Kernel launches one forward call makes for this input (sub-pixel phases of transposed convolutions, fused or not;
+ * 32-channel slices count once: they share a launch). -1 on bad arguments. */
+int basic_conv_plan_launches(const basic_conv_plan *p, int batch, int in_h, int in_w);
 
 /* ======================================================================================
  * 6. Topo-group masked convolution (TopoGroupDynamicMaskConv2d.forward,
