@@ -173,8 +173,14 @@ class GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(HotPathModule):
                  lower_bound_scale=0.11, quantizer_params=None, fixed_input_shape=None,
                  force_input_prior_shape_aligned=True, batch_stream_mode="auto", topo_group_predictor=None, **kwargs):
         super().__init__()
-        if use_joint_ar_model_impl:
-            raise NotImplementedError("use_joint_ar_model_impl (pgm_coder.py:1975-2070) is a 'next' row (SURVEY 8f rank 4)")
+        # use_joint_ar_model_impl (pgm_coder.py:1975-2070): raster-scan coding with a plain 1x1 entropy_parameters network
+        # on cat(prior, ctx) and "chunk" parameters (scales, then means).  Raster order IS the scanline schedule, so the
+        # coder runs on the same kernels: the layers are built from re-ordered views of the weights (_build_layers).
+        self.use_joint_ar_model_impl = bool(use_joint_ar_model_impl)
+        if self.use_joint_ar_model_impl:
+            if channel_groups != 1 or topo_group_context_model is not None or not use_param_merger:
+                raise ValueError("use_joint_ar_model_impl needs channel_groups == 1, the built-in context model and the param merger")
+            default_topo_group_method = "scanline"
         if not use_autoregressive_encode:
             raise NotImplementedError("use_autoregressive_encode=False")
         if quantizer_params is not None and list(quantizer_params)[0::2] != [0.0, 1.0]:
@@ -207,7 +213,11 @@ class GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(HotPathModule):
             self.conv_kernel_bias = nn.Parameter(torch.zeros(C2))
             self.context_prediction = TopoGroupDynamicMaskConv2d(in_channels, C2, kernel_size, padding=self.padding,
                                                                 dynamic_channel_groups=G)
-            if use_param_merger:
+            if use_param_merger and self.use_joint_ar_model_impl:  # (:1204-1212)
+                self.entropy_parameters = nn.Sequential(
+                    nn.Conv2d(C2 * 2, C2 * 5 // 3, 1), nn.LeakyReLU(inplace=True),
+                    nn.Conv2d(C2 * 5 // 3, C2 * 4 // 3, 1), nn.LeakyReLU(inplace=True), nn.Conv2d(C2 * 4 // 3, C2, 1))
+            elif use_param_merger:
                 bott = C2 * 4 if param_merger_expand_bottleneck else C2 * 2
                 mk = lambda i, o: TopoGroupDynamicMaskConv2d(i, o, 1, dynamic_channel_groups=G * 2, allow_same_topogroup_conv=True)
                 self.param_merger = nn.Sequential(mk(C2 * 2, bott), nn.LeakyReLU(inplace=True), mk(bott, bott),
@@ -259,7 +269,20 @@ class GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(HotPathModule):
         if cm is None:
             cp = self.context_prediction
             L["ctx"] = K.MaskedConvPlan(cp.weight, cp.bias, G, G, False)
-            if self.use_param_merger:
+            if self.use_param_merger and self.use_joint_ar_model_impl:
+                e = self.entropy_parameters
+                C = self.in_channels
+                # first layer: the reference feeds cat(prior, ctx) (:1619), the workspace holds cat(ctx, prior)
+                w0 = torch.cat([e[0].weight[:, C2:], e[0].weight[:, :C2]], 1)
+                # last layer: "chunk" output (scales 0..C-1, means C..2C-1) -> the interleaved (mean, scale) pairs the
+                # Gaussian kernels read
+                order = torch.stack([torch.arange(C, 2 * C), torch.arange(0, C)], 1).reshape(-1)
+                L["m"] = [
+                    (K.MaskedConvPlan(w0, e[0].bias, 1, 1, True, K.ACT_LEAKY_RELU), "pgm", "pgm"),
+                    (K.MaskedConvPlan(e[2].weight, e[2].bias, 1, 1, True, K.ACT_LEAKY_RELU), "pgm", "pgm"),
+                    (K.MaskedConvPlan(e[4].weight[order], e[4].bias[order], 1, 1, True, K.ACT_NONE), "pgm", "pgm"),
+                ]
+            elif self.use_param_merger:
                 m = self.param_merger
                 L["m"] = [
                     (K.MaskedConvPlan(m[0].weight, m[0].bias, 2 * G, 2 * G, True, K.ACT_LEAKY_RELU), "cat", "cat"),

@@ -144,10 +144,15 @@ class TopoGroupGaussianOracle:
     """GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder on the CPU, from a state_dict."""
 
     def __init__(self, sd, in_channels, channel_groups=1, method="none", expand_bottleneck=False, use_param_merger=True,
-                 context_model=False, pgm=None):
+                 context_model=False, pgm=None, joint_ar=False):
         self.sd = {k: v.detach().float().cpu() for k, v in sd.items()}
         self.C, self.method = in_channels, method
         self.pgm = pgm  # supplied / learned topo groups (integer map or logits); None = the default pattern
+        # use_joint_ar_model_impl (pgm_coder.py:1975-2070): raster-scan order (= the scanline groups), a plain 1x1
+        # entropy_parameters network on cat(prior, ctx) (:1619-1620) and "chunk" parameters, scales first (:1047-1048)
+        self.joint_ar = joint_ar
+        if joint_ar:
+            self.method = "scanline"
         self.G = in_channels // 16 if method in ("elic", "channelwise-g10") else channel_groups
         self.use_param_merger, self.context_model = use_param_merger, context_model
         self.table = scale_table()
@@ -174,6 +179,13 @@ class TopoGroupGaussianOracle:
         ctx = masked_conv(buf, sd["context_prediction.weight"], sd["context_prediction.bias"], pgm)
         if prior is None:
             prior = torch.zeros_like(ctx)
+        if self.joint_ar:
+            x = torch.cat([prior, ctx], 1)
+            for i in (0, 2, 4):
+                x = F.conv2d(x, sd[f"entropy_parameters.{i}.weight"], sd[f"entropy_parameters.{i}.bias"])
+                if i < 4:
+                    x = F.leaky_relu(x)
+            return x
         if not self.use_param_merger:
             return ctx + prior
         cat = torch.cat([ctx, prior], 1)
@@ -191,6 +203,9 @@ class TopoGroupGaussianOracle:
         return default_pgm(self.method, self.G, H, W)
 
     def _split(self, params):
+        if self.joint_ar:  # chunk + inverse_mean_scale: scales, then means
+            half = params.shape[1] // 2
+            return params[:, half:], params[:, :half]
         p = params.reshape(params.shape[0], params.shape[1] // 2, 2, *params.shape[2:])
         return p[:, :, 0], p[:, :, 1]  # split_interleave: mean, scale
 

@@ -438,9 +438,51 @@ def ar_coder_pgm():
         print(f"  combined sel {sel}: {len(data)} bytes")
     save("ar_coder_pgm.npz", **out)
 
+# ---------------------------------------------------------------- 10. joint-AR raster implementation (use_joint_ar_model_impl)
+def ar_coder_joint():
+    """pgm_coder.py:1975-2070: raster-scan coding with the plain 1x1 entropy_parameters network on cat(prior, ctx) and
+    "chunk" parameters (scales first, then means)."""
+    out, keys = {}, []
+    for i, (C, B, H, W) in enumerate([(16, 1, 4, 5), (16, 2, 3, 3), (32, 1, 2, 6)]):
+        coder = GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(in_channels=C, use_joint_ar_model_impl=True).eval()
+        names, shapes = [], []
+        torch.manual_seed(500 + i)
+        with torch.no_grad():
+            for name, p in coder.named_parameters():
+                p.copy_(torch.randn(p.shape) * (0.05 if p.dim() > 1 else 0.02))
+                names.append(name)
+                shapes.append(",".join(str(d) for d in p.shape))
+        coder.update_state()
+        gen = torch.Generator().manual_seed(600 + i)
+        y = torch.randn(B, C, H, W, generator=gen) * 3
+        # "chunk" layout with inverse_mean_scale: first C channels scales, last C channels means; the prior feeds the
+        # entropy_parameters network, so any values do -- kept positive-ish in the scale half for realism
+        prior = torch.cat([torch.rand(B, C, H, W, generator=gen) * 4 + 0.2, torch.randn(B, C, H, W, generator=gen)], 1)
+        captured = {}
+        orig = coder.ans_encoder
+
+        class Spy:
+            def encode_with_indexes(self, data, indexes, **k):
+                captured["symbols"], captured["indexes"] = np.array(data), np.array(indexes)
+                return orig.encode_with_indexes(data, indexes, **k)
+        coder.ans_encoder = Spy()
+        with torch.no_grad():
+            data = coder.encode(y, prior=prior)
+            yhat = coder.decode(data, prior=prior)
+        k = f"j{i}"
+        out.update({f"{k}.pnames": np.array(names), f"{k}.pshapes": np.array(shapes),
+                    f"{k}.wsum": np.array([float(sum(p.detach().double().sum() for p in coder.parameters()))]),
+                    f"{k}.y": y.numpy(), f"{k}.prior": prior.numpy(), f"{k}.bytes": b2a(data),
+                    f"{k}.symbols": captured["symbols"].astype(np.int32).reshape(-1), f"{k}.indexes": captured["indexes"].astype(np.int32).reshape(-1),
+                    f"{k}.yhat": yhat.numpy(), f"{k}.cfg": np.array([C, B, H, W])})
+        keys.append(k)
+        print(f"  {k}: {len(data)} bytes, max|yhat-y| {float((yhat - y).abs().max()):.3f}, params {names}")
+    out["keys"] = np.array(keys)
+    save("ar_coder_joint.npz", **out)
+
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["rans", "tables", "topo", "mconv", "ar", "framing", "harness", "search", "arpgm"]
-    fn = dict(rans=rans_kats, tables=gauss_tables, topo=topo_maps, mconv=masked_conv, ar=ar_coder, framing=framing, harness=harness, search=complexity_search, arpgm=ar_coder_pgm)
+    which = sys.argv[1:] or ["rans", "tables", "topo", "mconv", "ar", "framing", "harness", "search", "arpgm", "arjoint"]
+    fn = dict(rans=rans_kats, tables=gauss_tables, topo=topo_maps, mconv=masked_conv, ar=ar_coder, framing=framing, harness=harness, search=complexity_search, arpgm=ar_coder_pgm, arjoint=ar_coder_joint)
     for w in which:
         fn[w]()

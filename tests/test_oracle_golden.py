@@ -199,6 +199,21 @@ def test_ar_coder_supplied_topo_groups_match_reference():
         assert data == z[f"comb.bytes{sel}"].tobytes(), sel
 
 
+def test_ar_coder_joint_impl_matches_reference():
+    """use_joint_ar_model_impl (raster scan, entropy_parameters on cat(prior, ctx), chunk parameters)."""
+    from oracle.pgm_oracle import TopoGroupGaussianOracle
+    z = load("ar_coder_joint.npz")
+    for k in z["keys"]:
+        sd = pgm_case(z, k, 500 + int(str(k)[1:]))
+        C, B, H, W = (int(v) for v in z[f"{k}.cfg"])
+        o = TopoGroupGaussianOracle(sd, C, joint_ar=True)
+        y, prior = torch.from_numpy(z[f"{k}.y"]), torch.from_numpy(z[f"{k}.prior"])
+        data, sym, idx, buf = o.encode(y, prior)
+        assert np.array_equal(sym, z[f"{k}.symbols"]) and np.array_equal(idx, z[f"{k}.indexes"]), k
+        assert data == z[f"{k}.bytes"].tobytes(), k
+        assert torch.allclose(o.decode(data, prior, tuple(y.shape)), torch.from_numpy(z[f"{k}.yhat"]), atol=1e-5), k
+
+
 def test_framing():
     from cbench_basic_amd.utils.bytes_ops import merge_bytes, split_merged_bytes, encode_shape, decode_shape
     z = load("framing.npz")
