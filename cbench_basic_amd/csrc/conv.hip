@@ -1034,7 +1034,7 @@ int build_chunks(basic_conv_plan *p, const float *weight, const float *bias, int
         // Fused column phases (see conv_tap_mfma_kernel, KWB): for every row phase py, the launch (py, px = 0) takes the
         // taps of (py, px = 1) after its own.  Needs the second grid inside the first (same rows, columns shifted right
         // by kw - kwb) -- true for the codec's k5 s2 p2 transposed convolutions -- and at most 4 accumulator tiles.
-        if (transposed && stride == 2 && !slice && ch.mt <= 4 && ch.phases.size() == 4) {
+        if (transposed && stride == 2 && ch.mt <= 4 && ch.phases.size() == 4) {
             bool ok = true;
             std::vector<Phase> fused;
             for (int py = 0; py < 2 && ok; ++py) {
@@ -1052,7 +1052,7 @@ int build_chunks(basic_conv_plan *p, const float *weight, const float *bias, int
                 f.d_wpack = nullptr;
                 const int mtp = mtile_pitch(ch.mt);
                 f.split_wstride = static_cast<int64_t>(f.cin_pad) * f.ntaps * 32 * mtp;
-                std::vector<float> wp(static_cast<size_t>(f.split_wstride), 0.f);
+                std::vector<float> wp(static_cast<size_t>(f.split_wstride) * ch.nsplit, 0.f);  // [slice][stage][tap][CK][32][MTP]
                 // taps of a phase sit at grid position t = (dy - dymin) * kw + (dx - dxmin); recover (ky, kx) from the geometry
                 auto tap_weight = [&](int phase_px, int t, int kw_phase, int dymin_p, int dxmin_p, int c, int og) -> float {
                     const int dyv = dymin_p + t / kw_phase, dxv = dxmin_p + t % kw_phase;
@@ -1065,7 +1065,9 @@ int build_chunks(basic_conv_plan *p, const float *weight, const float *bias, int
                         for (int o = 0; o < ch.cout; ++o) {
                             const float w = t < a.ntaps ? tap_weight(0, t, a.kw, a.dymin, a.dxmin, c, co0 + o)
                                                         : tap_weight(1, t - a.ntaps, b.kw, b.dymin, b.dxmin, c, co0 + o);
-                            wp[(((static_cast<size_t>(c / kFusedCK) * f.ntaps + t) * kFusedCK + (c % kFusedCK)) * 32 + o % 32) * mtp + o / 32] = w;
+                            const int ol = o % ch.coutp;
+                            wp[static_cast<size_t>(o / ch.coutp) * f.split_wstride +
+                               (((static_cast<size_t>(c / kFusedCK) * f.ntaps + t) * kFusedCK + (c % kFusedCK)) * 32 + ol % 32) * mtp + ol / 32] = w;
                         }
                 wp.resize(wp.size() + 2048, 0.f);
                 const int rcf = upload(wp, &f.d_wpack);
@@ -1200,13 +1202,13 @@ int launch_one(const TapLaunch &g, int blocks, int nsplit, size_t lds_bytes, hip
 // Unrolled instantiations for the tap grids of the codec's layers (5x5 and 3x3 convolutions, the four
 // sub-pixel phases of the 5x5 stride-2 transposed convolution); anything else takes the runtime tap table.
 template <int MT>
-int launch_fused(const TapLaunch &g, int kh, int kw, int kwb, int plan_ck, int plan_waves_, int blocks, size_t lds_bytes, hipStream_t st)
+int launch_fused(const TapLaunch &g, int kh, int kw, int kwb, int plan_ck, int plan_waves_, int blocks, int nsplit, size_t lds_bytes, hipStream_t st)
 {
     BASIC_REQUIRE(plan_ck == kFusedCK && plan_waves_ == 4 && kw == 3 && kwb == 2 && (kh == 3 || kh == 2),
                   "conv_forward: fused plan / kernel instantiation mismatch");
     if constexpr (MT <= 4) {
-        if (kh == 3) return launch_one<MT, kFusedCK, 3, 3, 4, 2>(g, blocks, 1, lds_bytes, st);
-        return launch_one<MT, kFusedCK, 2, 3, 4, 2>(g, blocks, 1, lds_bytes, st);
+        if (kh == 3) return launch_one<MT, kFusedCK, 3, 3, 4, 2>(g, blocks, nsplit, lds_bytes, st);
+        return launch_one<MT, kFusedCK, 2, 3, 4, 2>(g, blocks, nsplit, lds_bytes, st);
     } else {
         set_error("conv_forward: fused phases need <= 4 accumulator tiles");
         return BASIC_ERR_INVALID;
@@ -1257,7 +1259,7 @@ LaunchChoice choose_launches(const basic_conv_plan *p, int batch, int oh, int ow
     LaunchChoice c;
     c.dbg = dbg;
     c.use_split = !p->split.empty() && !(dbg & 8) && (pos_blocks < kSplitBelowBlocks || (dbg & 4));
-    c.fuse_ok = !c.use_split && ow % 2 == 0 && (reinterpret_cast<uintptr_t>(d_out) & 7) == 0 && !(dbg & 512);
+    c.fuse_ok = ow % 2 == 0 && (reinterpret_cast<uintptr_t>(d_out) & 7) == 0 && !(dbg & 512);
     return c;
 }
 }  // namespace
@@ -1376,10 +1378,10 @@ extern "C" int basic_conv_forward_dev(const basic_conv_plan *p, const float *d_i
         }
         if (ph.kwb) {
             switch (ch.mt) {
-                case 1: rc = launch_fused<1>(g, ph.kh, ph.kw, ph.kwb, ph.ck, ph.waves, blocks, lds_bytes, st); break;
-                case 2: rc = launch_fused<2>(g, ph.kh, ph.kw, ph.kwb, ph.ck, ph.waves, blocks, lds_bytes, st); break;
-                case 3: rc = launch_fused<3>(g, ph.kh, ph.kw, ph.kwb, ph.ck, ph.waves, blocks, lds_bytes, st); break;
-                case 4: rc = launch_fused<4>(g, ph.kh, ph.kw, ph.kwb, ph.ck, ph.waves, blocks, lds_bytes, st); break;
+                case 1: rc = launch_fused<1>(g, ph.kh, ph.kw, ph.kwb, ph.ck, ph.waves, blocks, ch.nsplit, lds_bytes, st); break;
+                case 2: rc = launch_fused<2>(g, ph.kh, ph.kw, ph.kwb, ph.ck, ph.waves, blocks, ch.nsplit, lds_bytes, st); break;
+                case 3: rc = launch_fused<3>(g, ph.kh, ph.kw, ph.kwb, ph.ck, ph.waves, blocks, ch.nsplit, lds_bytes, st); break;
+                case 4: rc = launch_fused<4>(g, ph.kh, ph.kw, ph.kwb, ph.ck, ph.waves, blocks, ch.nsplit, lds_bytes, st); break;
                 default: set_error("conv_forward: fused phases need <= 4 accumulator tiles"); rc = BASIC_ERR_INVALID;
             }
             if (rc) return rc;
