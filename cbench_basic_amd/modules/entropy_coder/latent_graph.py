@@ -24,7 +24,7 @@ import torch.nn as nn
 from ...base import HotPathModule
 from ...codecs.base import (VariableComplexityCodecInterface, VariableRateCodecInterface,
                             VariableTaskCodecInterface)
-from ...utils.bytes_ops import merge_bytes, split_merged_bytes
+from ...utils.bytes_ops import merge_bodies, merge_bytes, split_merged_bytes, split_merged_views
 from .complexity_search import search_complexity_levels
 
 
@@ -307,7 +307,7 @@ class LatentGraphicalANSEntropyCoder(HotPathModule, VariableRateCodecInterface, 
                     if len(priors) == 1:
                         pk.update(prior=list(priors.values())[0])
                 with self.profiler.start_time_profile(f"latent_node_entropy_coders_{node}"):
-                    if isinstance(node_data, bytes):
+                    if isinstance(node_data, (bytes, memoryview)):
                         node_data = coder.decode(node_data, **pk)
                         data[node] = node_data
                     else:
@@ -356,14 +356,20 @@ class LatentGraphicalANSEntropyCoder(HotPathModule, VariableRateCodecInterface, 
             with self.profiler.start_time_profile("encode_generative"):
                 data_dict, _ = self._generative_process(latent_dict, prior_dict=prior_dict, do_encode=True)
             nodes = self._coded_nodes()
-            bodies = [data_dict[n].result() if hasattr(data_dict[n], "result") else data_dict[n] for n in nodes]
+            bodies = [data_dict[n] for n in nodes]
+            if any(hasattr(b, "write_into") for b in bodies):
+                return merge_bodies(bodies)  # = merge_bytes(..., num_segments=len(nodes)), bodies framed in place
+            bodies = [b.result() if hasattr(b, "result") else b for b in bodies]
             return merge_bytes(bodies, num_segments=len(nodes))
 
     def decode(self, data, *args, prior=None, **kwargs):
         with torch.no_grad():
             node_dict = self._node_generate_process(**self._get_default_node_dict(force_add_default_dynamic_nodes=True, **kwargs))
             nodes = self._coded_nodes()
-            input_dict = dict(zip(nodes, split_merged_bytes(data, num_segments=len(nodes))))
+            # coders that read their stream through the buffer protocol get it in place; others get bytes
+            segs = split_merged_views(data, num_segments=len(nodes))
+            input_dict = {n: (v if getattr(self.latent_node_entropy_coders[n], "accepts_buffer", False) else v.tobytes())
+                          for n, v in zip(nodes, segs)}
             prior_dict = dict() if prior is None else {self.DEFAULT_INPUT_NODE_NAME: dict(prior=prior)}
             if self.use_lossy_compression:
                 input_dict[self.DEFAULT_INPUT_NODE_NAME] = b""

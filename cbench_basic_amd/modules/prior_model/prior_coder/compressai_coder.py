@@ -50,9 +50,23 @@ class PendingBody:
     def __init__(self, tables, handle, shape_hw):
         self._tables, self._handle, self._shape = tables, handle, tuple(int(v) for v in shape_hw)
 
+    def _end(self):
+        if self._handle is not None:
+            self._host, self._off = self._tables.encode_batch_end(self._handle)  # the one host synchronisation
+            self._handle = None
+        return self._host, self._off
+
     def result(self) -> bytes:
-        host, off = self._tables.encode_batch_end(self._handle)
+        host, off = self._end()
         return K.frame_streams(host, off, self._shape)
+
+    def nbytes(self) -> int:
+        return K.frame_streams_size(self._end()[1])
+
+    def write_into(self, address: int, capacity: int) -> int:
+        """Frame the streams directly into caller memory (the codec's final bytes object): one copy instead of three."""
+        host, off = self._end()
+        return K.frame_streams_into(host, off, self._shape, address, capacity)
 
 
 def read_body(data: bytes, segments=1):
@@ -190,6 +204,7 @@ class CompressAIEntropyBottleneckPriorCoder(HotPathModule):
         return zhat
 
     supports_lazy_encode = True
+    accepts_buffer = True  # decode() reads the stream through the buffer protocol (bytes or memoryview)
 
     def encode(self, input, *args, channel_gains=None, channel_gains_inv=None, lazy=False, **kwargs) -> bytes:  # :230-236
         self._ready()
@@ -302,6 +317,7 @@ class CompressAIGaussianConditionalCoder(HotPathModule):
         return yhat
 
     supports_lazy_encode = True
+    accepts_buffer = True  # decode() reads the stream through the buffer protocol (bytes or memoryview)
 
     def encode(self, y, *args, prior=None, channel_gains=None, channel_gains_inv=None, lazy=False, **kwargs):  # :377-385
         self._ready()

@@ -166,6 +166,8 @@ class _GroupPlan:
 
 
 class GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(HotPathModule):
+    accepts_buffer = True  # decode() reads the stream through the buffer protocol (bytes or memoryview)
+
     def __init__(self, *args, in_channels=256, channel_groups=1, default_topo_group_method="none", default_num_topo_groups=-1,
                  topo_group_context_model: Optional[TopoGroupDynamicMaskConv2dContextModel] = None, kernel_size=5,
                  use_param_merger=True, use_joint_ar_model_impl=False, param_merger_expand_bottleneck=False,
@@ -613,6 +615,8 @@ class CombinedNNTrainablePGMPriorCoder(HotPathModule):
     """pgm_coder.py:632-715: a bank of prior coders of which ``blend_weight`` (a one-hot from a controller node, e.g.
     BaSIC's ``pgmy``) selects one per call -- the entropy-coder side of BaSIC's complexity scaling (scanline AR down to
     2-stage grouped coders, configs/presets/lossy_latent_graph_scalable_ar_models.py:198-372)."""
+
+    accepts_buffer = True
 
     def __init__(self, coders, *args, blend_weight_one_hot_threshold=0.9, fix_weight=False, training_use_max_capacity=False,
                  **kwargs):

@@ -357,6 +357,22 @@ def frame_streams(host_words, word_off, shape_hw) -> bytes:
     return out[: out_len.value].tobytes()
 
 
+def frame_streams_size(word_off) -> int:
+    """Bytes frame_streams() writes for these streams."""
+    n = len(word_off) - 1
+    return 12 + 4 * n + 4 * int(word_off[-1] - word_off[0])
+
+
+def frame_streams_into(host_words, word_off, shape_hw, address: int, capacity: int) -> int:
+    """frame_streams() straight into caller memory (e.g. the final bytes object of a codec): returns the length."""
+    host_words = np.ascontiguousarray(host_words, dtype=np.uint32)
+    word_off = np.ascontiguousarray(word_off, dtype=np.int64)
+    out_len = ctypes.c_int64()
+    _lib.check(_lib.lib().basic_frame_streams(host_words.ctypes.data, word_off.ctypes.data, len(word_off) - 1, int(shape_hw[0]),
+                                              int(shape_hw[1]), address, capacity, ctypes.byref(out_len)))
+    return out_len.value
+
+
 def frame_header(data: bytes):
     """(h, w, n streams) of a framed body."""
     buf = np.frombuffer(data, dtype=np.uint8)

@@ -57,3 +57,52 @@ def decode_shape(byte_string: bytes):
     n = byte_string[0]
     dims = list(struct.unpack("<%dH" % n, byte_string[1:1 + 2 * n]))
     return dims, 1 + 2 * n
+
+
+def split_merged_views(data, num_bytes_length=4, num_segments: Optional[int] = None) -> List[memoryview]:
+    """split_merged_bytes without copying the segments (memoryviews into ``data``): the multi-megabyte latent stream of a
+    batch is handed to the decoder in place."""
+    fmt = _fmt(num_bytes_length)
+    view = memoryview(data)
+    out, cur, total = [], 0, len(view)
+    while cur < total:
+        if num_segments is not None and len(out) >= num_segments - 1:
+            out.append(view[cur:])
+            cur = total
+        else:
+            (n,) = struct.unpack_from(fmt, view, cur)
+            cur += num_bytes_length
+            out.append(view[cur:cur + n])
+            cur += n
+    if num_segments is not None:
+        out.extend([memoryview(b"")] * (num_segments - len(out)))
+    return out
+
+
+def merge_bodies(bodies, num_bytes_length=4) -> bytes:
+    """merge_bytes(bodies, num_segments=len(bodies)) for bodies that are either ``bytes`` or objects with ``nbytes()`` /
+    ``write_into(address, capacity)`` (PendingBody): the result is allocated once and every body is written into it in
+    place -- the same bytes as merge_bytes would produce from the bodies' ``result()``."""
+    import ctypes
+    fmt = _fmt(num_bytes_length)
+    sizes = [len(b) if isinstance(b, (bytes, bytearray, memoryview)) else b.nbytes() for b in bodies]
+    total = sum(sizes) + num_bytes_length * (len(bodies) - 1)
+    api = ctypes.pythonapi
+    api.PyBytes_FromStringAndSize.restype, api.PyBytes_FromStringAndSize.argtypes = ctypes.py_object, [ctypes.c_char_p, ctypes.c_ssize_t]
+    api.PyBytes_AsString.restype, api.PyBytes_AsString.argtypes = ctypes.c_void_p, [ctypes.py_object]
+    out = api.PyBytes_FromStringAndSize(None, total)     # fresh, unshared bytes object: filling it in place is legal
+    base = api.PyBytes_AsString(out)
+    cur = 0
+    for i, (b, n) in enumerate(zip(bodies, sizes)):
+        if i < len(bodies) - 1:
+            ctypes.memmove(base + cur, struct.pack(fmt, n), num_bytes_length)
+            cur += num_bytes_length
+        if isinstance(b, (bytes, bytearray, memoryview)):
+            if n:
+                ctypes.memmove(base + cur, bytes(b) if isinstance(b, memoryview) else b, n)
+        else:
+            written = b.write_into(base + cur, n)
+            assert written == n, (written, n)
+        cur += n
+    assert cur == total
+    return out

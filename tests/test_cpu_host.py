@@ -304,3 +304,34 @@ def test_supplied_topo_group_maps_host_logic():
         assert got.shape == (G, H, W) and np.array_equal(got, want), (case, G, ph, pw, H, W)
     with pytest.raises(ValueError):
         Coder(in_channels=16, channel_groups=2)._topo_from_pgm(torch.zeros(1, 3, 2, 2, dtype=torch.long), 4, 4)
+
+
+def test_in_place_merge_and_zero_copy_split_match_the_reference_framing():
+    """merge_bodies / split_merged_views (in-place framing of the codec's final bytes object, zero-copy hand-over to the
+    decoders) produce exactly what merge_bytes / split_merged_bytes do."""
+    import ctypes
+    from cbench_basic_amd.utils.bytes_ops import merge_bodies, merge_bytes, split_merged_bytes, split_merged_views
+
+    class Body:  # stands in for PendingBody: knows its size, writes itself into caller memory
+        def __init__(self, payload):
+            self.payload = payload
+
+        def nbytes(self):
+            return len(self.payload)
+
+        def write_into(self, address, capacity):
+            assert capacity == len(self.payload)
+            ctypes.memmove(address, self.payload, len(self.payload))
+            return len(self.payload)
+
+    rng = np.random.default_rng(0)
+    for sizes in ([5, 0, 300], [0, 0], [1], [4096, 17], [0, 123456]):
+        segs = [rng.integers(0, 256, n, dtype=np.uint8).tobytes() for n in sizes]
+        want = merge_bytes(segs, num_segments=len(segs))
+        for mix in range(2 ** len(segs)):
+            bodies = [Body(s) if (mix >> i) & 1 else s for i, s in enumerate(segs)]
+            got = merge_bodies(bodies)
+            assert type(got) is bytes and got == want, (sizes, mix)
+        views = split_merged_views(want, num_segments=len(segs))
+        assert [v.tobytes() for v in views] == split_merged_bytes(want, num_segments=len(segs)) == segs
+        assert all(isinstance(v, memoryview) for v in views)
