@@ -75,6 +75,32 @@ def test_conv_matches_torch(case):
     _close(got, ref)
 
 
+@pytest.mark.parametrize("case", [c for c in CASES if c[6] and c[1] > 4], ids=lambda c: str(c))
+def test_transposed_conv_unfused_and_sliced_paths(case, monkeypatch):
+    """The transposed convolutions normally run with their column phases fused (8-byte pair stores); the four-phase
+    fallback (BASIC_CONV_DEBUG bit 512: what runs when the output rows are not 8-byte aligned) and the forced / forbidden
+    32-channel-slice variants (bits 4 / 8) must give the same results."""
+    from cbench_basic_amd.nn import kernels as K
+    cin, cout, k, s, p, op, tr, act, B, H, W = case
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn((cin, cout, k, k), generator=g) * (1.0 / (cin * k * k) ** 0.5)
+    b = torch.randn(cout, generator=g) * 0.1
+    gamma = beta = None
+    if act == "igdn":
+        gamma = torch.rand(cout, cout, generator=g) * 0.02 + 0.1 * torch.eye(cout)
+        beta = torch.rand(cout, generator=g) + 0.5
+    ref = F.conv_transpose2d(x, w, b, stride=s, padding=p, output_padding=op)
+    ref = F.relu(ref) if act == "relu" else F.leaky_relu(ref) if act == "leaky" else _gdn_ref(ref, gamma, beta, True) if act == "igdn" else ref
+    code = dict(none=K.ACT_NONE, relu=K.ACT_RELU, leaky=K.ACT_LEAKY_RELU, igdn=K.ACT_IGDN)[act]
+    plan = K.ConvPlan(w, b, s, p, op, tr, code, gamma, beta)
+    for debug in ("512", "516", "520", "4", "8"):
+        monkeypatch.setenv("BASIC_CONV_DEBUG", debug)
+        got = plan(x.cuda())
+        torch.cuda.synchronize()
+        _close(got, ref)
+
+
 def _random_case(rng):
     """Random layer geometry, biased towards the kernels' special paths (8-wave 25-tap 128-channel convs, the persistent
     first layer, the VALU output layer, 32-channel slices on tiny grids, runtime tap tables for k in {1, 2, 4})."""
