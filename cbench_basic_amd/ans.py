@@ -172,6 +172,12 @@ class Rans64Decoder(_Rans64Base):
         self._close_stream()
         super().__del__()
 
+    def _free(self):
+        # an open stream points INTO the table set (basic_rans_stream.t): replacing or releasing the tables ends it
+        # (the reference would go on with the new tables; here set_stream() has to be called again)
+        self._close_stream()
+        super()._free()
+
     def decode_with_indexes(self, encoded, indexes, ar_indexes=None, ar_offsets=None):
         """csrc/ans/rans64.cpp:389-499 -- int32 array shaped like ``indexes``."""
         if self._tables is None:

@@ -383,7 +383,17 @@ class LatentGraphicalANSEntropyCoder(HotPathModule, VariableRateCodecInterface, 
         with torch.no_grad():
             node_dict = self._node_generate_process(**self._get_default_node_dict(force_add_default_dynamic_nodes=True, **kwargs))
             latent = self._inference_process({self.DEFAULT_INPUT_NODE_NAME: data.to(self.device), **node_dict})
-            data_dict, prior_dict = self._generative_process(latent)
+            # the coders' forward() inside encode() skips the likelihood pass (nobody reads it there); here it is the
+            # point of the call (prior_entropy / estimated_bpd), as in the reference's forward
+            coders = [c for c in self.latent_node_entropy_coders.values() if hasattr(c, "estimate_rate")]
+            saved = [c.estimate_rate for c in coders]
+            for c in coders:
+                c.estimate_rate = True
+            try:
+                data_dict, prior_dict = self._generative_process(latent)
+            finally:
+                for c, v in zip(coders, saved):
+                    c.estimate_rate = v
             # rate metrics (latent_graph.py:1168-1178): nats per image summed over the coded nodes, bits per dimension
             total_prior_entropy, estimated_bpd = 0, 0
             for name, module in self.latent_node_entropy_coders.items():

@@ -104,6 +104,11 @@ class EntropyBottleneck(nn.Module):
         self.filters = tuple(int(f) for f in filters)
         self.init_scale = float(init_scale)
         self.tail_mass = float(tail_mass)
+        # EntropyModel's registered buffers (upstream): empty until update(); resized on load like
+        # compressai.models.utils.update_registered_buffers does
+        self.register_buffer("_offset", torch.IntTensor())
+        self.register_buffer("_quantized_cdf", torch.IntTensor())
+        self.register_buffer("_cdf_length", torch.IntTensor())
         f = (1,) + self.filters + (1,)
         scale = self.init_scale ** (1 / (len(self.filters) + 1))
         self.matrices, self.biases, self.factors = nn.ParameterList(), nn.ParameterList(), nn.ParameterList()
@@ -116,6 +121,19 @@ class EntropyBottleneck(nn.Module):
         self.quantiles = nn.Parameter(torch.tensor([-self.init_scale, 0.0, self.init_scale]).repeat(channels, 1, 1))
         target = np.log(2 / self.tail_mass - 1)
         self.register_buffer("target", torch.Tensor([-target, 0, target]))
+        self.likelihood_lower_bound = nn.Module()   # LowerBound(likelihood_bound) of EntropyModel (upstream)
+        self.likelihood_lower_bound.register_buffer("bound", torch.Tensor([1e-9]))
+        # parameters first, then the ParameterLists: the reference's key order
+        mats, bias, fact = self.matrices, self.biases, self.factors
+        del self.matrices, self.biases, self.factors
+        self.matrices, self.biases, self.factors = mats, bias, fact
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        for name in ("_offset", "_quantized_cdf", "_cdf_length"):   # table buffers take the checkpoint's size
+            v = state_dict.get(prefix + name)
+            if v is not None and v.shape != getattr(self, name).shape:
+                setattr(self, name, torch.zeros(v.shape, dtype=torch.int32, device=getattr(self, name).device))
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
     def _logits_cumulative(self, inputs):
         logits = inputs
@@ -162,6 +180,10 @@ class EntropyBottleneck(nn.Module):
             pmf = torch.abs(torch.sigmoid(sign * upper) - torch.sigmoid(sign * lower))[:, 0, :]
             tail = torch.sigmoid(lower[:, 0, :1]) + torch.sigmoid(-upper[:, 0, -1:])
         cdf = _pmf_to_cdf(pmf.numpy(), tail.numpy(), pmf_length.numpy(), max_length)
+        dev = self.quantiles.device
+        self._offset = offset.to(dev)
+        self._quantized_cdf = torch.from_numpy(cdf).to(dev)
+        self._cdf_length = (pmf_length + 2).to(dev)
         return cdf, (pmf_length + 2).numpy().astype(np.int32), offset.numpy().astype(np.int32)
 
 

@@ -195,7 +195,10 @@ class GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(HotPathModule):
         self.use_param_merger = use_param_merger
         self.param_merger_expand_bottleneck = param_merger_expand_bottleneck
         self.freq_precision, self.use_bypass_coding, self.bypass_precision = freq_precision, use_bypass_coding, bypass_precision
-        self.lower_bound_scale = lower_bound_scale
+        # LowerBound(lower_bound_scale) of GaussianPGMPriorCoderImpl (pgm_coder.py:720-721): a module holding the buffer ``bound``
+        self.lower_bound_scale = nn.Module()
+        self.lower_bound_scale.register_buffer("bound", torch.Tensor([float(lower_bound_scale)]))
+        self._lower_bound_scale = float(lower_bound_scale)
         self.fixed_input_shape = fixed_input_shape
         self.force_input_prior_shape_aligned = force_input_prior_shape_aligned
         self.batch_stream_mode = batch_stream_mode
@@ -243,7 +246,7 @@ class GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(HotPathModule):
     # ------------------------------------------------------------------ state
     def update_state(self, *args, **kwargs) -> None:
         """TorchANSPriorCoder.update_state (torch_ans.py:237-251)."""
-        freqs, nsym, offsets = gaussian_ans_params(self.scale_table, self.freq_precision, self.lower_bound_scale)
+        freqs, nsym, offsets = gaussian_ans_params(self.scale_table, self.freq_precision, self._lower_bound_scale)
         self._ans_params = (freqs, nsym, offsets)
         self._tables = K.RansTables(freqs=freqs, nsym=nsym, offsets=offsets, precision=self.freq_precision,
                                     bypass=self.use_bypass_coding, bypass_precision=self.bypass_precision)
@@ -475,7 +478,7 @@ class GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(HotPathModule):
             ws["ybuf"] = q
             allpos = torch.arange(B * H * W, device=self.device, dtype=torch.int32)
             params = self._context_at(ws, plan, allpos, prior)
-            nll = K.gauss_nll_per_image(q, params, True, self.lower_bound_scale, self.eps)
+            nll = K.gauss_nll_per_image(q, params, True, self._lower_bound_scale, self.eps)
             self.update_cache("metric_dict", prior_entropy=nll.mean())
         return q
 

@@ -19,6 +19,7 @@ class SlimmableConv2dPGMModel(nn.Module):
         self.mid_channels_list = list(mid_channels_list)
         self.out_channels_list = list(out_channels) if isinstance(out_channels, (list, tuple)) else [out_channels] * len(self.mid_channels_list)
         self.default_pgm = nn.Parameter(torch.zeros(1, 1, len(self.mid_channels_list)))  # state-dict compat (BasePGMLayer :111)
+        self.default_agg_pgm = nn.Parameter(torch.zeros(1, len(self.mid_channels_list)))        # (BasePGMLayer :117)
         self.pgm_model = self.build_pgm_model()
         self._plans = {}
         self._key = None

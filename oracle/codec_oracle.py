@@ -304,7 +304,7 @@ class TopoGroupCodecOracle:
         return write_body(z.shape[-2:], strings), sym + med
 
     def compress(self, x):
-        assert x.shape[0] == 1, "the reference's AR coder writes one stream per call; the oracle follows batch 1"
+        """A batch is coded the reference's way: one z string per image (write_body), ONE y stream for the whole batch."""
         y = self.g_a(x)
         bz, z_hat = self._z(self.h_a(y))
         prior = self.h_s(z_hat)
@@ -321,8 +321,17 @@ class TopoGroupCodecOracle:
         z_sym = torch.stack([torch.from_numpy(self.z_dec.decode_with_indexes(s, z_idx)) for s in z_strings])
         z_hat = z_sym.float() + self.eb[3].reshape(1, -1, 1, 1)
         prior = self.h_s(z_hat)
-        y_hat = self.y.decode(by, prior, (1, self.y.C, prior.shape[2], prior.shape[3]))
+        y_hat = self.y.decode(by, prior, (prior.shape[0], self.y.C, prior.shape[2], prior.shape[3]))
         return self.g_s(y_hat)
+
+    def forward_entropies(self, x):
+        """Eval forward()'s rate terms (latent_graph.py:1168-1178): nats per image for y and z."""
+        y = self.g_a(x)
+        z = self.h_a(y)
+        med = self.eb[3].reshape(1, -1, 1, 1)
+        prior = self.h_s(torch.round(z - med) + med)
+        return dict(y=float(self.y.forward_entropy(y, prior)),
+                    z=float(eb_entropy(self.sd, "latent_node_entropy_coders.z.entropy_bottleneck.", z)))
 
 
 SL_G_A = [("conv", 2, 5), ("gdn", False), ("conv", 2, 5), ("gdn", False), ("conv", 2, 5), ("gdn", False), ("conv", 2, 5)]

@@ -1,0 +1,115 @@
+"""Builders shared by the CPU and GPU tests of tests/golden/codec_graph.npz (the reference's GeneralCodec +
+LatentGraphicalANSEntropyCoder run end to end, see make_golden.py::codec_graph): this repository's codec with the
+fixture's constructor arguments and weight recipe, and the CPU oracle for the same state_dict."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+from recipe import named_seed_weights, recipe_input  # noqa: E402
+
+
+def load():
+    return np.load(os.path.join(HERE, "golden", "codec_graph.npz"), allow_pickle=False)
+
+
+def topo_cfg(z, k):
+    N, M, G, expand, ctxm, B, H, W = (int(v) for v in z[f"{k}.cfg"])
+    return dict(N=N, M=M, G=G, expand=bool(expand), B=B, H=H, W=W, method=str(z[f"{k}.method"]))
+
+
+def basic_cfg(z):
+    cfg = [int(v) for v in z["b0.cfg"]]
+    ctl = [str(c) for c in z["b0.controllers"]]
+    return dict(M=cfg[0], B=cfg[1], H=cfg[2], W=cfg[3], widths=cfg[4:], controllers=ctl,
+                levels=[dict(zip(ctl, (int(v) for v in row))) for row in z["b0.levels"]])
+
+
+def build_codec(z, k):
+    """This repository's codec for fixture case k ("t0".."t2", "b0"), weights by the recipe, on the CPU (no compute)."""
+    from cbench_basic_amd.codecs.general_codec import GeneralCodec
+    from cbench_basic_amd.modules.entropy_coder.latent_graph import LatentGraphicalANSEntropyCoder, LossyDummyEntropyCoder
+    from cbench_basic_amd.modules.prior_model.prior_coder.compressai_coder import CompressAIEntropyBottleneckPriorCoder
+    from cbench_basic_amd.modules.prior_model.prior_coder.pgm_coder import (GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder,
+                                                                            TopoGroupDynamicMaskConv2dContextModel)
+    if k.startswith("t"):
+        from cbench_basic_amd.nn.models.google import (HyperpriorAnalysisModel, HyperpriorHyperAnalysisModel,
+                                                       HyperpriorHyperSynthesisModel, HyperpriorSynthesisModel)
+        c = topo_cfg(z, k)
+        N, M = c["N"], c["M"]
+        ec = LatentGraphicalANSEntropyCoder(
+            latent_node_inference_topo_order=["x", "y", "z"], latent_node_generative_topo_order=["z", "y", "x"],
+            latent_node_entropy_coder_dict=dict(
+                x=LossyDummyEntropyCoder(lambda_rd=145.2225),
+                y=GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(in_channels=M, channel_groups=c["G"], default_topo_group_method=c["method"],
+                                                                       param_merger_expand_bottleneck=c["expand"], batch_stream_mode="reference"),
+                z=CompressAIEntropyBottleneckPriorCoder(entropy_bottleneck_channels=N, use_inner_aux_opt=True)),
+            latent_inference_dict=dict(x_y=HyperpriorAnalysisModel(N=N, M=M), y_z=HyperpriorHyperAnalysisModel(N=N, M=M)),
+            latent_generative_dict=dict(z_y=HyperpriorHyperSynthesisModel(N=N, M=2 * M), y_x=HyperpriorSynthesisModel(N=N, M=M)))
+    else:
+        from cbench_basic_amd.nn.layers import pgm_layers as P
+        from cbench_basic_amd.nn.layers.param_generator import IndexSelectParameterGeneratorWrapper, NNParameterGenerator
+        c = basic_cfg(z)
+        M, Wd, n = c["M"], c["widths"], len(c["widths"])
+
+        def slim_node():
+            return IndexSelectParameterGeneratorWrapper(
+                batched_generator=NNParameterGenerator(shape=(n, 1, 1, n), init_method="value",
+                                                       init_value=torch.eye(n).flip(-1).unsqueeze(1).unsqueeze(1), fix_params=True),
+                fix_for_inference=True)
+        ec = LatentGraphicalANSEntropyCoder(
+            node_generator_dict={c_: slim_node() for c_ in ["pgmxy", "pgmyx", "pgmyz", "pgmzy"]},
+            use_lossy_compression=True, lossy_compression_lambda_rd=145.2225,
+            latent_node_inference_topo_order=["x", "y", "z"], latent_node_generative_topo_order=["z", "y", "x"],
+            latent_node_entropy_coder_dict=dict(
+                y=GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(
+                    in_channels=M, default_topo_group_method="scanline", batch_stream_mode="reference",
+                    topo_group_context_model=TopoGroupDynamicMaskConv2dContextModel(in_channels=M, out_channels=2 * M)),
+                z=CompressAIEntropyBottleneckPriorCoder(entropy_bottleneck_channels=M, use_inner_aux_opt=True)),
+            latent_inference_dict=dict(
+                x_y=P.HyperpriorAnalysisSlimmableConv2dPGMModel(in_channels=3, out_channels=M, mid_channels_list=Wd),
+                y_z=P.MeanScaleHyperpriorHyperAnalysisSlimmableConv2dPGMModel(in_channels=M, out_channels=M, mid_channels_list=Wd)),
+            latent_generative_dict=dict(
+                z_y=P.MeanScaleHyperpriorHyperSynthesisSlimmableConv2dPGMModel(in_channels=M, out_channels=2 * M, mid_channels_list=Wd),
+                y_x=P.HyperpriorSynthesisSlimmableConv2dPGMModel(in_channels=M, out_channels=3, mid_channels_list=Wd)),
+            latent_inference_input_mapping=dict(x_y={"pgmxy": "pgm"}, y_z={"pgmyz": "pgm"}),
+            latent_generative_input_mapping=dict(y_x={"pgmyx": "pgm"}, z_y={"pgmzy": "pgm"}, y={"z": "prior"}),
+            complexity_level_greedy_search=True, complexity_level_greedy_search_custom_params=c["levels"],
+            complexity_level_greedy_search_custom_constraint=[float(i) for i in range(len(c["levels"]))],
+            complexity_level_controller_nodes=c["controllers"])
+    codec = GeneralCodec(entropy_coder=ec).eval()
+    if hasattr(ec, "_complexity_param_valid"):   # as after post_training_process / a loaded checkpoint (the fixture does the same)
+        ec._complexity_param_valid.fill_(True)
+        ec._valid_host = None
+    calib = list(zip(z[f"{k}.calib_names"], z[f"{k}.calib_mul"], z[f"{k}.calib_add_odd"]))
+    touched = named_seed_weights(codec, int(z[f"{k}.seed"]), calib)
+    return codec, touched
+
+
+def case_input(z, k):
+    c = topo_cfg(z, k) if k.startswith("t") else basic_cfg(z)
+    return recipe_input(int(z[f"{k}.xseed"]), (c["B"], 3, c["H"], c["W"]))
+
+
+def build_oracle(z, k, state_dict):
+    from oracle.codec_oracle import BasicCodecOracle, TopoGroupCodecOracle
+    if k.startswith("t"):
+        c = topo_cfg(z, k)
+        return TopoGroupCodecOracle(state_dict, method=c["method"], channels=c["M"], channel_groups=c["G"],
+                                    expand_bottleneck=c["expand"], prefix="entropy_coder.")
+    c = basic_cfg(z)
+    return BasicCodecOracle(state_dict, c["widths"], M=c["M"], prefix="entropy_coder.")
+
+
+def records(z, k):
+    """Fixture record prefixes of case k: the case itself, or one per complexity level for the BaSIC graph."""
+    if k.startswith("t"):
+        return [(k, None)]
+    return [(f"b0.l{i}", i) for i in range(len(z["b0.levels"]))]
+
+
+def metrics(z, rec):
+    return dict(zip((str(n) for n in z[f"{rec}.metric_names"]), (float(v) for v in z[f"{rec}.metric_values"])))

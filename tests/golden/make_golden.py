@@ -481,8 +481,169 @@ def ar_coder_joint():
     save("ar_coder_joint.npz", **out)
 
 
+# ---------------------------------------------------------------- 11. whole codec graphs (GeneralCodec + LatentGraphicalANSEntropyCoder)
+from recipe import named_seed_weights, recipe_input  # noqa: E402  (tests/golden/recipe.py)
+
+
+def codec_graph():
+    """The reference's GeneralCodec(entropy_coder=LatentGraphicalANSEntropyCoder(...)) (general_codec.py:44-130,
+    latent_graph.py:306,1232-1295) run end to end on CPU at tiny channel counts:
+      t0  topo-group graph, checkerboard + expand-bottleneck merger   (configs/lossy_latent_graph_topogroup.py:203-244)
+      t1  topo-group graph, channel-wise G=2
+      t2  topo-group graph, scanline, batch of 2 (one stream for the batch: the reference's layout)
+      b0  BaSIC slimmable graph (presets/lossy_latent_graph_scalable_ar_models.py:73-197), widths [4,6,8,12,16], eight
+          complexity levels = eight fixed controller index tuples (complexity_level_greedy_search_custom_params), every
+          uniform width plus three mixed ones
+    Recorded per case / level: compress() bytes, the y-coder's (symbols, indexes) as handed to the native encoder, the
+    latents y and z, x-hat of decompress(), the forward() metrics (prior_entropy, estimated_bpd, mse, per-node entropies), and
+    the complete state_dict key / shape list.  compressai's EntropyBottleneck / GDN / conv arithmetic underneath is
+    oracle/compressai_restated.py (compressai is absent here): these fixtures pin the reference's OWN graph code, not that."""
+    import logging
+    from cbench.codecs.general_codec import GeneralCodec
+    from cbench.modules.entropy_coder.latent_graph import LatentGraphicalANSEntropyCoder, LossyDummyEntropyCoder
+    from cbench.modules.prior_model.prior_coder.compressai_coder import CompressAIEntropyBottleneckPriorCoder
+    from cbench.nn.models.google import (HyperpriorAnalysisModel, HyperpriorSynthesisModel, HyperpriorHyperAnalysisModel,
+                                         HyperpriorHyperSynthesisModel)
+    from cbench.nn.layers import pgm_layers as P
+    from cbench.nn.layers.param_generator import IndexSelectParameterGeneratorWrapper, NNParameterGenerator
+    logging.disable(logging.CRITICAL)
+    out, keys = {}, []
+
+    def spy_y(coder, log):
+        orig = coder.ans_encoder
+
+        class Spy:
+            def encode_with_indexes(self, data, indexes, **k):
+                log.append((np.array(data).astype(np.int32).reshape(-1), np.array(indexes).astype(np.int32).reshape(-1)))
+                return orig.encode_with_indexes(data, indexes, **k)
+        coder.ans_encoder = Spy()
+
+    def record(k, codec, x, log):
+        ec = codec.entropy_coder
+        del log[:]
+        with torch.no_grad():
+            data = codec.compress(x)
+            sym, idx = log[-1]
+            xhat = codec.decompress(data)
+            node = ec._node_generate_process(**ec._get_default_node_dict(force_add_default_dynamic_nodes=True))
+            lat = ec._inference_process({"x": x, **node})
+            codec.reset_all_cache()
+            xfwd = codec(x)
+            met = {n.split("metric_dict/entropy_coder/")[-1]: float(v) for n, v in codec.get_cache("metric_dict").items()}
+        out.update({f"{k}.bytes": b2a(data), f"{k}.symbols": sym, f"{k}.indexes": idx, f"{k}.xhat": xhat.numpy(),
+                    f"{k}.y": lat["y"].numpy(), f"{k}.z": lat["z"].numpy(), f"{k}.xfwd_minus_xhat_max": np.float64((xfwd - xhat).abs().max()),
+                    f"{k}.metric_names": np.array(list(met)), f"{k}.metric_values": np.array(list(met.values()), np.float64)})
+        print(f"  {k}: {len(data)} bytes, {sym.size} y symbols, mse {met.get('mse', float('nan')):.4f}, y std {float(lat['y'].std()):.2f}, "
+              f"prior_entropy {met.get('prior_entropy', float('nan')):.2f}")
+
+    def finish(k, codec, touched, seed, xseed, calib):
+        sd = codec.state_dict()
+        out.update({f"{k}.xseed": np.int64(xseed), f"{k}.seed": np.int64(seed),
+                    f"{k}.calib_names": np.array([c[0] for c in calib]), f"{k}.calib_mul": np.array([c[1] for c in calib]),
+                    f"{k}.calib_add_odd": np.array([c[2] for c in calib]),
+                    f"{k}.pnames": np.array([n for n, _ in touched]), f"{k}.pshapes": np.array([s for _, s in touched]),
+                    f"{k}.wsum": np.array([float(sum(codec.state_dict()[n].double().sum() for n, _ in touched))]),
+                    f"{k}.sd_keys": np.array(list(sd)), f"{k}.sd_shapes": np.array([",".join(str(d) for d in v.shape) for v in sd.values()])})
+        keys.append(k)
+
+    # ---- topo-group graphs
+    N, M = 8, 16
+    for ci, (method, G, expand, ctxm, (B, H, W)) in enumerate([("checkerboard", 1, True, False, (1, 64, 128)), ("channelwise", 2, False, False, (1, 64, 64)),
+                                                                ("scanline", 1, False, False, (2, 64, 64))]):
+        k = f"t{ci}"
+        ykw = dict(in_channels=M, channel_groups=G, default_topo_group_method=method, param_merger_expand_bottleneck=expand)
+        ec = LatentGraphicalANSEntropyCoder(
+            latent_node_inference_topo_order=["x", "y", "z"], latent_node_generative_topo_order=["z", "y", "x"],
+            latent_node_entropy_coder_dict=dict(x=LossyDummyEntropyCoder(lambda_rd=145.2225),
+                                                y=GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(**ykw),
+                                                z=CompressAIEntropyBottleneckPriorCoder(entropy_bottleneck_channels=N, use_inner_aux_opt=True)),
+            latent_inference_dict=dict(x_y=HyperpriorAnalysisModel(N=N, M=M), y_z=HyperpriorHyperAnalysisModel(N=N, M=M)),
+            latent_generative_dict=dict(z_y=HyperpriorHyperSynthesisModel(N=N, M=2 * M), y_x=HyperpriorSynthesisModel(N=N, M=M)))
+        codec = GeneralCodec(entropy_coder=ec).eval()
+        seed = 700 + ci
+        pre = "entropy_coder.latent_inference_modules."
+        gen = "entropy_coder.latent_generative_modules."
+        # spread the latents over the scale table (y std ~ 2, predicted scales ~ 1) and keep x-hat O(1)
+        calib = [(pre + "x_y.model.6.weight", 8.0, 0.0), (pre + "y_z.model.4.weight", 6.0, 0.0),
+                 (gen + "z_y.model.4.bias", 1.0, 1.2), (gen + "y_x.model.0.weight", 0.05, 0.0),
+                 ("entropy_coder.latent_node_entropy_coders.y.param_merger.4.bias", 1.0, 1.2)]
+        touched = named_seed_weights(codec, seed, calib)
+        codec.update_state()
+        log = []
+        spy_y(ec.latent_node_entropy_coders["y"], log)
+        x = recipe_input(800 + ci, (B, 3, H, W))
+        record(k, codec, x, log)
+        out[f"{k}.cfg"] = np.array([N, M, G, int(expand), int(ctxm), B, H, W])
+        out[f"{k}.method"] = np.array(method)
+        finish(k, codec, touched, seed, 800 + ci, calib)
+
+    # ---- BaSIC slimmable graph
+    Wd, M = [4, 6, 8, 12, 16], 16
+    n = len(Wd)
+
+    def slim_node():
+        return IndexSelectParameterGeneratorWrapper(
+            batched_generator=NNParameterGenerator(shape=(n, 1, 1, n), init_method="value",
+                                                   init_value=torch.eye(n).flip(-1).unsqueeze(1).unsqueeze(1), fix_params=True),
+            fix_for_inference=True)
+    ctl = ["pgmxy", "pgmyz", "pgmzy", "pgmyx"]
+    levels = [dict(zip(ctl, t)) for t in [(0, 0, 0, 0), (1, 1, 1, 1), (2, 2, 2, 2), (3, 3, 3, 3), (4, 4, 4, 4), (0, 2, 1, 4), (3, 0, 4, 1), (2, 4, 0, 3)]]
+    ec = LatentGraphicalANSEntropyCoder(
+        node_generator_dict={c: slim_node() for c in ["pgmxy", "pgmyx", "pgmyz", "pgmzy"]},
+        use_lossy_compression=True, lossy_compression_lambda_rd=145.2225,
+        latent_node_inference_topo_order=["x", "y", "z"], latent_node_generative_topo_order=["z", "y", "x"],
+        latent_node_entropy_coder_dict=dict(
+            y=GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(
+                in_channels=M, default_topo_group_method="scanline",
+                topo_group_context_model=TopoGroupDynamicMaskConv2dContextModel(in_channels=M, out_channels=2 * M)),
+            z=CompressAIEntropyBottleneckPriorCoder(entropy_bottleneck_channels=M, use_inner_aux_opt=True)),
+        latent_inference_dict=dict(
+            x_y=P.HyperpriorAnalysisSlimmableConv2dPGMModel(in_channels=3, out_channels=M, mid_channels_list=Wd),
+            y_z=P.MeanScaleHyperpriorHyperAnalysisSlimmableConv2dPGMModel(in_channels=M, out_channels=M, mid_channels_list=Wd)),
+        latent_generative_dict=dict(
+            z_y=P.MeanScaleHyperpriorHyperSynthesisSlimmableConv2dPGMModel(in_channels=M, out_channels=2 * M, mid_channels_list=Wd),
+            y_x=P.HyperpriorSynthesisSlimmableConv2dPGMModel(in_channels=M, out_channels=3, mid_channels_list=Wd)),
+        latent_inference_input_mapping=dict(x_y={"pgmxy": "pgm"}, y_z={"pgmyz": "pgm"}),
+        latent_generative_input_mapping=dict(y_x={"pgmyx": "pgm"}, z_y={"pgmzy": "pgm"}, y={"z": "prior"}),
+        complexity_level_greedy_search=True, complexity_level_greedy_search_custom_params=levels,
+        complexity_level_greedy_search_custom_constraint=[float(i) for i in range(len(levels))],
+        complexity_level_controller_nodes=ctl)
+    codec = GeneralCodec(entropy_coder=ec).eval()
+    def last_conv(mod, prefix, first=False):
+        names = [nm for nm, p_ in mod.named_parameters() if p_.dim() == 4]
+        return prefix + (names[0] if first else names[-1])
+    pre, gen = "entropy_coder.latent_inference_modules.", "entropy_coder.latent_generative_modules."
+    w_hs = last_conv(ec.latent_generative_modules["z_y"], gen + "z_y.")
+    calib = [(last_conv(ec.latent_inference_modules["x_y"], pre + "x_y."), 8.0, 0.0),
+             ("entropy_coder.latent_node_entropy_coders.y.topo_group_context_model.param_merger_out.3.bias", 1.0, 1.2),
+             (last_conv(ec.latent_inference_modules["y_z"], pre + "y_z."), 6.0, 0.0),
+             (w_hs[:-len("weight")] + "bias", 1.0, 1.2),
+             (last_conv(ec.latent_generative_modules["y_x"], gen + "y_x.", first=True), 0.05, 0.0)]
+    touched = named_seed_weights(codec, 790, calib)
+    with torch.no_grad():
+        ec._complexity_param_valid.fill_(True)   # as after post_training_process / a loaded checkpoint (latent_graph.py:673-675)
+    codec.update_state()
+    log = []
+    spy_y(ec.latent_node_entropy_coders["y"], log)
+    x = recipe_input(890, (1, 3, 64, 64))
+    for li in range(len(levels)):
+        codec.set_complex_level(li)
+        record(f"b0.l{li}", codec, x, log)
+        try:
+            out[f"b0.l{li}.flops"] = np.float64(sum(float(m.get_current_flops()) for m in list(ec.latent_inference_modules.values()) + list(ec.latent_generative_modules.values())))
+        except Exception as e:
+            print("   flops unavailable:", repr(e))
+    out["b0.levels"] = np.array([[lv[c] for c in ctl] for lv in levels])
+    out["b0.controllers"] = np.array(ctl)
+    out["b0.cfg"] = np.array([M, 1, 64, 64] + Wd)
+    finish("b0", codec, touched, 790, 890, calib)
+    out["keys"] = np.array(keys)
+    logging.disable(logging.NOTSET)
+    save("codec_graph.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["rans", "tables", "topo", "mconv", "ar", "framing", "harness", "search", "arpgm", "arjoint"]
-    fn = dict(rans=rans_kats, tables=gauss_tables, topo=topo_maps, mconv=masked_conv, ar=ar_coder, framing=framing, harness=harness, search=complexity_search, arpgm=ar_coder_pgm, arjoint=ar_coder_joint)
+    which = sys.argv[1:] or ["rans", "tables", "topo", "mconv", "ar", "framing", "harness", "search", "arpgm", "arjoint", "codec"]
+    fn = dict(rans=rans_kats, tables=gauss_tables, topo=topo_maps, mconv=masked_conv, ar=ar_coder, framing=framing, harness=harness, search=complexity_search, arpgm=ar_coder_pgm, arjoint=ar_coder_joint, codec=codec_graph)
     for w in which:
         fn[w]()

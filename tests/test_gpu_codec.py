@@ -3,6 +3,7 @@
   * integer symbols / indexes: mismatch count reported; where they agree the bytes are identical,
   * decode(encode(x)) on the GPU reproduces the oracle's reconstruction, PSNR within 0.01 dB.
 """
+import math
 import struct
 
 import numpy as np
@@ -90,10 +91,10 @@ def test_compress_decompress_vs_oracle(setup, shape):
     assert _rel(xhat.cpu(), xcross) < 1e-3
     assert float((psnr(xhat.cpu(), x) - psnr(xref, x)).abs().max()) < 0.01
     a = oracle.analyse(x)
-    if data == ref:
-        assert _rel(xhat.cpu(), xref) < 1e-4
-    else:  # streams may differ only through (rare) symbol flips; sizes stay within a few bytes
-        assert abs(len(data) - len(ref)) <= 64
+    # byte-identical to the CPU oracle for every shape of this (seeded) test; an fp32 rounding tie would have to be
+    # recorded here by shape with the flipped symbol
+    assert data == ref, shape
+    assert _rel(xhat.cpu(), xref) < 1e-4
     (nz,) = struct.unpack("I", data[:4])
     assert struct.unpack(">3I", data[4:16]) == (a["z"].shape[-2], a["z"].shape[-1], shape[0])
 
@@ -103,8 +104,27 @@ def test_smoke_entry():
     g.smoke()
 
 
+def _entropy_stage_inputs(codec, x):
+    """The integer (symbols, indexes) the GPU codec hands to rANS for y, recomputed stage by stage."""
+    from cbench_basic_amd.nn import kernels as K
+    ec = codec.entropy_coder
+    y = ec.latent_inference_modules["x_y"](x.cuda())
+    z = ec.latent_inference_modules["y_z"](y)
+    zhat = ec.latent_node_entropy_coders["z"](z)
+    scales = ec.latent_generative_modules["z_y"](zhat)[..., : y.shape[-2], : y.shape[-1]].contiguous()
+    yc = ec.latent_node_entropy_coders["y"]
+    yc._ready()
+    sym, idx, _ = K.gc_quantize_index(y, scales, yc._scale_table_dev)
+    return y.cpu(), scales.cpu(), sym.cpu(), idx.cpu()
+
+
 def test_kodak_shaped_image_roundtrip(setup):
-    """BASELINE configs[1] shape: 3x512x768 (Kodak), batch 1 -- y is 192x32x48 = 294,912 symbols in one stream."""
+    """BASELINE configs[1] shape: 3x512x768 (Kodak), batch 1 -- y is 192x32x48 = 294,912 symbols in one stream.
+    The stream must equal the CPU oracle's byte for byte, EXCEPT for fp32 rounding ties between the MFMA and the
+    torch-CPU summation orders; every such flip is located and shown to be a tie (|frac(y)| within 2e-4 of .5, or the
+    scale within 2e-4 relative of a table threshold), at most 2 of them, and the rANS layer is then shown exact on the
+    oracle's own integers."""
+    from cbench_basic_amd import ans
     from oracle.codec_oracle import psnr
     codec, oracle = setup
     torch.manual_seed(24)
@@ -114,7 +134,30 @@ def test_kodak_shaped_image_roundtrip(setup):
     ref = oracle.compress(x)
     xref = oracle.decompress(ref)
     assert xhat.shape == x.shape
-    assert abs(len(data) - len(ref)) <= 64
+    a = oracle.analyse(x)
+    y, scales, sym, idx = _entropy_stage_inputs(codec, x)
+    flips_s = (sym != a["y_sym"]).nonzero()
+    flips_i = (idx != a["y_idx"]).nonzero()
+    print(f"kodak-shaped: identical={data == ref}; symbol flips {len(flips_s)}, index flips {len(flips_i)} of {sym.numel()}")
+    if data != ref:
+        assert 0 < len(flips_s) + len(flips_i) <= 2, "streams differ without a located symbol / index flip"
+        for f in flips_s:
+            v = float(a["y"][tuple(f)])
+            print(f"  symbol flip at {tuple(int(i) for i in f)}: y = {v!r} (oracle) vs {float(y[tuple(f)])!r} (GPU)")
+            assert abs(abs(v - math.floor(v)) - 0.5) < 2e-4
+        table = oracle.table
+        for f in flips_i:
+            v = float(a["scales"][tuple(f)])
+            print(f"  index flip at {tuple(int(i) for i in f)}: scale = {v!r} (oracle) vs {float(scales[tuple(f)])!r} (GPU)")
+            assert float(((table - v).abs() / table).min()) < 2e-4
+        # the rANS layer itself: the oracle's integers through the HIP coder give the oracle's y stream
+        enc = ans.Rans64Encoder(16, True, 4)
+        enc.init_cdf_params(*oracle.gc)
+        (nz,) = struct.unpack("I", ref[:4])
+        y_body = ref[4 + nz:]
+        assert enc.encode_with_indexes(a["y_sym"].numpy(), a["y_idx"].numpy()) == y_body[16:]
+    else:
+        assert len(flips_s) + len(flips_i) == 0
     assert float((psnr(xhat, x) - psnr(xref, x)).abs().max()) < 0.01
     # cross-decoding: the oracle reads the GPU stream
     assert _rel(oracle.decompress(data), xhat) < 1e-3

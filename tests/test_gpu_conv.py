@@ -1,5 +1,7 @@
 """GPU parity: MFMA implicit-GEMM conv / deconv / GDN kernels vs a plain PyTorch fp32 CPU
 reference of the same op (tolerance 1e-4 relative to the output scale, BASELINE.json north_star)."""
+import zlib
+
 import numpy as np
 import pytest
 import torch
@@ -49,9 +51,7 @@ CASES = [
 def test_conv_matches_torch(case):
     from cbench_basic_amd.nn import kernels as K
     cin, cout, k, s, p, op, tr, act, B, H, W = case
-    if cout > 192:
-        pytest.skip("cout > 192 unsupported by plan")
-    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    g = torch.Generator().manual_seed(zlib.crc32(repr(case).encode()) % (2 ** 31))   # reproducible (hash() of a str is salted per process)
     x = torch.randn(B, cin, H, W, generator=g)
     wshape = (cin, cout, k, k) if tr else (cout, cin, k, k)
     w = torch.randn(wshape, generator=g) * (1.0 / (cin * k * k) ** 0.5)
@@ -82,7 +82,7 @@ def test_transposed_conv_unfused_and_sliced_paths(case, monkeypatch):
     32-channel-slice variants (bits 4 / 8) must give the same results."""
     from cbench_basic_amd.nn import kernels as K
     cin, cout, k, s, p, op, tr, act, B, H, W = case
-    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    g = torch.Generator().manual_seed(zlib.crc32(repr(case).encode()) % (2 ** 31))
     x = torch.randn(B, cin, H, W, generator=g)
     w = torch.randn((cin, cout, k, k), generator=g) * (1.0 / (cin * k * k) ** 0.5)
     b = torch.randn(cout, generator=g) * 0.1

@@ -21,7 +21,7 @@ def build(sd, c, **kw):
     coder = GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(**args).eval()
     if sd is not None:
         missing, unexpected = coder.load_state_dict(sd, strict=False)
-        assert not unexpected and not [m for m in missing if not m.startswith("_")], (missing, unexpected)
+        assert not unexpected and not [m for m in missing if not m.startswith("_") and m != "lower_bound_scale.bound"], (missing, unexpected)
     coder = coder.cuda()
     coder.update_state()
     return coder
@@ -41,16 +41,15 @@ def test_golden_cases_reference_stream_format():
         sym, idx = sym.reshape(-1).cpu().numpy(), idx.reshape(-1).cpu().numpy()
         ms, mi = int((sym != z[f"{k}.symbols"]).sum()), int((idx != z[f"{k}.indexes"]).sum())
         print(f"{k} {c['method']}: symbol mismatches {ms}/{sym.size}, index mismatches {mi}/{idx.size}")
-        assert ms <= 1 and mi <= 1, k
+        assert ms == 0 and mi == 0, k      # every golden case: the reference's integer streams exactly
         data = coder.encode(y, prior=prior)
-        if ms == 0 and mi == 0:
-            assert data == z[f"{k}.bytes"].tobytes(), k
+        assert data == z[f"{k}.bytes"].tobytes(), k
         yhat = coder.decode(data, prior=prior)
         assert torch.allclose(yhat.cpu(), ybuf.cpu(), atol=0, rtol=0), k      # decoder reproduces the encoder's buffer exactly
-        assert torch.allclose(yhat.cpu(), torch.from_numpy(z[f"{k}.yhat"]), atol=1e-3) or ms + mi > 0, k
+        assert torch.allclose(yhat.cpu(), torch.from_numpy(z[f"{k}.yhat"]), atol=1e-3), k
         # the reference's own stream decodes on the GPU to the reference's latent
         yref = coder.decode(z[f"{k}.bytes"].tobytes(), prior=prior)
-        assert float((yref.cpu() - torch.from_numpy(z[f"{k}.yhat"])).abs().max()) < 1e-3 or ms + mi > 0, k
+        assert float((yref.cpu() - torch.from_numpy(z[f"{k}.yhat"])).abs().max()) < 1e-3, k
 
 
 @pytest.mark.parametrize("method,G,ctxm", [("checkerboard", 1, False), ("channelwise", 4, False), ("scanline", 1, True),
@@ -83,10 +82,10 @@ def test_per_image_batch_roundtrip_vs_oracle(method, G, ctxm):
         cur += lens[b]
         ref, rs, ri, rbuf = oracle.encode(y[b:b + 1], prior[b:b + 1])
         same += int(s == ref)
-        assert abs(len(s) - len(ref)) <= 8
+        assert s == ref, (method, b)
         assert float((yhat[b:b + 1] - rbuf).abs().max()) < 1.01  # at most a flipped rounding
     print(f"{method}: {same}/{B} image streams byte-identical to the CPU oracle")
-    assert same >= B - 1
+    assert same == B
 
 
 def test_pgm_forward_rate_estimate():
@@ -126,7 +125,7 @@ def test_supplied_and_learned_topo_groups_vs_reference_golden():
             sd["topo_group_predictor_cache"] = pgm
         coder = Coder(**kw).eval()
         missing, unexpected = coder.load_state_dict(sd, strict=False)
-        assert not unexpected and not [m for m in missing if not m.startswith("_")], (missing, unexpected)
+        assert not unexpected and not [m for m in missing if not m.startswith("_") and m != "lower_bound_scale.bound"], (missing, unexpected)
         coder = coder.cuda()
         coder.update_state()
         arg = None if from_pred else pgm.cuda()
@@ -138,14 +137,13 @@ def test_supplied_and_learned_topo_groups_vs_reference_golden():
         sym, idx = sym.reshape(-1).cpu().numpy(), idx.reshape(-1).cpu().numpy()
         ms, mi = int((sym != z[f"{k}.symbols"]).sum()), int((idx != z[f"{k}.indexes"]).sum())
         print(f"{k}: symbol mismatches {ms}/{sym.size}, index mismatches {mi}/{idx.size}, {len(plan.groups)} groups")
-        assert ms <= 1 and mi <= 1, k
+        assert ms == 0 and mi == 0, k      # every golden case: the reference's integer streams exactly
         data = coder.encode(y, prior=prior, pgm=arg)
-        if ms == 0 and mi == 0:
-            assert data == z[f"{k}.bytes"].tobytes(), k
+        assert data == z[f"{k}.bytes"].tobytes(), k
         yhat = coder.decode(data, prior=prior, pgm=arg)
         assert torch.equal(yhat.cpu(), ybuf.cpu()), k
         yref = coder.decode(z[f"{k}.bytes"].tobytes(), prior=prior, pgm=arg)
-        assert float((yref.cpu() - torch.from_numpy(z[f"{k}.yhat"])).abs().max()) < 1e-3 or ms + mi > 0, k
+        assert float((yref.cpu() - torch.from_numpy(z[f"{k}.yhat"])).abs().max()) < 1e-3, k
 
     sd = pgm_case(z, "comb", 390)
     pred = torch.from_numpy(z["comb.pred"])
@@ -154,7 +152,7 @@ def test_supplied_and_learned_topo_groups_vs_reference_golden():
         Coder(in_channels=16, default_topo_group_method="scanline", topo_group_context_model=Ctx(in_channels=16, out_channels=32)),
         Coder(in_channels=16, channel_groups=2, topo_group_predictor=torch.zeros_like(pred))]).eval()
     missing, unexpected = comb.load_state_dict(sd, strict=False)
-    assert not unexpected and not [m for m in missing if "._" not in m and not m.startswith("_")], (missing, unexpected)
+    assert not unexpected and not [m for m in missing if "._" not in m and not m.startswith("_") and not m.endswith("lower_bound_scale.bound")], (missing, unexpected)
     comb = comb.cuda()
     comb.update_state()
     y, prior = torch.from_numpy(z["comb.y"]).cuda(), torch.from_numpy(z["comb.prior"]).cuda()
@@ -163,7 +161,7 @@ def test_supplied_and_learned_topo_groups_vs_reference_golden():
         data = comb.encode(y, prior=prior, blend_weight=bw)
         yhat = comb.decode(z[f"comb.bytes{sel}"].tobytes(), prior=prior, blend_weight=bw)
         assert float((yhat.cpu() - torch.from_numpy(z[f"comb.yhat{sel}"])).abs().max()) < 1e-3, sel
-        assert data == z[f"comb.bytes{sel}"].tobytes() or abs(len(data) - z[f"comb.bytes{sel}"].size) <= 8, sel
+        assert data == z[f"comb.bytes{sel}"].tobytes(), sel
         print(f"combined sel {sel}: identical={data == z[f'comb.bytes{sel}'].tobytes()}")
 
 
@@ -178,7 +176,7 @@ def test_joint_ar_impl_vs_reference_golden():
         C, B, H, W = (int(v) for v in z[f"{k}.cfg"])
         coder = Coder(in_channels=C, use_joint_ar_model_impl=True, batch_stream_mode="reference").eval()
         missing, unexpected = coder.load_state_dict(sd, strict=False)
-        assert not unexpected and not [m for m in missing if not m.startswith("_")], (missing, unexpected)
+        assert not unexpected and not [m for m in missing if not m.startswith("_") and m != "lower_bound_scale.bound"], (missing, unexpected)
         coder = coder.cuda()
         coder.update_state()
         y, prior = torch.from_numpy(z[f"{k}.y"]).cuda(), torch.from_numpy(z[f"{k}.prior"]).cuda()
@@ -189,11 +187,10 @@ def test_joint_ar_impl_vs_reference_golden():
         sym, idx = sym.reshape(-1).cpu().numpy(), idx.reshape(-1).cpu().numpy()
         ms, mi = int((sym != z[f"{k}.symbols"]).sum()), int((idx != z[f"{k}.indexes"]).sum())
         print(f"{k}: symbol mismatches {ms}/{sym.size}, index mismatches {mi}/{idx.size}")
-        assert ms <= 1 and mi <= 1, k
+        assert ms == 0 and mi == 0, k      # every golden case: the reference's integer streams exactly
         data = coder.encode(y, prior=prior)
-        if ms == 0 and mi == 0:
-            assert data == z[f"{k}.bytes"].tobytes(), k
+        assert data == z[f"{k}.bytes"].tobytes(), k
         yhat = coder.decode(data, prior=prior)
         assert torch.equal(yhat.cpu(), ybuf.cpu()), k
         yref = coder.decode(z[f"{k}.bytes"].tobytes(), prior=prior)
-        assert float((yref.cpu() - torch.from_numpy(z[f"{k}.yhat"])).abs().max()) < 1e-3 or ms + mi > 0, k
+        assert float((yref.cpu() - torch.from_numpy(z[f"{k}.yhat"])).abs().max()) < 1e-3, k

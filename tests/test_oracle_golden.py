@@ -229,3 +229,55 @@ def test_framing():
     assert split_merged_bytes(b"", num_segments=3) == [b"", b"", b""]
     assert encode_shape((1, 192, 16, 16)) == z["shape_bytes"].tobytes()
     assert decode_shape(z["shape_bytes"].tobytes()) == ([1, 192, 16, 16], 9)
+
+
+# ---------------------------------------------------------------- whole codec graphs (codec_graph.npz)
+def test_codec_state_dict_contract_matches_reference():
+    """Key names and shapes of the whole codec's state_dict == the reference's GeneralCodec /
+    LatentGraphicalANSEntropyCoder (latent_graph.py:306; tools/compressai_checkpoint_to_cbench.py:58-172), for a
+    topo-group graph and the BaSIC slimmable graph; the recipe's checksum proves the same tensors got the same values."""
+    import codec_cases as cc
+    z = cc.load()
+    for k in (str(s) for s in z["keys"]):
+        codec, touched = cc.build_codec(z, k)
+        ours = {n: ",".join(str(d) for d in v.shape) for n, v in codec.state_dict().items()}
+        ref = dict(zip((str(s) for s in z[f"{k}.sd_keys"]), (str(s) for s in z[f"{k}.sd_shapes"])))
+        assert set(ours) == set(ref), (k, sorted(set(ours) ^ set(ref)))
+        table_buffers = ("entropy_bottleneck._offset", "entropy_bottleneck._quantized_cdf", "entropy_bottleneck._cdf_length")
+        diff = [(n, ours[n], ref[n]) for n in ours if ours[n] != ref[n] and not n.endswith(table_buffers)]
+        assert not diff, (k, diff)       # (the three table buffers are empty until update_state(), as upstream)
+        assert sorted(n for n, _ in touched) == sorted(str(s) for s in z[f"{k}.pnames"]), k
+        sd = codec.state_dict()
+        assert abs(float(sum(sd[n].double().sum() for n, _ in touched)) - float(z[f"{k}.wsum"][0])) < 1e-6, k
+        # a state_dict in the reference's layout loads strictly (table buffers resized to the checkpoint's)
+        fake = {n: torch.zeros([int(d) for d in s.split(",")] if s else [], dtype=sd[n].dtype) for n, s in ref.items()}
+        codec.load_state_dict(fake, strict=True)
+
+
+def test_codec_oracle_matches_reference_codec_graph():
+    """oracle/codec_oracle.py against the reference's own end-to-end run: compress() bytes, the y-coder's integer
+    (symbols, indexes), latents, x-hat and the forward() rate / distortion metrics, for three topo-group graphs
+    (incl. a batch of 2 in one stream) and the BaSIC graph at eight controller settings covering all five widths."""
+    import codec_cases as cc
+    z = cc.load()
+    for k in (str(s) for s in z["keys"]):
+        codec, _ = cc.build_codec(z, k)
+        o = cc.build_oracle(z, k, codec.state_dict())
+        x = cc.case_input(z, k)
+        for rec, level in cc.records(z, k):
+            if level is not None:
+                n = len(cc.basic_cfg(z)["widths"])
+                lv = cc.basic_cfg(z)["levels"][level]
+                o.set_levels(*(n - 1 - lv[c] for c in ("pgmxy", "pgmyz", "pgmzy", "pgmyx")))
+            data = o.compress(x)
+            assert np.array_equal(o.last["y_sym"].reshape(-1), z[f"{rec}.symbols"]), rec
+            assert np.array_equal(o.last["y_idx"].reshape(-1), z[f"{rec}.indexes"]), rec
+            assert data == z[f"{rec}.bytes"].tobytes(), rec
+            assert torch.allclose(o.last["y"], torch.from_numpy(z[f"{rec}.y"]), atol=1e-5, rtol=1e-5), rec
+            xhat = o.decompress(z[f"{rec}.bytes"].tobytes())
+            assert torch.allclose(xhat, torch.from_numpy(z[f"{rec}.xhat"]), atol=1e-5, rtol=1e-5), rec
+            m = cc.metrics(z, rec)
+            ent = o.forward_entropies(x)
+            assert abs(ent["y"] - m["latent_node_entropy_coders/y/prior_entropy"]) <= 1e-4 * abs(ent["y"]) + 1e-3, (rec, ent, m)
+            assert abs(ent["z"] - m["latent_node_entropy_coders/z/prior_entropy"]) <= 1e-4 * abs(ent["z"]) + 1e-3, (rec, ent, m)
+            assert abs(ent["y"] + ent["z"] - m["prior_entropy"]) <= 1e-4 * m["prior_entropy"] + 1e-3, rec
