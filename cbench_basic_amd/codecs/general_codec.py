@@ -18,7 +18,9 @@ class GeneralCodec(HotPathModule, CodecInterface, VariableRateCodecInterface, Va
         self.prior_first = prior_first
 
     def compress(self, data, *args, **kwargs):
-        if data.device != self.device:  # general_codec.py:46-47 (H2D is part of the timed region there too)
+        # general_codec.py:46-47: the upload is part of compress().  The latent-graph coder does it itself (on its
+        # stream, asynchronously from page-locked memory), so a host batch is handed over as it is.
+        if data.device != self.device and not (data.device.type == "cpu" and hasattr(self.entropy_coder, "_fused_session")):
             data = data.to(device=self.device)
         with self.profiler.start_time_profile("time_compress_entropy_coder"):
             return self.entropy_coder.encode(data, *args, prior=None, **kwargs)

@@ -31,6 +31,14 @@ int require_device();
 
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Raises a kernel's dynamic-LDS limit to the CU's 160 KiB, once per (kernel, device): the attribute belongs to the
+// device's copy of the code object, so a second GPU used by the same process needs its own call.  Thread-safe.
+hipError_t ensure_max_lds(const void *kernel);
+
+// Wavefronts (streams) per workgroup of the calling thread's next batched fast rANS launches (0 = default); returns the
+// previous setting.
+int set_rans_waves(int waves_per_block);
+
 constexpr int kWave = 64;  // CDNA wavefront
 
 }  // namespace basic

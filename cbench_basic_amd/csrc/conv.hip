@@ -1154,6 +1154,14 @@ extern "C" int basic_conv_plan_create(const float *weight, const float *bias, in
     return BASIC_OK;
 }
 
+extern "C" int basic_conv_plan_channels(const basic_conv_plan *p, int *cin_active, int *cout_active)
+{
+    BASIC_REQUIRE(p, "conv_plan_channels: null plan");
+    if (cin_active) *cin_active = p->cin;
+    if (cout_active) *cout_active = p->cout;
+    return BASIC_OK;
+}
+
 extern "C" int basic_conv_plan_out_hw(const basic_conv_plan *p, int in_h, int in_w, int *out_h, int *out_w)
 {
     BASIC_REQUIRE(p && in_h >= 1 && in_w >= 1, "conv_plan_out_hw: bad argument");
@@ -1188,12 +1196,7 @@ namespace {
 template <int MT, int CK, int KH, int KW, int WAVES, int KWB = 0>
 int launch_one(const TapLaunch &g, int blocks, int nsplit, size_t lds_bytes, hipStream_t st)
 {
-    static bool attr_set = false;
-    if (!attr_set) {
-        BASIC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_tap_mfma_kernel<MT, CK, KH, KW, WAVES, KWB>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    BASIC_HIP_TRY(ensure_max_lds(reinterpret_cast<const void *>(conv_tap_mfma_kernel<MT, CK, KH, KW, WAVES, KWB>)));
     hipLaunchKernelGGL((conv_tap_mfma_kernel<MT, CK, KH, KW, WAVES, KWB>), dim3(blocks, nsplit), dim3(64 * WAVES), lds_bytes, st, g);
     BASIC_HIP_TRY(hipGetLastError());
     return BASIC_OK;
@@ -1361,12 +1364,7 @@ extern "C" int basic_conv_forward_dev(const basic_conv_plan *p, const float *d_i
             const int patch_pad1 = (tb * kCK * g.ph * g.pwp + 511) / 512 * 512;
             const size_t lds1 = sizeof(float) * (12800 + 16384 + 2 * static_cast<size_t>(patch_pad1) + 256);
             if (lds1 <= 160 * 1024 && patch_pad1 <= kFirstSlots * 512) {
-                static bool attr1 = false;
-                if (!attr1) {
-                    BASIC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(conv5x5_cin4_gdn_persistent_kernel),
-                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                    attr1 = true;
-                }
+                BASIC_HIP_TRY(ensure_max_lds(reinterpret_cast<const void *>(conv5x5_cin4_gdn_persistent_kernel)));
                 int dev = 0, cus = 256;
                 (void)hipGetDevice(&dev);
                 (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);

@@ -2,6 +2,8 @@
 #include "common.h"
 
 #include <mutex>
+#include <set>
+#include <utility>
 
 namespace basic {
 
@@ -16,6 +18,20 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line)
     g_last_error = buf;
     (void)hipGetLastError();  // clear sticky state
     return BASIC_ERR_HIP;
+}
+
+hipError_t ensure_max_lds(const void *kernel)
+{
+    static std::mutex mu;
+    static std::set<std::pair<const void *, int>> done;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.count({kernel, dev})) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) done.insert({kernel, dev});
+    return e;
 }
 
 int require_device()

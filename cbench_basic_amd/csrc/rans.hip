@@ -557,17 +557,19 @@ __device__ __forceinline__ EncLane enc_prepare(const TablesDev &T, const int2 *r
     return e;
 }
 
-__global__ __launch_bounds__(64) void rans_encode_fast_kernel(TablesDev T, const int32_t *__restrict__ symbols,
-                                                              const int32_t *__restrict__ indexes,
-                                                              const int64_t *__restrict__ seg, uint32_t *out_words,
-                                                              int64_t slot_words, int32_t *out_nwords)
+template <int WPB>
+__global__ __launch_bounds__(64 * WPB) void rans_encode_fast_kernel(TablesDev T, const int32_t *__restrict__ symbols,
+                                                                    const int32_t *__restrict__ indexes,
+                                                                    const int64_t *__restrict__ seg, uint32_t *out_words,
+                                                                    int64_t slot_words, int32_t *out_nwords, int nstreams)
 {
     extern __shared__ uint32_t lds_words[];
     int2 *rowinfo_lds = reinterpret_cast<int2 *>(lds_words);
-    const int stream = blockIdx.x;
-    const int lane = threadIdx.x;
-    for (int r = lane; r < T.rows; r += 64) rowinfo_lds[r] = T.rowinfo[r];
+    const int stream = blockIdx.x * WPB + (WPB > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0);
+    const int lane = threadIdx.x & 63;
+    for (int r = threadIdx.x; r < T.rows; r += 64 * WPB) rowinfo_lds[r] = T.rowinfo[r];
     __syncthreads();
+    if (stream >= nstreams) return;
     const int64_t beg = seg[stream];
     const int64_t n = seg[stream + 1] - beg;
     const int32_t *sym = symbols + beg;
@@ -857,15 +859,21 @@ template <int kBegin, int kEnd, class F> __device__ __forceinline__ void static_
 
 // Per narrow-row symbol the chain is: mask, compare, ballot, two lane broadcasts, 64-bit multiply-add,
 // (rare) renormalisation.
-__global__ __launch_bounds__(64) void rans_decode_fast_kernel(TablesDev T, const uint32_t *__restrict__ words_all,
-                                                              const int64_t *__restrict__ word_off,
-                                                              const int32_t *__restrict__ indexes,
-                                                              const int64_t *__restrict__ seg, int32_t *out_symbols,
-                                                              uint64_t *state, int64_t *pos_io, StridedSeg ss)
+// WPB wavefronts (= streams) per workgroup share ONE LDS copy of the search image: a batch of streams then occupies
+// nstreams / WPB compute units instead of nstreams, and the units it leaves alone keep running the MFMA transforms of
+// another sub-batch on a second HIP stream (the image, not the wave slot, is what excludes a convolution workgroup).
+template <int WPB>
+__global__ __launch_bounds__(64 * WPB) void rans_decode_fast_kernel(TablesDev T, const uint32_t *__restrict__ words_all,
+                                                                    const int64_t *__restrict__ word_off,
+                                                                    const int32_t *__restrict__ indexes,
+                                                                    const int64_t *__restrict__ seg, int32_t *out_symbols,
+                                                                    uint64_t *state, int64_t *pos_io, StridedSeg ss, int nstreams)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t img[];
-    const int stream = blockIdx.x;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int stream_raw = blockIdx.x * WPB + (WPB > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0);
+    const bool live = stream_raw < nstreams;           // a surplus wave of the last workgroup only helps to copy the image
+    const int stream = live ? stream_raw : nstreams - 1;
     const int64_t beg = seg ? seg[stream] : ss.first + stream * ss.stride;
     const int n = static_cast<int>(seg ? seg[stream + 1] - beg : ss.count);
     const int32_t *idx = indexes + beg;
@@ -877,18 +885,20 @@ __global__ __launch_bounds__(64) void rans_decode_fast_kernel(TablesDev T, const
         const u32x4 *src = reinterpret_cast<const u32x4 *>(T.image);
         u32x4 *dst = reinterpret_cast<u32x4 *>(img);
         const int pieces = T.image_words >> 2;
-        int i = lane;
-        for (; i + 7 * 64 < pieces; i += 8 * 64) {
+        constexpr int kT = 64 * WPB;
+        int i = threadIdx.x;
+        for (; i + 7 * kT < pieces; i += 8 * kT) {
             u32x4 v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = src[i + u * 64];
+            for (int u = 0; u < 8; ++u) v[u] = src[i + u * kT];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) dst[i + u * 64] = v[u];
+            for (int u = 0; u < 8; ++u) dst[i + u * kT] = v[u];
         }
-        for (; i < pieces; i += 64) dst[i] = src[i];
-        for (int j = (pieces << 2) + lane; j < T.image_words; j += 64) img[j] = T.image[j];
+        for (; i < pieces; i += kT) dst[i] = src[i];
+        for (int j = (pieces << 2) + static_cast<int>(threadIdx.x); j < T.image_words; j += kT) img[j] = T.image[j];
     }
     __syncthreads();
+    if (!live) return;
 
     const uint32_t *words = words_all + word_off[stream];
     const int limit = static_cast<int>(word_off[stream + 1] - word_off[stream]);
@@ -1085,20 +1095,32 @@ namespace {
 
 constexpr size_t kLdsTableBudget = 144 * 1024;  // of the 160 KiB per CU
 
+// Streams (wavefronts) per workgroup of the batched fast coders.  Default: one per workgroup, spread over the chip (a
+// stream is a serial chain bound by the issue latency of a lone wave; measured on MI355X, 256 streams x 51,200 symbols:
+// 4 per workgroup costs +2 %, 8 +10 %, 16 doubles the chain time).  More per workgroup (BASIC_RANS_WPB = 2/4/8/16, or the
+// codec session's setting) packs a batch onto nstreams / WPB compute units, which leaves the others -- and their LDS,
+// which the decoder's 124 KB search image would otherwise claim -- to transforms running on other HIP streams.
+thread_local int g_wpb_override = 0;   // set by a codec session around its launches (basic::set_rans_waves)
+
+int rans_waves_per_block(int nstreams)
+{
+    static const int forced = [] { const char *e = getenv("BASIC_RANS_WPB"); return e ? atoi(e) : 0; }();
+    int w = g_wpb_override > 0 ? g_wpb_override : forced > 0 ? forced : 1;
+    (void)nstreams;
+    if (w >= 16) return 16;
+    if (w >= 8) return 8;
+    if (w >= 4) return 4;
+    if (w >= 2) return 2;
+    return 1;
+}
+
 template <bool AR, bool LDS>
 int launch_decode_v(const basic_rans_tables *t, const ArDev &ar, int nstreams, hipStream_t st, const uint32_t *d_words,
                     const int64_t *d_word_off, const int32_t *d_indexes, const int64_t *d_seg, int32_t *d_out,
                     uint64_t *d_state, int64_t *d_pos, StridedSeg ss)
 {
     const size_t lds = LDS ? t->cdf16.size() * sizeof(uint16_t) : 0;
-    if (LDS) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            BASIC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(rans_decode_kernel<AR, LDS>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr_set = true;
-        }
-    }
+    if (LDS) BASIC_HIP_TRY(ensure_max_lds(reinterpret_cast<const void *>(rans_decode_kernel<AR, LDS>)));
     hipLaunchKernelGGL((rans_decode_kernel<AR, LDS>), dim3(nstreams), dim3(64), lds, st, dev_view(t), ar, d_words, d_word_off,
                        d_indexes, d_seg, d_out, d_state, d_pos, ss);
     BASIC_HIP_TRY(hipGetLastError());
@@ -1115,14 +1137,22 @@ int launch_decode(const basic_rans_tables *t, const ArDev &ar, int nstreams, hip
     for (int v : t->sizes) max_size = v > max_size ? v : max_size;
     (void)max_size;
     if (!ar.tab && t->fast_ok) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            BASIC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(rans_decode_fast_kernel),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr_set = true;
+        const size_t lds_img = t->image.size() * sizeof(uint32_t);
+        const int wpb = rans_waves_per_block(nstreams);
+#define BASIC_DEC_LAUNCH(W)                                                                                              \
+        do {                                                                                                             \
+            BASIC_HIP_TRY(ensure_max_lds(reinterpret_cast<const void *>(rans_decode_fast_kernel<W>)));                   \
+            hipLaunchKernelGGL(rans_decode_fast_kernel<W>, dim3((nstreams + W - 1) / W), dim3(64 * W), lds_img, st, dev_view(t), \
+                               d_words, d_word_off, d_indexes, d_seg, d_out, d_state, d_pos, ss, nstreams);              \
+        } while (0)
+        switch (wpb) {
+            case 16: BASIC_DEC_LAUNCH(16); break;
+            case 8: BASIC_DEC_LAUNCH(8); break;
+            case 4: BASIC_DEC_LAUNCH(4); break;
+            case 2: BASIC_DEC_LAUNCH(2); break;
+            default: BASIC_DEC_LAUNCH(1); break;
         }
-        hipLaunchKernelGGL(rans_decode_fast_kernel, dim3(nstreams), dim3(64), t->image.size() * sizeof(uint32_t), st, dev_view(t),
-                           d_words, d_word_off, d_indexes, d_seg, d_out, d_state, d_pos, ss);
+#undef BASIC_DEC_LAUNCH
         BASIC_HIP_TRY(hipGetLastError());
         return BASIC_OK;
     }
@@ -1134,6 +1164,15 @@ int launch_decode(const basic_rans_tables *t, const ArDev &ar, int nstreams, hip
 }
 
 }  // namespace
+
+namespace basic {
+int set_rans_waves(int waves_per_block)
+{
+    const int prev = g_wpb_override;
+    g_wpb_override = waves_per_block;
+    return prev;
+}
+}  // namespace basic
 
 namespace {
 inline void put_be32(uint8_t *p, uint32_t v) { p[0] = v >> 24; p[1] = (v >> 16) & 0xFF; p[2] = (v >> 8) & 0xFF; p[3] = v & 0xFF; }
@@ -1204,9 +1243,19 @@ extern "C" int basic_rans_encode_batch_dev(const basic_rans_tables *t, const int
     BASIC_REQUIRE(!t->d_ar, "rans_encode_batch: AR tables are only supported by the host-buffer entry points");
     static const bool no_fast = getenv("BASIC_RANS_NO_FAST_ENCODE") != nullptr;  // profiling ablation
     if (t->fast_enc_ok && !no_fast) {
-        hipLaunchKernelGGL(rans_encode_fast_kernel, dim3(nstreams), dim3(64), static_cast<size_t>(t->rows) * sizeof(int2),
-                           as_stream(hip_stream), dev_view(t), d_symbols, d_indexes, d_seg, d_out_words, slot_words,
-                           d_out_nwords);
+        const size_t lds_rows = static_cast<size_t>(t->rows) * sizeof(int2);
+#define BASIC_ENC_LAUNCH(W)                                                                                          \
+        hipLaunchKernelGGL(rans_encode_fast_kernel<W>, dim3((nstreams + W - 1) / W), dim3(64 * W), lds_rows,         \
+                           as_stream(hip_stream), dev_view(t), d_symbols, d_indexes, d_seg, d_out_words, slot_words, \
+                           d_out_nwords, nstreams)
+        switch (rans_waves_per_block(nstreams)) {
+            case 16: BASIC_ENC_LAUNCH(16); break;
+            case 8: BASIC_ENC_LAUNCH(8); break;
+            case 4: BASIC_ENC_LAUNCH(4); break;
+            case 2: BASIC_ENC_LAUNCH(2); break;
+            default: BASIC_ENC_LAUNCH(1); break;
+        }
+#undef BASIC_ENC_LAUNCH
         BASIC_HIP_TRY(hipGetLastError());
         return BASIC_OK;
     }
@@ -1318,9 +1367,9 @@ extern "C" int basic_rans_encode_host(const basic_rans_tables *t, const int32_t 
     int rc = stage_ar(t, n, ar_indexes, ar_off0, ar_off1, b_ai, b_o0, b_o1, ar);
     if (rc) return rc;
     if (!ar.tab && t->fast_enc_ok)  // same kernel choice as the batched device entry point
-        hipLaunchKernelGGL(rans_encode_fast_kernel, dim3(1), dim3(64), static_cast<size_t>(t->rows) * sizeof(int2), nullptr,
+        hipLaunchKernelGGL(rans_encode_fast_kernel<1>, dim3(1), dim3(64), static_cast<size_t>(t->rows) * sizeof(int2), nullptr,
                            dev_view(t), b_sym.as<int32_t>(), b_idx.as<int32_t>(), b_seg.as<int64_t>(), b_out.as<uint32_t>(),
-                           slot_words, b_nw.as<int32_t>());
+                           slot_words, b_nw.as<int32_t>(), 1);
     else
         hipLaunchKernelGGL(rans_encode_kernel, dim3(1), dim3(64), 0, nullptr, dev_view(t), ar, b_sym.as<int32_t>(),
                            b_idx.as<int32_t>(), b_seg.as<int64_t>(), b_out.as<uint32_t>(), slot_words, b_nw.as<int32_t>());

@@ -212,6 +212,10 @@ class LatentGraphicalANSEntropyCoder(HotPathModule, VariableRateCodecInterface, 
         if self._num_tasks > 0 and self.task_names is None:
             self.task_names = list(range(self._num_tasks))
 
+    # Optional callable run by encode() right after the analysis transforms have been ENQUEUED on the current HIP stream
+    # (before the entropy stage): concurrent stream workers use it to order their transform phases (benchmark/stream_workers.py).
+    after_inference_hook = None
+
     def _levels_valid(self):
         """_complexity_param_valid as a host bool (read once; refreshed after load_state_dict / search)."""
         if self._valid_host is None:
@@ -344,8 +348,60 @@ class LatentGraphicalANSEntropyCoder(HotPathModule, VariableRateCodecInterface, 
             nodes.remove(self.DEFAULT_INPUT_NODE_NAME)
         return nodes
 
+    # ---- fused C entry points for the plain hyperprior graph (include/basic_hip.h section 8)
+    use_fused_session = True    # set False to force the module-by-module path (the two give identical bytes: tests)
+    fused_rans_waves = 0        # wavefronts (image streams) per workgroup of the session's rANS launches; 0 = library default
+
+    def _fused_session(self, kwargs, prior):
+        """The HyperpriorSession serving this graph, or None when the graph is anything but
+        x -g_a-> y -h_a-> z, z: EntropyBottleneck coder, y: GaussianConditional coder on h_s(z), x: dummy
+        (configs/lossy_graph_scalable_exp_hp.py:182-215) with no dynamic nodes / gains / caller-supplied inputs."""
+        if not self.use_fused_session or self.training or prior is not None or kwargs:
+            return None
+        elig = getattr(self, "_fused_eligible", None)
+        if elig is None:
+            from ..prior_model.prior_coder.compressai_coder import (CompressAIEntropyBottleneckPriorCoder,
+                                                                    CompressAIGaussianConditionalCoder)
+            from ...nn.models.google import BasicHyperpriorModule
+            c, inf, gen = self.latent_node_entropy_coders, self.latent_inference_modules, self.latent_generative_modules
+            elig = (list(self.latent_node_inference_topo_order) == ["x", "y", "z"]
+                    and list(self.latent_node_generative_topo_order) == ["z", "y", "x"]
+                    and len(self.node_generators) == 0 and self._num_rate_levels <= 0 and self._num_complex_levels <= 0
+                    and self._num_tasks <= 0 and set(inf.keys()) == {"x_y", "y_z"} and set(gen.keys()) == {"z_y", "y_x"}
+                    and all(type(m).forward is BasicHyperpriorModule.forward for m in list(inf.values()) + list(gen.values()))
+                    and type(c["y"]) is CompressAIGaussianConditionalCoder and type(c["z"]) is CompressAIEntropyBottleneckPriorCoder
+                    and not self.latent_inference_input_mapping and not self.latent_generative_input_mapping
+                    and (self.use_lossy_compression or isinstance(c["x"] if "x" in c else None, LossyDummyEntropyCoder)))
+            self._fused_eligible = bool(elig)
+        if not elig:
+            return None
+        c, inf, gen = self.latent_node_entropy_coders, self.latent_inference_modules, self.latent_generative_modules
+        zc, yc = c["z"], c["y"]
+        zc._ready()
+        yc._ready()
+        plans = [m.plans() for m in (inf["x_y"], inf["y_z"], gen["z_y"], gen["y_x"])]
+        key = tuple(p._h.value for pl in plans for p in pl) + (zc._tables._h.value, yc._tables._h.value)
+        sess = getattr(self, "_fused", None)
+        if sess is None or sess.key != key:
+            from ...nn import kernels as K
+            sess = K.HyperpriorSession(*plans, zc.entropy_bottleneck.medians(), zc._tables, yc.scale_table, yc.scale_bound, yc._tables)
+            self._fused = sess
+        if getattr(sess, "_waves", 0) != self.fused_rans_waves:
+            sess.set_rans_waves(self.fused_rans_waves)
+            sess._waves = self.fused_rans_waves
+        return sess
+
     def encode(self, data, *args, prior=None, **kwargs):
         with torch.no_grad():
+            sess = self._fused_session(kwargs, prior) if not args else None
+            if sess is not None:   # one C call: upload (when the batch is on the host), transforms, entropy stage, framing
+                if data.is_cuda and data.device != self.device:
+                    data = data.to(device=self.device)
+                with self.profiler.start_time_profile("encode_fused"):
+                    out = sess.encode(data)
+                if self.after_inference_hook is not None:
+                    self.after_inference_hook()
+                return out
             if data.device != self.device:
                 data = data.to(device=self.device)
             node_dict = self._node_generate_process(**self._get_default_node_dict(force_add_default_dynamic_nodes=True, **kwargs))
@@ -353,6 +409,8 @@ class LatentGraphicalANSEntropyCoder(HotPathModule, VariableRateCodecInterface, 
             prior_dict = dict() if prior is None else {self.DEFAULT_INPUT_NODE_NAME: dict(prior=prior)}
             with self.profiler.start_time_profile("encode_inference"):
                 latent_dict = self._inference_process(input_dict)
+            if self.after_inference_hook is not None:   # the analysis transforms are enqueued (see stream_workers.py)
+                self.after_inference_hook()
             with self.profiler.start_time_profile("encode_generative"):
                 data_dict, _ = self._generative_process(latent_dict, prior_dict=prior_dict, do_encode=True)
             nodes = self._coded_nodes()
@@ -364,6 +422,10 @@ class LatentGraphicalANSEntropyCoder(HotPathModule, VariableRateCodecInterface, 
 
     def decode(self, data, *args, prior=None, **kwargs):
         with torch.no_grad():
+            sess = self._fused_session(kwargs, prior) if not args else None
+            if sess is not None:
+                with self.profiler.start_time_profile("decode_fused"):
+                    return sess.decode(data, device=self.device)
             node_dict = self._node_generate_process(**self._get_default_node_dict(force_add_default_dynamic_nodes=True, **kwargs))
             nodes = self._coded_nodes()
             # coders that read their stream through the buffer protocol get it in place; others get bytes

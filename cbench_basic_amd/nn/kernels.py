@@ -395,3 +395,69 @@ def unframe_streams(data: bytes, out=None):
     _lib.check(_lib.lib().basic_unframe_streams(buf.ctypes.data, len(data), ctypes.byref(h), ctypes.byref(w), ctypes.byref(n),
                                                 word_off.ctypes.data, n.value, words.ctypes.data))
     return words[: int(word_off[-1])], word_off, (h.value, w.value)
+
+
+class HyperpriorSession:
+    """basic_hp_session_*: the fused compress / decompress entry points of the plain hyperprior latent graph (one C call
+    per batch instead of a Python walk over the graph).  Borrows the layer plans and table sets it is given (kept alive
+    here); one session serves one call at a time."""
+
+    def __init__(self, g_a, h_a, h_s, g_s, eb_medians, z_tables, scale_table, scale_bound, y_tables):
+        self._keep = (list(g_a), list(h_a), list(h_s), list(g_s), z_tables, y_tables)
+        arrs = []
+        for plans in self._keep[:4]:
+            a = (ctypes.c_void_p * len(plans))(*[p._h for p in plans])
+            arrs.append(a)
+        med = np.ascontiguousarray(eb_medians.detach().cpu().numpy() if isinstance(eb_medians, torch.Tensor) else eb_medians, dtype=np.float32)
+        tab = np.ascontiguousarray(scale_table.detach().cpu().numpy() if isinstance(scale_table, torch.Tensor) else scale_table, dtype=np.float32)
+        h = ctypes.c_void_p()
+        _lib.check(_lib.lib().basic_hp_session_create(arrs[0], len(g_a), arrs[1], len(h_a), arrs[2], len(h_s), arrs[3], len(g_s),
+                                                      med.ctypes.data, med.size, z_tables._h, tab.ctypes.data, tab.size,
+                                                      float(scale_bound), y_tables._h, ctypes.byref(h)))
+        self._h = h
+        self.key = tuple(p._h.value for plans in self._keep[:4] for p in plans) + (z_tables._h.value, y_tables._h.value)
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                _lib.lib().basic_hp_session_destroy(h)
+            except Exception:
+                pass
+
+    def set_rans_waves(self, waves_per_block):
+        _lib.check(_lib.lib().basic_hp_session_set_rans_waves(self._h, int(waves_per_block)))
+
+    def encode(self, x) -> bytes:
+        """x: float32 [B, C, H, W], on the GPU or on the host (uploaded inside the call; pinned memory goes at DMA rate)."""
+        if x.dtype != torch.float32:
+            raise TypeError(f"expected float32, got {x.dtype}")
+        x = x.contiguous()
+        B, C, H, W = x.shape
+        cap = _lib.lib().basic_hp_encode_bound(self._h, B, H, W)
+        if cap < 0:
+            raise ValueError("hp_encode_bound: bad shape")
+        # the bound is the coder's worst case (12 bytes per symbol); a stream of real latents is far below 1 byte per symbol
+        guess = min(cap, 4 + 2 * (12 + 4 * B) + B * ((C * H * W) // 48 + 4096))
+        api = ctypes.pythonapi
+        api.PyBytes_FromStringAndSize.restype, api.PyBytes_FromStringAndSize.argtypes = ctypes.py_object, [ctypes.c_char_p, ctypes.c_ssize_t]
+        api.PyBytes_AsString.restype, api.PyBytes_AsString.argtypes = ctypes.c_void_p, [ctypes.py_object]
+        n = ctypes.c_int64()
+        for size in (guess, cap):
+            buf = np.empty(size, dtype=np.uint8)
+            rc = _lib.lib().basic_hp_encode_images(self._h, x.data_ptr(), 0 if x.is_cuda else 1, B, H, W, buf.ctypes.data, size,
+                                                   ctypes.byref(n), _stream())
+            if rc == _lib.ERR_OVERFLOW and size != cap:
+                continue
+            _lib.check(rc)
+            return buf[: n.value].tobytes()
+
+    def decode(self, data, device=None):
+        buf = np.frombuffer(data, dtype=np.uint8)
+        b, c, h, w = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        _lib.check(_lib.lib().basic_hp_decoded_shape(self._h, buf.ctypes.data, buf.size, ctypes.byref(b), ctypes.byref(c),
+                                                     ctypes.byref(h), ctypes.byref(w)))
+        out = torch.empty((b.value, c.value, h.value, w.value), device=device or torch.device("cuda", torch.cuda.current_device()),
+                          dtype=torch.float32)
+        _lib.check(_lib.lib().basic_hp_decode_images(self._h, buf.ctypes.data, buf.size, out.data_ptr(), out.numel(), _stream()))
+        return out

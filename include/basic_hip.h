@@ -203,6 +203,8 @@ int basic_conv_plan_create(const float *weight, const float *bias, int cin, int 
                            const float *gamma, const float *beta, int cin_active, int cout_active,
                            basic_conv_plan **out);
 int basic_conv_plan_out_hw(const basic_conv_plan *p, int in_h, int in_w, int *out_h, int *out_w);
+/* Active (sliced) channel counts of the plan's input and output tensors. */
+int basic_conv_plan_channels(const basic_conv_plan *p, int *cin_active, int *cout_active);
 /* d_in: float32 [batch][cin_active][in_h][in_w]; d_out: float32 [batch][cout_active][out_h][out_w]. */
 int basic_conv_forward_dev(const basic_conv_plan *p, const float *d_in, int batch, int in_h, int in_w,
                            float *d_out, void *hip_stream);
@@ -254,6 +256,46 @@ void basic_mconv_plan_destroy(basic_mconv_plan *p);
  * ==================================================================================== */
 int basic_mse_per_image_dev(const float *d_a, const float *d_b, int batch, int64_t elems_per_image,
                             float *d_mse, void *hip_stream);
+
+/* ======================================================================================
+ * 8. Fused image entry points of the plain hyperprior latent graph (SURVEY 8b "basic_encode_image / decode_image"):
+ *    ONE call runs what GeneralCodec.compress / decompress run for that graph
+ *      compress   general_codec.py:44-89 -> LatentGraphicalANSEntropyCoder.encode latent_graph.py:1232-1264
+ *                 x -> g_a -> y -> h_a -> z ; EntropyBottleneck coder (compressai_coder.py:230-236) ; h_s ;
+ *                 GaussianConditional coder (:377-385) ; merge_bytes([z body, y body], num_segments=2)
+ *      decompress general_codec.py:91-130 -> .decode latent_graph.py:1266-1295 ; g_s
+ *    with the same kernels in the same order as the module-by-module path, so the bytes are identical; the host
+ *    side of a call is ~60 kernel launches from C++ instead of a Python interpreter walking the graph.
+ *    A session BORROWS the layer plans and table sets (they must outlive it), owns its device workspace and pinned
+ *    staging buffers, and serves one call at a time (one session per host thread / HIP stream).
+ *    Wire format: [u32 native-endian len(z body)] [z body] [y body]; a body is write_body's ">III" (h, w, n) followed by
+ *    ">I" length + rANS words per image (compressai_coder.py:63-84).
+ * ==================================================================================== */
+typedef struct basic_hp_session basic_hp_session;
+/* g_a / h_a / h_s / g_s: the fused layer plans of each transform in execution order.  eb_medians: float32
+ * [z_channels] (host).  scale_table: float32 [n_scales] (host), scale_bound = GaussianConditional's lower bound. */
+int basic_hp_session_create(const basic_conv_plan *const *g_a, int n_g_a, const basic_conv_plan *const *h_a, int n_h_a,
+                            const basic_conv_plan *const *h_s, int n_h_s, const basic_conv_plan *const *g_s, int n_g_s,
+                            const float *eb_medians, int z_channels, const basic_rans_tables *z_tables,
+                            const float *scale_table, int n_scales, float scale_bound,
+                            const basic_rans_tables *y_tables, basic_hp_session **out);
+/* Upper bound of basic_hp_encode_images' output for this input shape (always sufficient). */
+int64_t basic_hp_encode_bound(const basic_hp_session *s, int batch, int h, int w);
+/* x: float32 [batch][cin][h][w], on the device (x_on_host == 0) or in host memory (x_on_host != 0: uploaded inside the
+ * call on hip_stream -- asynchronously when the memory is page-locked -- as GeneralCodec.compress does,
+ * general_codec.py:46-47).  Returns with the bytes complete in `out` (the stream has been synchronised). */
+int basic_hp_encode_images(basic_hp_session *s, const float *x, int x_on_host, int batch, int h, int w, uint8_t *out,
+                           int64_t out_capacity, int64_t *out_len, void *hip_stream);
+/* Shape of the reconstruction a stream decodes to (from its headers only). */
+int basic_hp_decoded_shape(const basic_hp_session *s, const uint8_t *data, int64_t len, int *batch, int *channels, int *h,
+                           int *w);
+/* d_xhat: float32 [batch][channels][h][w] on the device (the un-clamped output of g_s).  The work is ENQUEUED on
+ * hip_stream; the call returns once the stream words have left `data` (no final synchronisation). */
+int basic_hp_decode_images(basic_hp_session *s, const uint8_t *data, int64_t len, float *d_xhat,
+                           int64_t xhat_capacity_floats, void *hip_stream);
+/* Wavefronts (image streams) per workgroup of this session's rANS launches: 1, 2, 4, 8 or 16 (0 = library default). */
+int basic_hp_session_set_rans_waves(basic_hp_session *s, int waves_per_block);
+void basic_hp_session_destroy(basic_hp_session *s);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,86 @@
+"""The fused C entry points (basic_hp_encode_images / basic_hp_decode_images, include/basic_hip.h section 8) against the
+module-by-module path of the same codec: identical bytes, identical reconstruction, for device and host inputs, ragged
+sizes (cropped hyper-synthesis output) and several batch sizes; and against the CPU oracle."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def codec():
+    from cbench_basic_amd.presets import hyperprior_codec, seed_synthetic_weights
+    c = seed_synthetic_weights(hyperprior_codec(), seed=0).eval().cuda()
+    c.update_state()
+    return c
+
+
+@pytest.mark.parametrize("shape", [(1, 3, 64, 64), (3, 3, 128, 192), (2, 3, 80, 112), (7, 3, 64, 64), (1, 3, 48, 272), (16, 3, 256, 256)])
+def test_fused_equals_module_path(codec, shape):
+    ec = codec.entropy_coder
+    torch.manual_seed(sum(shape))
+    x = torch.rand(*shape)
+    ec.use_fused_session = False
+    ref = codec.compress(x.cuda())
+    xref = codec.decompress(ref)
+    ec.use_fused_session = True
+    assert ec._fused_session({}, None) is not None, "the plain hyperprior graph must be served by the fused session"
+    for inp in (x.cuda(), x, x.pin_memory()):       # device, pageable host, page-locked host
+        data = codec.compress(inp)
+        assert data == ref, (shape, inp.device, inp.is_pinned() if not inp.is_cuda else None)
+    xhat = codec.decompress(ref)
+    assert xhat.is_cuda and xhat.shape == xref.shape and torch.equal(xhat, xref)
+    assert ec.profiler.count["encode_fused"] >= 3 and ec.profiler.count["decode_fused"] >= 1
+
+
+def test_fused_vs_cpu_oracle(codec):
+    from oracle.codec_oracle import HyperpriorOracle
+    oracle = HyperpriorOracle({k: v.cpu() for k, v in codec.entropy_coder.state_dict().items()})
+    torch.manual_seed(5)
+    x = torch.rand(2, 3, 128, 64)
+    data = codec.compress(x)
+    assert data == oracle.compress(x)
+    assert float((codec.decompress(data).cpu() - oracle.decompress(data)).abs().max()) < 1e-3
+
+
+def test_fused_rans_waves_do_not_change_bytes(codec):
+    ec = codec.entropy_coder
+    torch.manual_seed(9)
+    x = torch.rand(40, 3, 64, 64).cuda()
+    ec.fused_rans_waves = 0
+    ref = codec.compress(x)
+    xref = codec.decompress(ref)
+    try:
+        for w in (1, 2, 4, 8, 16):
+            ec.fused_rans_waves = w
+            assert codec.compress(x) == ref, w
+            assert torch.equal(codec.decompress(ref), xref), w
+    finally:
+        ec.fused_rans_waves = 0
+
+
+def test_fused_bypass_heavy_latents_take_the_retry_path(codec):
+    """Latents far outside the tables make every symbol a bypass symbol: the reference-sized slot (n + 2 words) overflows
+    and the session re-encodes with the guaranteed slot; the bytes still equal the module path's."""
+    import copy
+    from cbench_basic_amd.presets import hyperprior_codec, seed_synthetic_weights
+    c = seed_synthetic_weights(hyperprior_codec(N=32, M=48), seed=1).eval()
+    with torch.no_grad():
+        c.entropy_coder.latent_inference_modules["x_y"].model[6].weight.mul_(4000.0)
+    c = c.cuda()
+    c.update_state()
+    torch.manual_seed(2)
+    x = torch.rand(2, 3, 64, 64).cuda()
+    c.entropy_coder.use_fused_session = False
+    ref = c.compress(x)
+    c.entropy_coder.use_fused_session = True
+    data = c.compress(x)
+    assert data == ref and len(data) > 2 * 48 * 16 * 4   # more than 4 bytes per symbol: bypass everywhere
+    assert torch.equal(c.decompress(data), c.decompress(ref))
+
+
+def test_non_hyperprior_graphs_keep_the_module_path():
+    from cbench_basic_amd.presets import topogroup_ar_codec
+    c = topogroup_ar_codec("checkerboard", N=32, M=48).eval().cuda()
+    c.update_state()
+    assert c.entropy_coder._fused_session({}, None) is None
