@@ -61,9 +61,11 @@ _SIGNATURES = {
     "basic_hp_session_create": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _F, _P, _P]),
     "basic_hp_encode_bound": (_L, [_P, _I, _I, _I]),
     "basic_hp_encode_images": (_I, [_P, _P, _I, _I, _I, _I, _P, _L, _P, _P]),
+    "basic_hp_encode_result": (_I, [_P, _P, _L, _P]),
     "basic_hp_decoded_shape": (_I, [_P, _P, _L, _P, _P, _P, _P]),
     "basic_hp_decode_images": (_I, [_P, _P, _L, _P, _L, _P]),
     "basic_hp_session_set_rans_waves": (_I, [_P, _I]),
+    "basic_hp_session_set_transform_token": (_I, [_P, _I]),
     "basic_hp_session_destroy": (None, [_P]),
     "basic_conv_plan_destroy": (None, [_P]),
     "basic_conv_plan_flops": (_L, [_P, _I, _I, _I]),

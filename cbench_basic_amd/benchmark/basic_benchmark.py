@@ -66,7 +66,10 @@ class BasicLosslessCompressionBenchmark:
             torch.cuda.synchronize()  # the device queue is empty before and after every timed region
 
     def _run_step(self, step, data, metric_logger):
-        data_input = data_target = data.to(self.force_testing_device) if self.force_testing_device else data
+        # the batch stays where the loader left it (the host): codec.compress() uploads it INSIDE the timed region, as the
+        # reference's does (general_codec.py:46-47 under basic_benchmark.py:199-202); only the metric's target is moved
+        data_input = data
+        data_target = data.to(self.force_testing_device) if self.force_testing_device else data
         original_length = self._estimate_byte_length(data_input)
         metric_logger.update(original_length=original_length)
         dm = self.distortion_metric

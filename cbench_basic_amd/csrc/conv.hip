@@ -455,7 +455,12 @@ __global__ __launch_bounds__(64 * WAVES, (MT <= 4 && WAVES == 4 ? 2 : 1)) void c
 // ---------------------------------------------------------------------------------------------
 constexpr int kFirstSlots = 10;  // patch elements per thread (512 threads): <= 5120 floats, checked by the host
 
-__global__ __launch_bounds__(512, 1) void conv5x5_cin4_gdn_persistent_kernel(const TapLaunch g, int ntiles)
+// Tiles: workgroup w starts with tile w; further tiles are handed out by `sched` (a device counter the host zeroes
+// before the launch), fetched one tile ahead so that the patch DMA of the next tile still overlaps this tile's MFMAs.  A
+// static stride (tile += gridDim.x, what runs when sched == nullptr) makes the launch as slow as its LAST workgroup to
+// start: with rANS workgroups of another HIP stream holding the LDS of some compute units for milliseconds, the workgroups
+// meant for those units start late with their full share of tiles still to do (measured 1.07 -> 2.05 ms at 128 images).
+__global__ __launch_bounds__(512, 1) void conv5x5_cin4_gdn_persistent_kernel(const TapLaunch g, int ntiles, int *sched)
 {
     extern __shared__ float lds[];
     constexpr int MT = 4, kCK = 4, KW = 5, kSteps = 25 * 2;
@@ -474,6 +479,7 @@ __global__ __launch_bounds__(512, 1) void conv5x5_cin4_gdn_persistent_kernel(con
     const int n_pslots = patch_pad / 512;
     float *pbuf = gl + kGFloats;  // two patch buffers of patch_pad floats
     float *chan_const = pbuf + 2 * patch_pad;  // [128] bias, [128] beta: read from LDS in every tile's epilogue
+    int *next_slot = reinterpret_cast<int *>(chan_const + 256);  // [2]: the tile after next, published one barrier ahead
     if (tid < 128) {
         chan_const[tid] = g.bias ? g.bias[tid] : 0.f;
         chan_const[128 + tid] = g.beta ? g.beta[tid] : 1.f;
@@ -546,14 +552,20 @@ __global__ __launch_bounds__(512, 1) void conv5x5_cin4_gdn_persistent_kernel(con
 
     int tile = blockIdx.x;
     if (tile < ntiles) BASIC_FIRST_ISSUE_PATCH(tile, 0);
+    if (sched && tid == 0) next_slot[1] = static_cast<int>(gridDim.x) + atomicAdd(sched, 1);   // tile of iteration 1
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // weights, gamma and the first patch: this wave's DMAs have landed
-    for (int it = 0; tile < ntiles; tile += gridDim.x, ++it) {
+    int tile_next = tile + static_cast<int>(gridDim.x);
+    for (int it = 0; tile < ntiles; tile = tile_next, ++it) {
         // Every wave waited for its own DMAs of this tile's patch BEFORE it issued the previous tile's stores (below), so a
         // bare barrier publishes the patch -- and, unlike __syncthreads(), does not wait for those 64 stores per lane: the
         // HBM-bound store phase of tile i drains underneath the MFMAs of tile i + 1.
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (tile + static_cast<int>(gridDim.x) < ntiles && !(g.debug & 1)) BASIC_FIRST_ISSUE_PATCH(tile + gridDim.x, (it + 1) & 1);
+        // the barrier also published next_slot[(it + 1) & 1], written by thread 0 during the previous iteration
+        tile_next = sched ? __builtin_amdgcn_readfirstlane(next_slot[(it + 1) & 1]) : tile + static_cast<int>(gridDim.x);
+        if (tile_next < ntiles && !(g.debug & 1)) BASIC_FIRST_ISSUE_PATCH(tile_next, (it + 1) & 1);
+        int tile_after = 0;   // thread 0: the tile of iteration it + 2, requested now, published at the end of this iteration
+        if (sched && tid == 0) tile_after = static_cast<int>(gridDim.x) + atomicAdd(sched, 1);
         const float *patch = pbuf + (it & 1) * patch_pad;
 
         f32x16 acc[MT];
@@ -649,6 +661,8 @@ __global__ __launch_bounds__(512, 1) void conv5x5_cin4_gdn_persistent_kernel(con
                     oc += 4 * plane;
                 }
         }
+        // slot it & 1 was last read right after THIS iteration's barrier: free to take the tile of iteration it + 2
+        if (sched && tid == 0) next_slot[it & 1] = tile_after;
     }
 #undef BASIC_FIRST_ISSUE_PATCH
 }
@@ -921,6 +935,7 @@ struct basic_conv_plan {
     std::vector<Chunk> split;  // the same layer as 32-channel slices over gridDim.y (small position grids), may be empty
     float *d_gammaT = nullptr, *d_beta = nullptr;
     float *d_wsm = nullptr, *d_bias4 = nullptr;  // VALU path of the Cout <= 4 synthesis output layer
+    int *d_sched = nullptr;                      // tile counter of the persistent first-layer kernel (allocated on first use)
 };
 
 extern "C" void basic_conv_plan_destroy(basic_conv_plan *p)
@@ -934,6 +949,7 @@ extern "C" void basic_conv_plan_destroy(basic_conv_plan *p)
                 if (ph.d_wpack) (void)hipFree(ph.d_wpack);
             if (ch.d_bias) (void)hipFree(ch.d_bias);
         }
+    if (p->d_sched) (void)hipFree(p->d_sched);
     if (p->d_wsm) (void)hipFree(p->d_wsm);
     if (p->d_bias4) (void)hipFree(p->d_bias4);
     if (p->d_gammaT) (void)hipFree(p->d_gammaT);
@@ -1362,14 +1378,17 @@ extern "C" int basic_conv_forward_dev(const basic_conv_plan *p, const float *d_i
         if (first_layer_path) {
             // single-stage GDN layer (the first analysis layer): persistent workgroups with resident weights and gamma
             const int patch_pad1 = (tb * kCK * g.ph * g.pwp + 511) / 512 * 512;
-            const size_t lds1 = sizeof(float) * (12800 + 16384 + 2 * static_cast<size_t>(patch_pad1) + 256);
+            const size_t lds1 = sizeof(float) * (12800 + 16384 + 2 * static_cast<size_t>(patch_pad1) + 256 + 4);
             if (lds1 <= 160 * 1024 && patch_pad1 <= kFirstSlots * 512) {
                 BASIC_HIP_TRY(ensure_max_lds(reinterpret_cast<const void *>(conv5x5_cin4_gdn_persistent_kernel)));
                 int dev = 0, cus = 256;
                 (void)hipGetDevice(&dev);
                 (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
                 const int grid = blocks < cus ? blocks : cus;
-                hipLaunchKernelGGL(conv5x5_cin4_gdn_persistent_kernel, dim3(grid), dim3(512), lds1, st, g, blocks);
+                auto *pm = const_cast<basic_conv_plan *>(p);   // the counter is scratch of the launch, not plan state
+                if (!pm->d_sched) BASIC_HIP_TRY(hipMalloc(&pm->d_sched, sizeof(int)));
+                BASIC_HIP_TRY(hipMemsetAsync(pm->d_sched, 0, sizeof(int), st));
+                hipLaunchKernelGGL(conv5x5_cin4_gdn_persistent_kernel, dim3(grid), dim3(512), lds1, st, g, blocks, pm->d_sched);
                 BASIC_HIP_TRY(hipGetLastError());
                 continue;
             }

@@ -563,6 +563,10 @@ __global__ __launch_bounds__(64 * WPB) void rans_encode_fast_kernel(TablesDev T,
                                                                     const int64_t *__restrict__ seg, uint32_t *out_words,
                                                                     int64_t slot_words, int32_t *out_nwords, int nstreams)
 {
+    // A stream is a serial chain that issues one instruction every ~8 cycles: when its wave shares a SIMD with the waves of
+    // an MFMA transform running on another HIP stream, losing the issue arbitration stretches the chain several times over
+    // (measured: 2.4 -> 11.9 ms beside conv_tap_mfma_kernel), while winning it costs the other waves next to nothing.
+    __builtin_amdgcn_s_setprio(3);
     extern __shared__ uint32_t lds_words[];
     int2 *rowinfo_lds = reinterpret_cast<int2 *>(lds_words);
     const int stream = blockIdx.x * WPB + (WPB > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0);
@@ -869,6 +873,7 @@ __global__ __launch_bounds__(64 * WPB) void rans_decode_fast_kernel(TablesDev T,
                                                                     const int64_t *__restrict__ seg, int32_t *out_symbols,
                                                                     uint64_t *state, int64_t *pos_io, StridedSeg ss, int nstreams)
 {
+    __builtin_amdgcn_s_setprio(3);   // see rans_encode_fast_kernel
     extern __shared__ __attribute__((aligned(16))) uint32_t img[];
     const int lane = threadIdx.x & 63;
     const int stream_raw = blockIdx.x * WPB + (WPB > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0);
@@ -1243,12 +1248,23 @@ extern "C" int basic_rans_encode_batch_dev(const basic_rans_tables *t, const int
     BASIC_REQUIRE(!t->d_ar, "rans_encode_batch: AR tables are only supported by the host-buffer entry points");
     static const bool no_fast = getenv("BASIC_RANS_NO_FAST_ENCODE") != nullptr;  // profiling ablation
     if (t->fast_enc_ok && !no_fast) {
-        const size_t lds_rows = static_cast<size_t>(t->rows) * sizeof(int2);
+        // Packed launches (several streams per workgroup) exist to share the chip with transforms on other HIP streams.
+        // The encoder needs almost no LDS, so a convolution workgroup would settle on the same compute unit -- and its
+        // LDS-DMA traffic then owns that unit's vector-memory queue: the encoder's table gathers wait behind it and the
+        // chain runs 6x slower (measured: 4.0 -> 25 ms beside conv_tap_mfma_kernel, while the decoder, whose 124 KB
+        // search image keeps its unit to itself, goes 8.1 -> 8.6 ms).  So a packed encoder workgroup claims the whole
+        // unit's LDS as well: nstreams / W units are then the coder's alone.
+        const int wpb_ = rans_waves_per_block(nstreams);
+        size_t lds_rows = static_cast<size_t>(t->rows) * sizeof(int2);
+        if (wpb_ > 1 && lds_rows < 159 * 1024) lds_rows = 159 * 1024;
 #define BASIC_ENC_LAUNCH(W)                                                                                          \
+        do {                                                                                                         \
+        if (lds_rows > 64 * 1024) BASIC_HIP_TRY(ensure_max_lds(reinterpret_cast<const void *>(rans_encode_fast_kernel<W>))); \
         hipLaunchKernelGGL(rans_encode_fast_kernel<W>, dim3((nstreams + W - 1) / W), dim3(64 * W), lds_rows,         \
                            as_stream(hip_stream), dev_view(t), d_symbols, d_indexes, d_seg, d_out_words, slot_words, \
-                           d_out_nwords, nstreams)
-        switch (rans_waves_per_block(nstreams)) {
+                           d_out_nwords, nstreams);                                                                  \
+        } while (0)
+        switch (wpb_) {
             case 16: BASIC_ENC_LAUNCH(16); break;
             case 8: BASIC_ENC_LAUNCH(8); break;
             case 4: BASIC_ENC_LAUNCH(4); break;

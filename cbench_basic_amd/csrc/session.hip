@@ -8,6 +8,7 @@
 #include "common.h"
 
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 using namespace basic;
@@ -112,8 +113,12 @@ struct basic_hp_session {
     DBuf act[2], d_x, d_y, d_z, d_zhat, d_prior, d_scales;
     DBuf z_sym, z_idx, y_sym, y_idx, seg_z, seg_y, slots_z, slots_y, nw, off, packed, words, woff, state, pos;
     HBuf h_nw, h_words, h_in;
+    std::vector<int64_t> off_z, off_y;   // word offsets of the last encoded batch (its words sit in h_words)
+    int res_batch = 0, res_zh = 0, res_zw = 0, res_yh = 0, res_yw = 0;
     hipEvent_t in_done = nullptr;   // the last decode's upload out of h_in
-    ~basic_hp_session() { if (in_done) (void)hipEventDestroy(in_done); }
+    bool use_token = false;
+    hipEvent_t enc_phase = nullptr, dec_phase = nullptr;   // close this session's transform phases (see TransformToken)
+    ~basic_hp_session();
 };
 
 namespace {
@@ -166,13 +171,64 @@ int chain_out_hw(const std::vector<const basic_conv_plan *> &plans, int h, int w
     return BASIC_OK;
 }
 
+// The "transform token": sessions that opt in (basic_hp_session_set_transform_token) run their MFMA-heavy phases one
+// after another in GPU time, in the order their host threads enqueue them -- a phase starts with a stream-wait on the
+// event that closed the previous holder's phase and ends by recording its own.  Without it, equal workers drift into
+// lock-step (all in their transforms together, sharing the chip; then all in their rANS chains together, leaving it
+// idle); with it, one worker's chains always run beside another worker's transforms.  Nothing blocks on the host
+// except the short critical section that keeps wait / launches / record of one phase together.
+struct TransformToken {
+    std::mutex mu;
+    hipEvent_t last = nullptr;   // closes the most recently enqueued phase (owned by the session that recorded it)
+};
+TransformToken g_token;
+
+struct TokenPhase {   // RAII: a phase of one session on one stream
+    basic_hp_session *s;
+    hipStream_t st;
+    hipEvent_t *evt;
+    bool on;
+    int rc = BASIC_OK;
+    TokenPhase(basic_hp_session *s_, hipStream_t st_, hipEvent_t *evt_);
+    int close();
+    ~TokenPhase() { if (on) (void)close(); }
+};
+
 struct WavesGuard {   // the session's rANS geometry applies to this thread's launches for the duration of a call
     int prev;
     explicit WavesGuard(int w) : prev(set_rans_waves(w)) {}
     ~WavesGuard() { set_rans_waves(prev); }
 };
 
+TokenPhase::TokenPhase(basic_hp_session *s_, hipStream_t st_, hipEvent_t *evt_) : s(s_), st(st_), evt(evt_), on(s_->use_token)
+{
+    if (!on) return;
+    g_token.mu.lock();
+    hipError_t e = hipSuccess;
+    if (!*evt) e = hipEventCreateWithFlags(evt, hipEventDisableTiming);
+    if (e == hipSuccess && g_token.last && g_token.last != *evt) e = hipStreamWaitEvent(st, g_token.last, 0);
+    if (e != hipSuccess) rc = hip_fail(e, "transform token: wait", __FILE__, __LINE__);
+}
+
+int TokenPhase::close()
+{
+    if (!on) return rc;
+    on = false;
+    hipError_t e = hipEventRecord(*evt, st);
+    if (e == hipSuccess) g_token.last = *evt;
+    g_token.mu.unlock();
+    if (e != hipSuccess && rc == BASIC_OK) rc = hip_fail(e, "transform token: record", __FILE__, __LINE__);
+    return rc;
+}
+
 }  // namespace
+
+extern "C" int basic_hp_session_set_transform_token(basic_hp_session *s, int enable)
+{
+    BASIC_REQUIRE(s, "hp_session_set_transform_token: null session");
+    s->use_token = enable != 0;
+    return BASIC_OK;
+}
 
 extern "C" int basic_hp_session_create(const basic_conv_plan *const *g_a, int n_g_a, const basic_conv_plan *const *h_a, int n_h_a,
                                        const basic_conv_plan *const *h_s, int n_h_s, const basic_conv_plan *const *g_s, int n_g_s,
@@ -221,6 +277,19 @@ extern "C" int basic_hp_session_create(const basic_conv_plan *const *g_a, int n_
     return BASIC_OK;
 }
 
+basic_hp_session::~basic_hp_session()
+{
+    {
+        std::lock_guard<std::mutex> lock(g_token.mu);
+        if (g_token.last && (g_token.last == enc_phase || g_token.last == dec_phase)) {
+            (void)hipEventSynchronize(g_token.last);   // whoever waits on it has been released
+            g_token.last = nullptr;
+        }
+    }
+    for (hipEvent_t e : {in_done, enc_phase, dec_phase})
+        if (e) (void)hipEventDestroy(e);
+}
+
 extern "C" void basic_hp_session_destroy(basic_hp_session *s) { delete s; }
 
 extern "C" int basic_hp_session_set_rans_waves(basic_hp_session *s, int waves_per_block)
@@ -262,7 +331,8 @@ int encode_latent(basic_hp_session *s, const basic_rans_tables *t, const int32_t
 extern "C" int basic_hp_encode_images(basic_hp_session *s, const float *x, int x_on_host, int batch, int h, int w, uint8_t *out,
                                       int64_t out_capacity, int64_t *out_len, void *hip_stream)
 {
-    BASIC_REQUIRE(s && x && out && out_len && batch >= 1 && h >= 1 && w >= 1, "hp_encode_images: bad argument");
+    BASIC_REQUIRE(s && x && out_len && batch >= 1 && h >= 1 && w >= 1, "hp_encode_images: bad argument");
+    s->res_batch = 0;
     hipStream_t st = as_stream(hip_stream);
     WavesGuard guard(s->rans_waves);
     int rc;
@@ -276,7 +346,11 @@ extern "C" int basic_hp_encode_images(basic_hp_session *s, const float *x, int x
     }
     // ---- inference pass x -> y -> z (latent_graph.py:721-758)
     int yh, yw, zh, zw, ph, pw;
+    TokenPhase phase(s, st, &s->enc_phase);   // the analysis transform: ~95 % of the encoder's MFMA work
+    if (phase.rc) return phase.rc;
     rc = run_chain(s, s->g_a, d_x, batch, h, w, &s->d_y, nullptr, &yh, &yw, st);
+    if (rc) return rc;
+    rc = phase.close();   // the small hyper-path kernels and both rANS stages run beside the next holder's transforms
     if (rc) return rc;
     rc = run_chain(s, s->h_a, s->d_y.as<float>(), batch, yh, yw, &s->d_z, nullptr, &zh, &zw, st);
     if (rc) return rc;
@@ -354,9 +428,10 @@ extern "C" int basic_hp_encode_images(basic_hp_session *s, const float *x, int x
             if (rc) return rc;
         }
     }
-    std::vector<int64_t> off_z(batch + 1, 0), off_y(batch + 1, 0);
-    for (int i = 0; i < batch; ++i) { off_z[i + 1] = off_z[i] + h_nw[i]; off_y[i + 1] = off_y[i] + h_nw[batch + i]; }
-    const int64_t wz = off_z[batch], wy = off_y[batch];
+    s->off_z.assign(batch + 1, 0);
+    s->off_y.assign(batch + 1, 0);
+    for (int i = 0; i < batch; ++i) { s->off_z[i + 1] = s->off_z[i] + h_nw[i]; s->off_y[i + 1] = s->off_y[i] + h_nw[batch + i]; }
+    const int64_t wz = s->off_z[batch], wy = s->off_y[batch];
     rc = s->h_words.ensure(sizeof(uint32_t) * static_cast<size_t>(wz + wy));
     if (rc) return rc;
     uint32_t *h_wz = s->h_words.as<uint32_t>(), *h_wy = h_wz + wz;
@@ -364,19 +439,31 @@ extern "C" int basic_hp_encode_images(basic_hp_session *s, const float *x, int x
     if (wz) BASIC_HIP_TRY(hipMemcpyAsync(h_wz, d_pz, sizeof(uint32_t) * wz, hipMemcpyDeviceToHost, st));
     if (wy) BASIC_HIP_TRY(hipMemcpyAsync(h_wy, d_py, sizeof(uint32_t) * wy, hipMemcpyDeviceToHost, st));
     BASIC_HIP_TRY(hipStreamSynchronize(st));
-    // ---- framing: merge_bytes([z body, y body], num_segments=2) with write_body bodies (bytes_ops.py:19-33)
+    s->res_batch = batch; s->res_zh = zh; s->res_zw = zw; s->res_yh = yh; s->res_yw = yw;
+    *out_len = 4 + (12 + 4ll * batch + 4 * wz) + (12 + 4ll * batch + 4 * wy);
+    if (!out) return BASIC_OK;   // the caller fetches the bytes with basic_hp_encode_result() once it knows their size
+    return basic_hp_encode_result(s, out, out_capacity, out_len);
+}
+
+// framing: merge_bytes([z body, y body], num_segments=2) with write_body bodies (bytes_ops.py:19-33)
+extern "C" int basic_hp_encode_result(basic_hp_session *s, uint8_t *out, int64_t out_capacity, int64_t *out_len)
+{
+    BASIC_REQUIRE(s && out && s->res_batch >= 1, "hp_encode_result: no encoded batch is held by this session");
+    const int batch = s->res_batch;
+    const int64_t wz = s->off_z[batch], wy = s->off_y[batch];
+    const uint32_t *h_wz = s->h_words.as<uint32_t>(), *h_wy = h_wz + wz;
     const int64_t len_z = 12 + 4ll * batch + 4 * wz, len_y = 12 + 4ll * batch + 4 * wy;
-    *out_len = 4 + len_z + len_y;
-    if (*out_len > out_capacity) { set_error("hp_encode_images: output buffer too small"); return BASIC_ERR_OVERFLOW; }
-    BASIC_REQUIRE(len_z <= 0xFFFFFFFFll, "hp_encode_images: z body exceeds the 32-bit length prefix");
+    if (out_len) *out_len = 4 + len_z + len_y;
+    if (4 + len_z + len_y > out_capacity) { set_error("hp_encode_result: output buffer too small"); return BASIC_ERR_OVERFLOW; }
+    BASIC_REQUIRE(len_z <= 0xFFFFFFFFll, "hp_encode_result: z body exceeds the 32-bit length prefix");
     const uint32_t lz32 = static_cast<uint32_t>(len_z);
     std::memcpy(out, &lz32, 4);   // native-endian struct "I"
     int64_t written = 0;
-    rc = basic_frame_streams(h_wz, off_z.data(), batch, static_cast<uint32_t>(zh), static_cast<uint32_t>(zw), out + 4, len_z, &written);
+    int rc = basic_frame_streams(h_wz, s->off_z.data(), batch, static_cast<uint32_t>(s->res_zh), static_cast<uint32_t>(s->res_zw), out + 4,
+                                 len_z, &written);
     if (rc) return rc;
-    rc = basic_frame_streams(h_wy, off_y.data(), batch, static_cast<uint32_t>(yh), static_cast<uint32_t>(yw), out + 4 + len_z, len_y,
-                             &written);
-    return rc;
+    return basic_frame_streams(h_wy, s->off_y.data(), batch, static_cast<uint32_t>(s->res_yh), static_cast<uint32_t>(s->res_yw),
+                               out + 4 + len_z, len_y, &written);
 }
 
 namespace {
@@ -509,5 +596,9 @@ extern "C" int basic_hp_decode_images(basic_hp_session *s, const uint8_t *data, 
     rc = basic_i32_to_f32_dev(s->y_sym.as<int32_t>(), batch * ny, s->d_y.as<float>(), st);
     if (rc) return rc;
     // ---- edge y -> x: g_s straight into the caller's buffer
-    return run_chain(s, s->g_s, s->d_y.as<float>(), batch, yh, yw, nullptr, d_xhat, nullptr, nullptr, st);
+    TokenPhase phase(s, st, &s->dec_phase);
+    if (phase.rc) return phase.rc;
+    rc = run_chain(s, s->g_s, s->d_y.as<float>(), batch, yh, yw, nullptr, d_xhat, nullptr, nullptr, st);
+    const int rc2 = phase.close();
+    return rc ? rc : rc2;
 }

@@ -351,6 +351,7 @@ class LatentGraphicalANSEntropyCoder(HotPathModule, VariableRateCodecInterface, 
     # ---- fused C entry points for the plain hyperprior graph (include/basic_hip.h section 8)
     use_fused_session = True    # set False to force the module-by-module path (the two give identical bytes: tests)
     fused_rans_waves = 0        # wavefronts (image streams) per workgroup of the session's rANS launches; 0 = library default
+    fused_transform_token = False   # serialise the transform phases of all such sessions in GPU time (stream workers)
 
     def _fused_session(self, kwargs, prior):
         """The HyperpriorSession serving this graph, or None when the graph is anything but
@@ -389,6 +390,9 @@ class LatentGraphicalANSEntropyCoder(HotPathModule, VariableRateCodecInterface, 
         if getattr(sess, "_waves", 0) != self.fused_rans_waves:
             sess.set_rans_waves(self.fused_rans_waves)
             sess._waves = self.fused_rans_waves
+        if getattr(sess, "_token", False) != self.fused_transform_token:
+            sess.set_transform_token(self.fused_transform_token)
+            sess._token = self.fused_transform_token
         return sess
 
     def encode(self, data, *args, prior=None, **kwargs):

@@ -428,29 +428,24 @@ class HyperpriorSession:
     def set_rans_waves(self, waves_per_block):
         _lib.check(_lib.lib().basic_hp_session_set_rans_waves(self._h, int(waves_per_block)))
 
+    def set_transform_token(self, enable):
+        _lib.check(_lib.lib().basic_hp_session_set_transform_token(self._h, int(bool(enable))))
+
     def encode(self, x) -> bytes:
         """x: float32 [B, C, H, W], on the GPU or on the host (uploaded inside the call; pinned memory goes at DMA rate)."""
         if x.dtype != torch.float32:
             raise TypeError(f"expected float32, got {x.dtype}")
         x = x.contiguous()
         B, C, H, W = x.shape
-        cap = _lib.lib().basic_hp_encode_bound(self._h, B, H, W)
-        if cap < 0:
-            raise ValueError("hp_encode_bound: bad shape")
-        # the bound is the coder's worst case (12 bytes per symbol); a stream of real latents is far below 1 byte per symbol
-        guess = min(cap, 4 + 2 * (12 + 4 * B) + B * ((C * H * W) // 48 + 4096))
+        n = ctypes.c_int64()
+        _lib.check(_lib.lib().basic_hp_encode_images(self._h, x.data_ptr(), 0 if x.is_cuda else 1, B, H, W, None, 0, ctypes.byref(n), _stream()))
+        # the final bytes object is allocated once at its exact size and the streams are framed straight into it
         api = ctypes.pythonapi
         api.PyBytes_FromStringAndSize.restype, api.PyBytes_FromStringAndSize.argtypes = ctypes.py_object, [ctypes.c_char_p, ctypes.c_ssize_t]
         api.PyBytes_AsString.restype, api.PyBytes_AsString.argtypes = ctypes.c_void_p, [ctypes.py_object]
-        n = ctypes.c_int64()
-        for size in (guess, cap):
-            buf = np.empty(size, dtype=np.uint8)
-            rc = _lib.lib().basic_hp_encode_images(self._h, x.data_ptr(), 0 if x.is_cuda else 1, B, H, W, buf.ctypes.data, size,
-                                                   ctypes.byref(n), _stream())
-            if rc == _lib.ERR_OVERFLOW and size != cap:
-                continue
-            _lib.check(rc)
-            return buf[: n.value].tobytes()
+        out = api.PyBytes_FromStringAndSize(None, n.value)
+        _lib.check(_lib.lib().basic_hp_encode_result(self._h, api.PyBytes_AsString(out), n.value, None))
+        return out
 
     def decode(self, data, device=None):
         buf = np.frombuffer(data, dtype=np.uint8)

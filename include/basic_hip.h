@@ -286,6 +286,9 @@ int64_t basic_hp_encode_bound(const basic_hp_session *s, int batch, int h, int w
  * general_codec.py:46-47).  Returns with the bytes complete in `out` (the stream has been synchronised). */
 int basic_hp_encode_images(basic_hp_session *s, const float *x, int x_on_host, int batch, int h, int w, uint8_t *out,
                            int64_t out_capacity, int64_t *out_len, void *hip_stream);
+/* With out == NULL basic_hp_encode_images only reports the size in *out_len and keeps the encoded batch in the session
+ * (page-locked host memory); this call frames it into caller memory (any number of times, until the next encode). */
+int basic_hp_encode_result(basic_hp_session *s, uint8_t *out, int64_t out_capacity, int64_t *out_len);
 /* Shape of the reconstruction a stream decodes to (from its headers only). */
 int basic_hp_decoded_shape(const basic_hp_session *s, const uint8_t *data, int64_t len, int *batch, int *channels, int *h,
                            int *w);
@@ -295,6 +298,11 @@ int basic_hp_decode_images(basic_hp_session *s, const uint8_t *data, int64_t len
                            int64_t xhat_capacity_floats, void *hip_stream);
 /* Wavefronts (image streams) per workgroup of this session's rANS launches: 1, 2, 4, 8 or 16 (0 = library default). */
 int basic_hp_session_set_rans_waves(basic_hp_session *s, int waves_per_block);
+/* Opt this session into the process-wide "transform token": the MFMA-heavy phases (compress: everything up to the y
+ * rANS encoder; decompress: g_s) of all such sessions then run one after another in GPU time, in host enqueue order,
+ * through stream-wait events -- so that with several sessions on several HIP streams one session's rANS chains always
+ * run beside another's transforms instead of all sessions falling into lock-step.  No effect on results. */
+int basic_hp_session_set_transform_token(basic_hp_session *s, int enable);
 void basic_hp_session_destroy(basic_hp_session *s);
 
 #ifdef __cplusplus

@@ -7,6 +7,7 @@ import os
 import sys
 import time
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # one hardware queue per worker stream (the default 4 make streams share)
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -21,6 +22,7 @@ def main():
     ap.add_argument("--stagger", action="store_true")
     ap.add_argument("--waves", type=int, default=0, help="rANS wavefronts per workgroup of the fused session")
     ap.add_argument("--no-fused", action="store_true")
+    ap.add_argument("--token", action="store_true")
     ap.add_argument("--free", action="store_true", help="free-running workers: each loops over its shard --steps times, one join at the end")
     ap.add_argument("--prio", action="store_true", help="descending stream priority per worker (breaks the lock-step)")
     args = ap.parse_args()
@@ -33,6 +35,7 @@ def main():
         c.update_state()
         c.entropy_coder.fused_rans_waves = args.waves
         c.entropy_coder.use_fused_session = not args.no_fused
+        c.entropy_coder.fused_transform_token = args.token
         return c
 
     g = torch.Generator().manual_seed(1234)
@@ -64,7 +67,7 @@ def main():
                     n = sum(pool.map(work, shards, stagger=args.stagger))
             torch.cuda.synchronize()
             dt = (time.time() - t0) / args.steps
-        print(json.dumps(dict(workers=w, wpb=args.waves, fused=not args.no_fused, host_input=args.host_input, stagger=args.stagger, free=args.free, prio=str(pr) + str(lo_hi), ms_per_step=dt * 1e3,
+        print(json.dumps(dict(workers=w, wpb=args.waves, fused=not args.no_fused, token=args.token, host_input=args.host_input, stagger=args.stagger, free=args.free, prio=str(pr) + str(lo_hi), ms_per_step=dt * 1e3,
                               mpix_s=args.batch * 65536 / dt / 1e6, bytes=n)), flush=True)
 
 

@@ -17,6 +17,8 @@ print(f"{'start_ms':>9s} {'dur_us':>8s} {'q':>3s} {'s':>3s} kernel")
 for s, e, n, q, st in sel:
     if e - s > 20000:
         print(f"{(s - t0) / 1e6:9.3f} {(e - s) / 1e3:8.0f} {q:>3s} {st:>3s} {n[:70]}")
+pairs = sorted({(q, st) for _, _, _, q, st in sel})
+print("(queue, stream) pairs in window:", pairs)
 convs = [(s, e) for s, e, n, _, _ in ev if "conv" in n]
 tot_r = cov = 0
 for s, e, n, _, _ in sel:

@@ -642,8 +642,44 @@ def codec_graph():
     save("codec_graph.npz", **out)
 
 
+# ---------------------------------------------------------------- 12. GroupedVariableRateCodec (codecs/base.py:138-243)
+from recipe import GROUPED_OPS, GROUPED_VR_CONFIG, run_grouped_ops  # noqa: E402
+
+
+def grouped():
+    from cbench.codecs.base import (GroupedVariableRateCodec, NNTrainableCodec, VariableComplexityCodecInterface,
+                                    VariableRateCodecInterface, VariableTaskCodecInterface)
+
+    def make_member(i, log, rate=0, complex=0, tasks=0):
+        bases = [NNTrainableCodec] + ([VariableRateCodecInterface] if rate else []) + \
+                ([VariableComplexityCodecInterface] if complex else []) + ([VariableTaskCodecInterface] if tasks else [])
+        ns = dict(
+            compress=lambda self, data, *a, **k: (log.append((i, "compress", data)), f"bytes{i}:{data}")[1],
+            decompress=lambda self, data, *a, **k: (log.append((i, "decompress", data)), f"out{i}:{data}")[1],
+            forward=lambda self, *a, **k: (log.append((i, "forward", a)), f"fwd{i}")[1],
+            forward_estimate_bitlen=lambda self, *a, **k: (log.append((i, "feb", a)), (f"fwd{i}", 10.0 + i))[1],
+            update_state=lambda self, *a, **k: log.append((i, "update_state")),
+            post_training_process=lambda self, *a, **k: log.append((i, "post_training_process")),
+            set_rate_level=lambda self, level, *a, **k: log.append((i, "set_rate_level", level)),
+            set_complex_level=lambda self, level, *a, **k: log.append((i, "set_complex_level", level)),
+            get_current_complex_metrics=lambda self, *a, **k: (log.append((i, "metrics")), {"FLOPs": 100.0 * (i + 1)})[1],
+            set_task=lambda self, task, *a, **k: (log.append((i, "set_task", task)), task < tasks)[1],
+            num_rate_levels=property(lambda self: rate), num_complex_levels=property(lambda self: complex),
+            num_tasks=property(lambda self: tasks))
+        return type(f"Member{i}", tuple(bases), ns)()
+
+    out = {}
+    for tag, cfg in (("plain", None), ("cfg", GROUPED_VR_CONFIG)):
+        log, rets = run_grouped_ops(make_member, GroupedVariableRateCodec, cfg)
+        out[f"{tag}.log"], out[f"{tag}.rets"] = np.array(log), np.array(rets)
+        print(tag, len(log), rets[:6])
+    g = GroupedVariableRateCodec([make_member(j, []) for j in range(3)])
+    out["module_names"] = np.array([n for n, _ in g.named_children()])
+    save("grouped_codec.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["rans", "tables", "topo", "mconv", "ar", "framing", "harness", "search", "arpgm", "arjoint", "codec"]
-    fn = dict(rans=rans_kats, tables=gauss_tables, topo=topo_maps, mconv=masked_conv, ar=ar_coder, framing=framing, harness=harness, search=complexity_search, arpgm=ar_coder_pgm, arjoint=ar_coder_joint, codec=codec_graph)
+    which = sys.argv[1:] or ["rans", "tables", "topo", "mconv", "ar", "framing", "harness", "search", "arpgm", "arjoint", "codec", "grouped"]
+    fn = dict(rans=rans_kats, tables=gauss_tables, topo=topo_maps, mconv=masked_conv, ar=ar_coder, framing=framing, harness=harness, search=complexity_search, arpgm=ar_coder_pgm, arjoint=ar_coder_joint, codec=codec_graph, grouped=grouped)
     for w in which:
         fn[w]()

@@ -48,3 +48,38 @@ def named_seed_weights(module, base_seed, calib=()):
 
 def recipe_input(seed, shape):
     return torch.rand(*[int(s) for s in shape], generator=torch.Generator().manual_seed(int(seed)))
+
+
+# ---- GroupedVariableRateCodec op script (fixture grouped_codec.npz)
+GROUPED_OPS = [  # (method, args, kwargs) applied in order to a grouped codec of 4 members; see tests/test_cpu_host.py
+    ("num_rate_levels", (), {}), ("num_complex_levels", (), {}), ("num_tasks", (), {}), ("__len__", (), {}),
+    ("compress", ("x0",), {}), ("set_rate_level", (2,), {}), ("compress", ("x1",), {}), ("decompress", ("b1",), {}),
+    ("set_complex_level", (5,), {}), ("set_complex_level", (3,), {"active_only": True}), ("get_current_complex_metrics", (), {}),
+    ("set_rate_level", (3,), {}), ("get_current_complex_metrics", (), {}), ("set_task", (1,), {}), ("set_task", (0,), {"active_only": True}),
+    ("update_state", (), {}), ("post_training_process", (), {}), ("forward_estimate_bitlen", ("x2",), {}), ("forward", ("x3",), {}),
+    ("set_rate_level", (0,), {}), ("forward", ("x4",), {}),
+]
+GROUPED_VR_CONFIG = {0: (1, 2), 1: (1, 0), 2: (3, 1), 3: (0, 0), 4: (2, 1), 5: (2, 0)}   # outer level -> (member, member's level)
+
+
+def run_grouped_ops(make_member, Grouped, vr_config):
+    """Shared by the generator (reference classes) and the test (this repository's): returns the call log and the values
+    returned by every op.  Members: 0 and 2 have rate levels / complexity levels / tasks, 1 only complexity, 3 none."""
+    log = []
+    members = [make_member(0, log, rate=3, complex=8, tasks=2), make_member(1, log, complex=5), make_member(2, log, rate=2, complex=8, tasks=3),
+               make_member(3, log)]
+    g = Grouped(members, **({"codec_vr_level_config": vr_config} if vr_config else {}))
+    log.append(("init_active", g.active_codec_idx))
+    rets = []
+    for name, args, kwargs in GROUPED_OPS:
+        if name in ("num_rate_levels", "num_complex_levels", "num_tasks"):
+            r = getattr(g, name)
+        elif name == "__len__":
+            r = len(g)
+        elif name == "forward":
+            r = g(*args, **kwargs)
+        else:
+            r = getattr(g, name)(*args, **kwargs)
+        rets.append(repr(r))
+        log.append(("active", g.active_codec_idx))
+    return [repr(e) for e in log], rets

@@ -335,3 +335,41 @@ def test_in_place_merge_and_zero_copy_split_match_the_reference_framing():
         views = split_merged_views(want, num_segments=len(segs))
         assert [v.tobytes() for v in views] == split_merged_bytes(want, num_segments=len(segs)) == segs
         assert all(isinstance(v, memoryview) for v in views)
+
+
+def test_grouped_variable_rate_codec_matches_reference_class():
+    """codecs/grouped.py against the call log / return values of the REFERENCE's GroupedVariableRateCodec
+    (codecs/base.py:138-243) driven through the same op script with the same mock members (tests/golden/recipe.py)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from recipe import GROUPED_VR_CONFIG, run_grouped_ops
+    from cbench_basic_amd.base import HotPathModule
+    from cbench_basic_amd.codecs.base import (CodecInterface, VariableComplexityCodecInterface, VariableRateCodecInterface,
+                                              VariableTaskCodecInterface)
+    from cbench_basic_amd.codecs.grouped import GroupedVariableRateCodec
+
+    def make_member(i, log, rate=0, complex=0, tasks=0):
+        bases = [HotPathModule, CodecInterface] + ([VariableRateCodecInterface] if rate else []) + \
+                ([VariableComplexityCodecInterface] if complex else []) + ([VariableTaskCodecInterface] if tasks else [])
+        ns = dict(
+            compress=lambda self, data, *a, **k: (log.append((i, "compress", data)), f"bytes{i}:{data}")[1],
+            decompress=lambda self, data, *a, **k: (log.append((i, "decompress", data)), f"out{i}:{data}")[1],
+            forward=lambda self, *a, **k: (log.append((i, "forward", a)), f"fwd{i}")[1],
+            forward_estimate_bitlen=lambda self, *a, **k: (log.append((i, "feb", a)), (f"fwd{i}", 10.0 + i))[1],
+            update_state=lambda self, *a, **k: log.append((i, "update_state")),
+            post_training_process=lambda self, *a, **k: log.append((i, "post_training_process")),
+            set_rate_level=lambda self, level, *a, **k: log.append((i, "set_rate_level", level)),
+            set_complex_level=lambda self, level, *a, **k: log.append((i, "set_complex_level", level)),
+            get_current_complex_metrics=lambda self, *a, **k: (log.append((i, "metrics")), {"FLOPs": 100.0 * (i + 1)})[1],
+            set_task=lambda self, task, *a, **k: (log.append((i, "set_task", task)), task < tasks)[1],
+            num_rate_levels=property(lambda self: rate), num_complex_levels=property(lambda self: complex),
+            num_tasks=property(lambda self: tasks))
+        return type(f"Member{i}", tuple(bases), ns)()
+
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "grouped_codec.npz"))
+    for tag, cfg in (("plain", None), ("cfg", GROUPED_VR_CONFIG)):
+        log, rets = run_grouped_ops(make_member, GroupedVariableRateCodec, cfg)
+        assert log == [str(s) for s in z[f"{tag}.log"]], tag
+        assert rets == [str(s) for s in z[f"{tag}.rets"]], tag
+    g = GroupedVariableRateCodec([make_member(j, []) for j in range(3)])
+    assert [n for n, _ in g.named_children()] == [str(s) for s in z["module_names"]]
