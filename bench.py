@@ -1,25 +1,34 @@
 #!/usr/bin/env python3
-"""Headline benchmark: encode+decode throughput (Mpix/s) of the hyperprior codec on synthetic
-3x256x256 batches, one process per GPU, images sharded per rank (no data-path collective), one
-RCCL all-reduce of the metric sums at the end (the analogue of reduce_across_processes,
-cbench/utils/logging_utils.py:458-465).
+"""Headline benchmark: encode+decode throughput (Mpix/s) of the hyperprior codec (BASELINE.json configs[4] shape:
+synthetic 3x256x256 images, N=128 / M=192, configs/lossy_graph_scalable_exp_hp.py) on one MI355X per process.
 
-A "step" = codec.compress(batch) followed by codec.decompress(bytes) for one batch of
---batch images resident in HBM (bytes cross PCIe in both directions inside the step, exactly as
-the reference's timed region does, basic_benchmark.py:200-231).
+  python bench.py --gpus N --steps K --warmup W
+      N == 1: runs in this process.  N > 1 without a launcher: this process starts
+      `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same flags>` as a CHILD before it has
+      touched the GPU and exits with the child's code (one rank per GPU, RCCL over xGMI for the metric reduction only).
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline     -- conv MFMA kernel family: algorithmic FLOPs / measured kernel time vs 157.3 TF fp32
-  cpu_baseline -- the CPU oracle (PyTorch-CPU fp32 convs + C rANS restatement) on a bounded sample
+A "step" = every image of the rank's batch goes through codec.compress() and codec.decompress() once.  The batch is
+split over `--workers` concurrent stream workers (cbench_basic_amd/benchmark/stream_workers.py, the analogue of the
+reference's num_testing_workers pool, basic_benchmark.py:829-858): each worker loops compress -> decompress over its
+shard on its own HIP stream, so one worker's serial rANS chains run beside another worker's MFMA transforms.  The timed
+region is bracketed by barrier + synchronize on both sides and holds exactly K steps of every worker.
+
+`value` is measured with the input batch resident in HBM (the tier's contract); `pcie_inclusive` repeats the run with
+the batch in page-locked host memory, uploaded INSIDE compress() as the reference's timed region does
+(general_codec.py:46-47 under basic_benchmark.py:199-202).  `scaling` is "weak" (--batch images per GPU at every N);
+at N > 1 the same run also times BASELINE configs[4] as written (256 images over N GPUs) and reports it as `strong`.
+
+One JSON line on rank 0, with
+  roofline     -- MFMA transform kernels: algorithmic FLOPs / HIP-event time of the transform launches vs 157.3 TF fp32,
+                  plus `end_to_end` = FLOPs of a step / wall time of a step (everything included)
+  cpu_baseline -- the CPU oracle (PyTorch-CPU fp32 convs + C rANS restatement) on a bounded sample of the SAME images
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -30,14 +39,36 @@ PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=256, help="images per GPU per step (weak scaling)")
+    ap.add_argument("--total", type=int, default=256, help="images per step over ALL GPUs in the strong-scaling leg (cfg-5)")
     ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--workers", type=int, default=2, help="concurrent stream workers per GPU (1 = plain sequential calls)")
+    ap.add_argument("--rans-waves", type=int, default=-1, help="image streams per rANS workgroup (-1: 4 with workers > 1, else library default)")
     ap.add_argument("--cpu-images", type=int, default=2000, help="bounded CPU-baseline sample (images)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the pcie_inclusive and strong-scaling legs (profiling runs)")
     ap.add_argument("--no-dominant", action="store_true", help="skip the single-launch roofline (counter passes: keeps the launch mix = timed passes)")
+    ap.add_argument("--master-port", type=int, default=29533)
     return ap.parse_args()
+
+
+def self_launch(args):
+    """--gpus N > 1 outside a launcher: become the parent of a torch.distributed.run job.  Nothing in this process has
+    initialised the GPU (torch is not even imported yet), and the job runs as a CHILD -- never an exec."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(args.master_port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
+def image(i, size):
+    """Image i of the synthetic set: torch.manual_seed(i); torch.rand(3, S, S)
+    (configs/datasets/images/random_image_generator.py:12-15) -- the SAME images feed the GPU legs and the CPU baseline."""
+    import torch
+    torch.manual_seed(int(i))
+    return torch.rand(3, size, size)
 
 
 def conv_flops_per_image(codec, size):
@@ -52,8 +83,9 @@ def conv_flops_per_image(codec, size):
 
 
 def measure_conv_kernels(codec, x, reps=3):
-    """HIP-event time of the transform launches alone (same stream as the launches), returning
+    """HIP-event time of the transform launches alone (events on the stream the kernels are launched on), returning
     (seconds per pass over the batch, launches per pass)."""
+    import torch
     ec = codec.entropy_coder
     g_a, h_a = ec.latent_inference_modules["x_y"], ec.latent_inference_modules["y_z"]
     h_s, g_s = ec.latent_generative_modules["z_y"], ec.latent_generative_modules["y_x"]
@@ -61,10 +93,9 @@ def measure_conv_kernels(codec, x, reps=3):
     def one_pass():
         y = g_a(x)
         z = h_a(y)
-        s = h_s(z)
-        s2 = h_s(z)
-        xh = g_s(y)
-        return xh
+        h_s(z)
+        h_s(z)
+        return g_s(y)
 
     one_pass()
     torch.cuda.synchronize()
@@ -74,8 +105,7 @@ def measure_conv_kernels(codec, x, reps=3):
         one_pass()
     e1.record()
     torch.cuda.synchronize()
-    # launches per pass, as the plans report them for these shapes (sub-pixel phases of the transposed convolutions,
-    # fused pairwise where the kernel allows it)
+
     def count(m, t):
         n, (b, _, h, w) = 0, t.shape
         for p in m.plans():
@@ -91,6 +121,7 @@ def measure_conv_kernels(codec, x, reps=3):
 def measure_dominant_kernel(codec, x, reps=5):
     """The single heaviest launch of the pass -- the second analysis layer (conv 5x5 s2 128->128 + GDN on the
     H/2 x W/2 map), one conv_tap_mfma_kernel<4,4,5,5,8> launch -- timed alone with HIP events."""
+    import torch
     g_a = codec.entropy_coder.latent_inference_modules["x_y"]
     p0, p1 = g_a.plans()[0], g_a.plans()[1]
     h1 = p0(x)
@@ -109,6 +140,7 @@ def measure_dominant_kernel(codec, x, reps=5):
 
 
 def cpu_baseline(codec_cpu_state, n_images, size):
+    import torch
     from oracle.codec_oracle import HyperpriorOracle
     # the GPU box gives one GPU a 16-core CPU share; more threads than that only oversubscribes
     try:
@@ -118,27 +150,52 @@ def cpu_baseline(codec_cpu_state, n_images, size):
     cores = max(1, min(cores, 16))
     torch.set_num_threads(cores)
     oracle = HyperpriorOracle(codec_cpu_state)
-    torch.manual_seed(0)
-    oracle.decompress(oracle.compress(torch.rand(1, 3, size, size)))  # warm-up
+    oracle.decompress(oracle.compress(image(0, size).unsqueeze(0)))  # warm-up
     t0, done = time.time(), 0
     for i in range(n_images):  # bounded sample: stop after ~12 s of CPU work
-        torch.manual_seed(i)
-        x = torch.rand(1, 3, size, size)
+        x = image(i, size).unsqueeze(0)
         oracle.decompress(oracle.compress(x))
         done += 1
         if time.time() - t0 > 12.0:
             break
     dt = time.time() - t0
     return dict(value=done * size * size / dt / 1e6, unit="Mpix/s", cores=cores, kind="port",
-                sample=f"{done} images 3x{size}x{size}, batch 1 (seeds 0..{done - 1}), PyTorch-CPU fp32 transforms + "
+                sample=f"images 0..{done - 1} of the same synthetic set (3x{size}x{size}), batch 1, PyTorch-CPU fp32 transforms + "
                        f"C rANS oracle, {dt:.1f} s wall")
+
+
+def traffic_from_profiles():
+    """HBM bytes per transform launch from the SEPARATE rocprofv3 --pmc passes committed under profiles/ (a profiler cannot
+    run inside the timed process); (value, source) -- (None, None) when no file of this round exists."""
+    for name in ("r02_pmc_traffic.json",):
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            try:
+                with open(path) as f:
+                    d = json.load(f)
+                return d["hbm_bytes_per_launch_avg"], f"profiles/{name} (collected at git {d.get('git', '?')}, {d.get('note', 'FETCH_SIZE + WRITE_SIZE')})"
+            except Exception as e:  # a broken file must not pass silently as "no data"
+                return None, f"profiles/{name} unreadable: {e!r}"
+    return None, None
 
 
 def main():
     args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        raise SystemExit(self_launch(args))
+    world = int(env_world or "1")
+    if args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} "
+                         f"(or run `python bench.py --gpus {args.gpus}` without a launcher)")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    workers = max(1, args.workers)
+    if workers > 1:  # one hardware queue per worker stream (+ its entropy side stream); HIP's default 4 make streams share
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+    import numpy as np
+    import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -148,86 +205,126 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # "nccl" IS RCCL on ROCm (xGMI)
     dev = torch.device("cuda", local_rank)
 
-    from cbench_basic_amd.presets import hyperprior_codec, seed_synthetic_weights
-    codec = seed_synthetic_weights(hyperprior_codec(), seed=0).eval()
-    cpu_state = {k: v.clone() for k, v in codec.entropy_coder.state_dict().items()}
-    codec = codec.to(dev)
-    codec.update_state()
-
-    # per-rank shard of the synthetic set: image i = torch.manual_seed(i); torch.rand(3,S,S)
-    # (configs/datasets/images/random_image_generator.py:12-15); rank r owns ids r*batch .. (r+1)*batch-1
-    g = torch.Generator().manual_seed(1234 + rank)
-    x = torch.rand(args.batch, 3, args.size, args.size, generator=g).to(dev)
-
-    def step():
-        data = codec.compress(x)
-        xhat = codec.decompress(data)
-        return data, xhat
-
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    t0 = time.time()
-    nbytes = 0
-    for _ in range(args.steps):
-        data, xhat = step()
-        nbytes += len(data)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    dt = time.time() - t0
-
+    from cbench_basic_amd.benchmark.stream_workers import StreamWorkerPool, split_batch
     from cbench_basic_amd.nn import kernels as K
-    from cbench_basic_amd.utils.dist_metrics import gather_per_image, reduce_metric_sums
-    mse = K.mse_per_image(xhat, x)
-    psnr_img = -10 * torch.log10(mse.double())
-    psnr_sum = float(psnr_img.sum())
-    # per-image (bytes, PSNR) of the last step, gathered over xGMI into image order (image i lives on rank i mod world):
-    # the analogue of the reference's per-image metric rows; not part of the timed region
+    from cbench_basic_amd.presets import hyperprior_codec, seed_synthetic_weights
     from cbench_basic_amd.utils.bytes_ops import split_merged_bytes
-    zb, yb = split_merged_bytes(data, num_segments=2)
-    (_, zo, _), (_, yo, _) = K.unframe_streams(zb), K.unframe_streams(yb)
-    img_bytes = torch.from_numpy(4.0 * (np.diff(zo) + np.diff(yo)) + 8.0).to(dev)
-    table = gather_per_image(torch.stack([img_bytes.double(), psnr_img.to(dev)], dim=1), args.batch * world, rank, world)
-    # the ONLY collective of the run: metric sums (analogue of cbench/utils/logging_utils.py:458-465)
-    red = reduce_metric_sums(dict(time_s=dt, images=float(args.batch * args.steps), bytes=float(nbytes), psnr_sum=psnr_sum,
-                                  psnr_n=float(args.batch)), device=dev)
-    dt_max, n_img, n_bytes, psnr_tot, n_psnr = red["time_s"], red["images"], red["bytes"], red["psnr_sum"], red["psnr_n"]
+    from cbench_basic_amd.utils.dist_metrics import gather_per_image, reduce_metric_sums, shard_indices
+
+    waves = args.rans_waves if args.rans_waves >= 0 else (4 if workers > 1 else 0)
+
+    def make_codec():
+        c = seed_synthetic_weights(hyperprior_codec(), seed=0).eval().to(dev)   # every replica: the same seeded weights
+        c.update_state()
+        c.entropy_coder.fused_rans_waves = waves
+        c.entropy_coder.fused_transform_token = workers > 1
+        return c
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    def run_leg(pool, shards, steps, warmup):
+        """K steps of every worker over its shard; returns (seconds, bytes per step, last step's [(bytes, xhat)] per shard)."""
+        def loop(codec, shard, n):
+            out = None
+            for _ in range(n):
+                data = codec.compress(shard)
+                out = (data, codec.decompress(data))
+            return out
+        if warmup:
+            pool.map(lambda c, s: loop(c, s, warmup), shards)
+        barrier()
+        t0 = time.time()
+        last = pool.map(lambda c, s: loop(c, s, steps), shards)
+        barrier()
+        dt = time.time() - t0
+        return dt, sum(len(d) for d, _ in last), last
+
+    # ---- the rank's images.  weak: ids rank*B .. rank*B+B-1;  strong: image i of `total` lives on rank i mod world
+    weak_ids = list(range(rank * args.batch, (rank + 1) * args.batch))
+    x_host = torch.stack([image(i, args.size) for i in weak_ids]).pin_memory()
+    x = x_host.to(dev)
+    pool = StreamWorkerPool(make_codec, workers, dev)
+    codec = pool.codecs[0]
+    cpu_state = {k: v.detach().cpu().clone() for k, v in codec.entropy_coder.state_dict().items()}
+
+    shards = split_batch(x, workers)
+    dt, step_bytes, last = run_leg(pool, shards, args.steps, args.warmup)
+
+    # per-image (bytes, PSNR) of the last step, gathered over xGMI into image order: not part of the timed region
+    xhat = torch.cat([xh for _, xh in last])
+    psnr_img = -10 * torch.log10(K.mse_per_image(xhat, x).double())
+    img_bytes = []
+    for data, _ in last:
+        zb, yb = split_merged_bytes(data, num_segments=2)
+        (_, zo, _), (_, yo, _) = K.unframe_streams(zb), K.unframe_streams(yb)
+        img_bytes.append(4.0 * (np.diff(zo) + np.diff(yo)) + 8.0)
+    img_bytes = torch.from_numpy(np.concatenate(img_bytes)).to(dev)
+    table = torch.stack([img_bytes.double(), psnr_img.to(dev)], dim=1)
+    if dist is not None and world > 1:   # contiguous shards per rank -> concatenation in rank order is image order
+        bufs = [torch.empty_like(table) for _ in range(world)]
+        dist.all_gather(bufs, table)
+        table = torch.cat(bufs)
+    # the ONLY collective of a leg: metric sums (analogue of cbench/utils/logging_utils.py:458-465)
+    red = reduce_metric_sums(dict(time_s=dt, images=float(args.batch * args.steps), bytes=float(step_bytes * args.steps),
+                                  psnr_sum=float(psnr_img.sum()), psnr_n=float(args.batch)), device=dev)
+
+    extra = {}
+    if not args.no_extra_legs:
+        # (1) input in page-locked HOST memory, uploaded inside compress() (the reference's timed region)
+        hdt, _, _ = run_leg(pool, split_batch(x_host, workers), args.steps, 1)
+        hred = reduce_metric_sums(dict(time_s=hdt, images=float(args.batch * args.steps)), device=dev)
+        extra["pcie_inclusive"] = dict(value=hred["images"] * args.size ** 2 / hred["time_s"] / 1e6, unit="Mpix/s",
+                                       ms_per_step=hred["time_s"] / args.steps * 1e3,
+                                       note="same run, batch in page-locked host memory, H2D inside compress() (general_codec.py:46-47)")
+        # (2) BASELINE configs[4] as written: `total` images per step over all GPUs (strong scaling)
+        if world > 1:
+            ids = shard_indices(args.total, rank, world)
+            xs = torch.stack([image(i, args.size) for i in ids]).to(dev)
+            sdt, _, _ = run_leg(pool, split_batch(xs, workers), args.steps, 1)
+            sred = reduce_metric_sums(dict(time_s=sdt, images=float(len(ids) * args.steps)), device=dev)
+            extra["strong"] = dict(value=sred["images"] * args.size ** 2 / sred["time_s"] / 1e6, unit="Mpix/s", scaling="strong",
+                                   images_total_per_step=args.total, images_per_gpu=len(ids),
+                                   ms_per_step=sred["time_s"] / args.steps * 1e3,
+                                   note="image i of the step's set on rank i mod world; compare with the N=1 line's value (256 images on one GPU)")
+    pool.close()
 
     if rank == 0:
+        dt_max, n_img, n_bytes = red["time_s"], red["images"], red["bytes"]
         pix = n_img * args.size * args.size
         enc_f, dec_f = conv_flops_per_image(codec, args.size)
+        codec.entropy_coder.fused_transform_token = False
         conv_s, launches = measure_conv_kernels(codec, x)
         flops_pass = (enc_f + dec_f) * args.batch
         achieved = flops_pass / conv_s / 1e12
-        # HBM traffic per launch: collected in SEPARATE rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; a profiler
-        # cannot run inside the timed process) and committed under profiles/; null when that file is absent.
-        traffic = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-                traffic = json.load(f)["hbm_bytes_per_launch_avg"]
-        except Exception:
-            pass
+        ms_step = dt_max / args.steps * 1e3
+        e2e = flops_pass / (ms_step / 1e3) / 1e12
+        traffic, traffic_source = traffic_from_profiles()
         out = dict(
             metric="encode+decode Mpix/s", value=pix / dt_max / 1e6, unit="Mpix/s", n_gpus=world, steps=args.steps,
-            warmup=args.warmup, ms_per_step=dt_max / args.steps * 1e3, higher_is_better=True, scaling="weak",
+            warmup=args.warmup, ms_per_step=ms_step, higher_is_better=True, scaling="weak",
             vs_baseline=None, dtype="f32", data="synthetic",
-            config=dict(workload=f"hyperprior codec N=128 M=192 (lossy_graph_scalable_exp_hp), synthetic 3x{args.size}x{args.size}, "
-                                 f"{args.batch} images per GPU per step, compress+decompress incl. bytes D2H/H2D",
-                        images_per_gpu=args.batch, bpp=n_bytes * 8 / pix, psnr_db=psnr_tot / n_psnr,
+            config=dict(workload=f"hyperprior codec N=128 M=192 (lossy_graph_scalable_exp_hp), synthetic 3x{args.size}x{args.size} images "
+                                 f"(image i = manual_seed(i), rand), {args.batch} images per GPU per step resident in HBM, "
+                                 f"compress+decompress incl. bitstream D2H/H2D, {workers} concurrent stream workers per GPU",
+                        images_per_gpu=args.batch, workers=workers, rans_waves_per_workgroup=waves,
+                        bpp=n_bytes * 8 / pix, psnr_db=red["psnr_sum"] / red["psnr_n"],
                         gathered_images=int(table.shape[0]),
                         gathered_bpp=float(table[:, 0].sum()) * 8 / (table.shape[0] * args.size * args.size),
                         gathered_psnr_db=float(table[:, 1].mean()),
                         parallelism=f"image-sharded x{world}, RCCL all-reduce of metric sums + all-gather of per-image (bytes, PSNR)"),
             roofline=dict(bound="mfma", achieved=achieved, peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
-                          frac=achieved / PEAK_FP32_MFMA_TFLOPS, traffic=traffic,
-                          kernel="conv_tap_mfma_kernel<MT,CK,KH,KW,WAVES> + first/last-layer kernels (the transform launches of one encode+decode pass)",
+                          frac=achieved / PEAK_FP32_MFMA_TFLOPS, traffic=traffic, traffic_source=traffic_source,
+                          kernel="conv_tap_mfma_kernel<MT,CK,KH,KW,WAVES> + first/last-layer kernels (the transform launches of one encode+decode pass, alone on the GPU)",
                           flops_per_launch=flops_pass / launches, launches_per_pass=launches,
                           avg_launch_ms=conv_s / launches * 1e3, pass_ms=conv_s * 1e3,
+                          end_to_end=dict(achieved=e2e, frac=e2e / PEAK_FP32_MFMA_TFLOPS,
+                                          note="transform FLOPs of a step / wall time of a step (rANS chains, hyper path, copies, host included)"),
                           dominant=None if args.no_dominant else measure_dominant_kernel(codec, x)),
         )
+        out.update(extra)
         if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only; at N > 1 the other ranks would just wait for it
             out["cpu_baseline"] = cpu_baseline(cpu_state, args.cpu_images, args.size)
         print(json.dumps(out))

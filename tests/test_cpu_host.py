@@ -373,3 +373,32 @@ def test_grouped_variable_rate_codec_matches_reference_class():
         assert rets == [str(s) for s in z[f"{tag}.rets"]], tag
     g = GroupedVariableRateCodec([make_member(j, []) for j in range(3)])
     assert [n for n, _ in g.named_children()] == [str(s) for s in z["module_names"]]
+
+
+def test_bench_gpus_flag_launches_children_or_refuses(monkeypatch):
+    """bench.py --gpus N: without a launcher the parent starts torch.distributed.run as a CHILD process (never an exec, and
+    before anything touches the GPU); under a launcher a WORLD_SIZE that disagrees with --gpus is an error, not a silent
+    one-GPU run."""
+    import importlib
+    bench = importlib.import_module("bench")
+    calls = {}
+
+    def fake_call(cmd, env=None):
+        calls["cmd"], calls["env"] = cmd, env
+        return 7
+    monkeypatch.setattr(bench.subprocess, "call", fake_call)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.delenv("RANK", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7
+    cmd = calls["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "127.0.0.1" in cmd
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"] and cmd[-7].endswith("bench.py")
+    assert calls["env"]["MASTER_ADDR"] == "127.0.0.1" and calls["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # under a launcher with the wrong world size
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert "WORLD_SIZE=2" in str(e.value.code)
