@@ -91,10 +91,10 @@ def test_compress_decompress_vs_oracle(setup, shape):
     assert _rel(xhat.cpu(), xcross) < 1e-3
     assert float((psnr(xhat.cpu(), x) - psnr(xref, x)).abs().max()) < 0.01
     a = oracle.analyse(x)
-    # byte-identical to the CPU oracle for every shape of this (seeded) test; an fp32 rounding tie would have to be
-    # recorded here by shape with the flipped symbol
-    assert data == ref, shape
-    assert _rel(xhat.cpu(), xref) < 1e-4
+    # byte-identical to the CPU oracle, or every difference is a located fp32 rounding tie (printed with -s)
+    flips = _assert_identical_or_located_ties(codec, oracle, x, data, ref, a, f"shape {shape}")
+    if flips == 0:
+        assert _rel(xhat.cpu(), xref) < 1e-4
     (nz,) = struct.unpack("I", data[:4])
     assert struct.unpack(">3I", data[4:16]) == (a["z"].shape[-2], a["z"].shape[-1], shape[0])
 
@@ -118,13 +118,49 @@ def _entropy_stage_inputs(codec, x):
     return y.cpu(), scales.cpu(), sym.cpu(), idx.cpu()
 
 
+def _assert_identical_or_located_ties(codec, oracle, x, data, ref, a, tag, max_flips=2):
+    """data == ref byte for byte, EXCEPT for fp32 rounding ties between the MFMA and the torch-CPU summation orders:
+    every differing symbol / index is located and shown to be a tie (y within 2e-4 of a rounding boundary, or the scale
+    within 2e-4 relative of a table threshold), at most max_flips of them, and the rANS layer is then shown exact on the
+    oracle's own integers.  Returns the number of flips (0 = identical)."""
+    from cbench_basic_amd import ans
+    if data == ref:
+        return 0
+    y, scales, sym, idx = _entropy_stage_inputs(codec, x)
+    flips_s = (sym != a["y_sym"]).nonzero()
+    flips_i = (idx != a["y_idx"]).nonzero()
+    z_same = bool((codec.entropy_coder.latent_node_entropy_coders["z"](
+        codec.entropy_coder.latent_inference_modules["y_z"](codec.entropy_coder.latent_inference_modules["x_y"](x.cuda()))).cpu()
+        == a["z_hat"]).all())
+    print(f"{tag}: streams differ; symbol flips {len(flips_s)}, index flips {len(flips_i)} of {sym.numel()}, z identical {z_same}")
+    assert z_same, "a z symbol flipped: the scales of the whole image differ, not a single tie"
+    assert 0 < len(flips_s) + len(flips_i) <= max_flips, "streams differ without a located symbol / index flip"
+    for f in flips_s:
+        v = float(a["y"][tuple(f)])
+        print(f"  symbol flip at {tuple(int(i) for i in f)}: y = {v!r} (oracle) vs {float(y[tuple(f)])!r} (GPU)")
+        assert abs(abs(v - math.floor(v)) - 0.5) < 2e-4
+    for f in flips_i:
+        v = float(a["scales"][tuple(f)])
+        print(f"  index flip at {tuple(int(i) for i in f)}: scale = {v!r} (oracle) vs {float(scales[tuple(f)])!r} (GPU)")
+        assert float(((oracle.table - v).abs() / oracle.table).min()) < 2e-4
+    # the rANS layer itself: the oracle's integers through the HIP coder give the oracle's y streams
+    enc = ans.Rans64Encoder(16, True, 4)
+    enc.init_cdf_params(*oracle.gc)
+    (nz,) = struct.unpack("I", ref[:4])
+    y_body, cur = ref[4 + nz:], 12
+    for b in range(x.shape[0]):
+        (n,) = struct.unpack(">I", y_body[cur:cur + 4])
+        assert enc.encode_with_indexes(a["y_sym"][b].numpy(), a["y_idx"][b].numpy()) == y_body[cur + 4:cur + 4 + n], b
+        cur += 4 + n
+    return len(flips_s) + len(flips_i)
+
+
 def test_kodak_shaped_image_roundtrip(setup):
     """BASELINE configs[1] shape: 3x512x768 (Kodak), batch 1 -- y is 192x32x48 = 294,912 symbols in one stream.
     The stream must equal the CPU oracle's byte for byte, EXCEPT for fp32 rounding ties between the MFMA and the
     torch-CPU summation orders; every such flip is located and shown to be a tie (|frac(y)| within 2e-4 of .5, or the
     scale within 2e-4 relative of a table threshold), at most 2 of them, and the rANS layer is then shown exact on the
     oracle's own integers."""
-    from cbench_basic_amd import ans
     from oracle.codec_oracle import psnr
     codec, oracle = setup
     torch.manual_seed(24)
@@ -135,29 +171,8 @@ def test_kodak_shaped_image_roundtrip(setup):
     xref = oracle.decompress(ref)
     assert xhat.shape == x.shape
     a = oracle.analyse(x)
-    y, scales, sym, idx = _entropy_stage_inputs(codec, x)
-    flips_s = (sym != a["y_sym"]).nonzero()
-    flips_i = (idx != a["y_idx"]).nonzero()
-    print(f"kodak-shaped: identical={data == ref}; symbol flips {len(flips_s)}, index flips {len(flips_i)} of {sym.numel()}")
-    if data != ref:
-        assert 0 < len(flips_s) + len(flips_i) <= 2, "streams differ without a located symbol / index flip"
-        for f in flips_s:
-            v = float(a["y"][tuple(f)])
-            print(f"  symbol flip at {tuple(int(i) for i in f)}: y = {v!r} (oracle) vs {float(y[tuple(f)])!r} (GPU)")
-            assert abs(abs(v - math.floor(v)) - 0.5) < 2e-4
-        table = oracle.table
-        for f in flips_i:
-            v = float(a["scales"][tuple(f)])
-            print(f"  index flip at {tuple(int(i) for i in f)}: scale = {v!r} (oracle) vs {float(scales[tuple(f)])!r} (GPU)")
-            assert float(((table - v).abs() / table).min()) < 2e-4
-        # the rANS layer itself: the oracle's integers through the HIP coder give the oracle's y stream
-        enc = ans.Rans64Encoder(16, True, 4)
-        enc.init_cdf_params(*oracle.gc)
-        (nz,) = struct.unpack("I", ref[:4])
-        y_body = ref[4 + nz:]
-        assert enc.encode_with_indexes(a["y_sym"].numpy(), a["y_idx"].numpy()) == y_body[16:]
-    else:
-        assert len(flips_s) + len(flips_i) == 0
+    flips = _assert_identical_or_located_ties(codec, oracle, x, data, ref, a, "kodak-shaped")
+    print(f"kodak-shaped: identical={flips == 0}")
     assert float((psnr(xhat, x) - psnr(xref, x)).abs().max()) < 0.01
     # cross-decoding: the oracle reads the GPU stream
     assert _rel(oracle.decompress(data), xhat) < 1e-3
