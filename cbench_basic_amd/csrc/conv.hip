@@ -84,6 +84,16 @@ struct TapLaunch {
     signed char dy[kMaxTaps], dx[kMaxTaps];  // relative to (dymin, dxmin)
 };
 
+// Workgroup -> tile map.  Workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share one; speed only, never
+// correctness), and each XCD has its own L2: with tile = blockIdx.x, horizontally adjacent tiles -- which share the 128-byte
+// lines under their common halo columns -- always sit on different XCDs and every such line is pulled out of the
+// fabric twice.  Handing each XCD a CONTIGUOUS range of tiles keeps neighbours behind one L2.
+__device__ __forceinline__ int xcd_tile(int b, int n)
+{
+    const int per = n >> 3;
+    return b < (per << 3) ? (b & 7) * per + (b >> 3) : b;
+}
+
 __device__ __forceinline__ float apply_act(float v, int act)
 {
     if (act == BASIC_ACT_RELU) return v > 0.f ? v : 0.f;
@@ -156,7 +166,7 @@ __global__ __launch_bounds__(64 * WAVES, (MT <= 4 && WAVES == 4 ? 2 : 1)) void c
     const int khalf = lane >> 5, col = lane & 31;
 
     // tile origin
-    int bid = blockIdx.x;
+    int bid = xcd_tile(blockIdx.x, gridDim.x);
     const int tx_i = bid % g.tiles_x; bid /= g.tiles_x;
     const int ty_i = bid % g.tiles_y; bid /= g.tiles_y;
     const int TB = 1 << g.tb_log, TH = 1 << g.th_log, TW = 1 << g.tw_log;
@@ -720,7 +730,7 @@ __global__ __launch_bounds__(256) void deconv5s2_cout3_kernel(const SmallLaunch 
 {
     __shared__ __attribute__((aligned(16))) float patch[kSmCK][kSmPH][kSmPitch];
     const int tid = threadIdx.x;
-    int bid = blockIdx.x;
+    int bid = xcd_tile(blockIdx.x, gridDim.x);
     const int tx_i = bid % g.tiles_x; bid /= g.tiles_x;
     const int ty_i = bid % g.tiles_y; bid /= g.tiles_y;
     const int b = bid;
@@ -805,7 +815,7 @@ __global__ __launch_bounds__(256) void deconv5s2_cout3_dma_kernel(const SmallLau
     __shared__ __attribute__((aligned(16))) float buf[2 * kSmDStage];
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: LDS-DMA bases stay scalar
-    int bid = blockIdx.x;
+    int bid = xcd_tile(blockIdx.x, gridDim.x);
     const int tx_i = bid % g.tiles_x; bid /= g.tiles_x;
     const int ty_i = bid % g.tiles_y; bid /= g.tiles_y;
     const int b = bid;
