@@ -10,7 +10,11 @@ rows = list(csv.DictReader(open(f)))
 def nm(r):
     return r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
 ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), nm(r), r.get("Queue_Id", "?"), r.get("Stream_Id", "?")) for r in rows))
-t_end = max(e[1] for e in ev)
+# window = the last window_ms before the final rANS kernel ends (the timed loop; the roofline measurement passes that
+# follow it in bench.py run on one stream), or before the end of the trace when there is no rANS kernel
+rans_ends = [e[1] for e in ev if "rans_" in e[2]]
+t_end = max(rans_ends) if rans_ends else max(e[1] for e in ev)
+ev = [e for e in ev if e[0] <= t_end]
 t0 = t_end - int(window_ms * 1e6)
 sel = [e for e in ev if e[0] >= t0]
 print(f"{'start_ms':>9s} {'dur_us':>8s} {'q':>3s} {'s':>3s} kernel")
