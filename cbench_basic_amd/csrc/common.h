@@ -41,4 +41,12 @@ int set_rans_waves(int waves_per_block);
 
 constexpr int kWave = 64;  // CDNA wavefront
 
+// Device view of a table set's fast-decoder search image (rans.hip), for kernels outside rans.hip that decode in place.
+struct RansFastView {
+    const uint32_t *image = nullptr, *meta = nullptr;   // image: per row 64 x {key, start, freq, pad} (rows <= 64 entries)
+    const int32_t *sizes = nullptr, *offsets = nullptr; //        or {dummy lane, 64 block-end probes, the row}; meta: byte offsets
+    int image_words = 0, rows = 0, precision = 16, bypass = 1, bypass_precision = 4;
+};
+int rans_fast_view(const basic_rans_tables *t, RansFastView *out);   // BASIC_ERR_INVALID when the set has no fast image
+
 }  // namespace basic

