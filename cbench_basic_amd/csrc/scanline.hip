@@ -202,16 +202,16 @@ __device__ __forceinline__ void stage_inputs(const ScanArgs &a, int l, int p, in
 //      Lanes with the same image read the same input address (LDS broadcast); weight rows are padded by 4 (1) floats so
 //      that the lanes' rows start on different banks.  The order of summation depends only on the layer shapes: the same in
 //      the encoder and in the decoder launch, which is all that matters for the stream.
-__device__ __forceinline__ float quarter_dot(const float *wr, const float *xr, int K, int wave, int vec4)
+__device__ __forceinline__ float slice_dot(const float *wr, const float *xr, int K, int chunk, int nchunks, int vec4)
 {
     // four independent running sums (columns j, j+1, j+2, j+3 of every group of four) keep four LDS read pairs and four FMA
     // chains in flight; they are folded as (a0 + a1) + (a2 + a3)
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     if (vec4) {
-        const int K4 = K >> 2, q = (K4 + 3) >> 2;
-        const int kend = (wave + 1) * q < K4 ? (wave + 1) * q : K4;
+        const int K4 = K >> 2, q = (K4 + nchunks - 1) / nchunks;
+        const int kend = (chunk + 1) * q < K4 ? (chunk + 1) * q : K4;
         const f4 *x4 = reinterpret_cast<const f4 *>(xr), *w4 = reinterpret_cast<const f4 *>(wr);
-        int k4 = wave * q;
+        int k4 = chunk * q;
 #define BASIC_FMA4(A, WV, XV) A = fmaf(WV[0], XV[0], A); A = fmaf(WV[1], XV[1], A); A = fmaf(WV[2], XV[2], A); A = fmaf(WV[3], XV[3], A)
         for (; k4 + 4 <= kend; k4 += 4) {
             const f4 x0 = x4[k4], x1 = x4[k4 + 1], x2 = x4[k4 + 2], x3 = x4[k4 + 3];
@@ -221,9 +221,9 @@ __device__ __forceinline__ float quarter_dot(const float *wr, const float *xr, i
         for (; k4 < kend; ++k4) { const f4 xv = x4[k4], wv = w4[k4]; BASIC_FMA4(a0, wv, xv); }
 #undef BASIC_FMA4
     } else {
-        const int q = (K + 3) >> 2;
-        const int kend = (wave + 1) * q < K ? (wave + 1) * q : K;
-        int kk = wave * q;
+        const int q = (K + nchunks - 1) / nchunks;
+        const int kend = (chunk + 1) * q < K ? (chunk + 1) * q : K;
+        int kk = chunk * q;
         for (; kk + 4 <= kend; kk += 4) {
             a0 = fmaf(wr[kk], xr[kk], a0); a1 = fmaf(wr[kk + 1], xr[kk + 1], a1);
             a2 = fmaf(wr[kk + 2], xr[kk + 2], a2); a3 = fmaf(wr[kk + 3], xr[kk + 3], a3);
@@ -399,15 +399,22 @@ __global__ __launch_bounds__(kThreads) void scanline_persistent_kernel(const Sca
                 const int nb = (a.B - b0) < a.bc ? (a.B - b0) : a.bc;
                 if (rw > 0 && !(a.debug & 2)) stage_inputs(a, l, p, py, px, b0, nb, xs);
                 __syncthreads();
+                // S lanes per output (a power of two: 64 / S outputs per round), each of the 4 * S (wave, sub-lane) pairs walks
+                // one contiguous slice of K; the finishing thread adds the 4 * S slice sums in slice order
                 const int items = (a.debug & 4) ? 0 : nb * rw, Kp = K + (a.vec4 ? 4 : 1);
-                for (int i0 = 0; i0 < items; i0 += 64) {
-                    const int item = i0 + lane;
-                    const bool on = item < items;
+                int S = 1;
+                while (S < 16 && items * (S << 1) <= 64) S <<= 1;
+                const int per_round = 64 / S;
+                for (int i0 = 0; i0 < items; i0 += per_round) {
+                    const int item = i0 + lane / S, sub = lane & (S - 1);
+                    const bool on = item < items && lane / S < per_round;
                     const int bi = on ? item / rw : 0, r = on ? item - bi * rw : 0;
-                    part[wave * 64 + lane] = quarter_dot(wl + r * Kp, xs + bi * K, K, wave, a.vec4);
+                    part[wave * 64 + lane] = slice_dot(wl + r * Kp, xs + bi * K, K, wave * S + sub, 4 * S, a.vec4);
                     __syncthreads();
-                    if (wave == 0 && on) {
-                        float v = ((part[lane] + part[64 + lane]) + part[128 + lane]) + part[192 + lane];
+                    if (wave == 0 && on && sub == 0) {
+                        float v = 0.f;
+                        for (int w4 = 0; w4 < 4; ++w4)
+                            for (int s2 = 0; s2 < S; ++s2) v += part[w4 * 64 + (lane / S) * S + s2];
                         v += a.bias[l] ? a.bias[l][r_first + r] : 0.f;
                         if (a.act_after[l]) v = v > 0.f ? v : 0.01f * v;   // LeakyReLU(0.01)
                         if (l < last) st_sc1(a.act[l] + static_cast<int64_t>(b0 + bi) * a.rows[l] + r_first + r, v);
