@@ -50,6 +50,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the pcie_inclusive and strong-scaling legs (profiling runs)")
     ap.add_argument("--no-dominant", action="store_true", help="skip the single-launch roofline (counter passes: keeps the launch mix = timed passes)")
+    ap.add_argument("--workload", default="hyperprior", choices=["hyperprior", "checkerboard", "basic"],
+                    help="hyperprior = the headline (BASELINE configs[4] shape); checkerboard = configs[2] topo-group AR codec; "
+                         "basic = configs[3] BaSIC slimmable scan-line codec at complexity level 0 (parity-test configurations, extra lines)")
     ap.add_argument("--master-port", type=int, default=29533)
     return ap.parse_args()
 
@@ -179,8 +182,148 @@ def traffic_from_profiles():
     return None, None
 
 
+def masked_conv_flops(plan_cin, plan_cout, k, topo_in, topo_out, allow_same, positions):
+    """Algorithmic FLOPs (2 * MAC) of TopoGroupDynamicMaskConv2d (masked_conv.py:102-228) evaluated at `positions` (flat
+    ids y * W + x): for every output group the (input group, tap) pairs whose neighbour id is < (<=) the centre id."""
+    import numpy as np
+    Gi, H, W = topo_in.shape
+    Go = topo_out.shape[0]
+    half = k // 2
+    macs = 0
+    ys, xs = np.asarray(positions) // W, np.asarray(positions) % W
+    for dy in range(-half, half + 1):
+        for dx in range(-half, half + 1):
+            ny, nx = ys + dy, xs + dx
+            ok = (ny >= 0) & (ny < H) & (nx >= 0) & (nx < W)
+            nyc, nxc = np.clip(ny, 0, H - 1), np.clip(nx, 0, W - 1)
+            for gi in range(Gi):
+                tn = topo_in[gi, nyc, nxc]
+                for go in range(Go):
+                    tc = topo_out[go, ys, xs]
+                    m = ok & ((tn <= tc) if allow_same else (tn < tc))
+                    macs += int(m.sum()) * (plan_cin // Gi) * (plan_cout // Go)
+    return 2 * macs
+
+
+def run_ar_workload(args):
+    """Extra bench lines for the AR parity configurations: one codec, one stream (module path), HIP-event time of every
+    masked-convolution launch of one measured encode + decode pass for the roofline of masked_conv_pos_kernel."""
+    import numpy as np
+    import torch
+    from cbench_basic_amd.nn import kernels as K
+    from cbench_basic_amd.presets import basic_codec, seed_synthetic_weights, topogroup_ar_codec
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    if args.workload == "checkerboard":
+        codec, batch, name = topogroup_ar_codec("checkerboard"), args.batch, "topo-group AR codec, checkerboard + expand-bottleneck merger (lossy_latent_graph_topogroup)"
+    else:
+        codec, batch, name = basic_codec(), min(args.batch, 64), "BaSIC slimmable scan-line codec, complexity level 0 (lossy_latent_graph_scalable_ar_models)"
+    codec = seed_synthetic_weights(codec, seed=0).eval()
+    g = torch.Generator().manual_seed(1)
+    with torch.no_grad():
+        for n, p in codec.named_parameters():
+            if ".latent_node_entropy_coders.y." in n:
+                p.copy_(torch.randn(p.shape, generator=g) * (0.02 if p.dim() > 1 else 0.01))
+    cpu_state = {k: v.detach().cpu().clone() for k, v in codec.entropy_coder.state_dict().items()}
+    codec = codec.to(dev)
+    codec.update_state()
+    if args.workload == "basic":
+        codec.set_complex_level(0)
+    x = torch.stack([image(i, args.size) for i in range(batch)]).to(dev)
+    for _ in range(args.warmup):
+        codec.decompress(codec.compress(x))
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(args.steps):
+        data = codec.compress(x)
+        xhat = codec.decompress(data)
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    pix = batch * args.size ** 2 * args.steps
+    # ---- one instrumented pass (HIP graphs off): events around every masked-convolution launch, FLOPs from the masks
+    yc = codec.entropy_coder.latent_node_entropy_coders["y"]
+    yc.use_hip_graphs = False
+    yc._graphs = {}
+    events, flops = [], [0]
+    orig = K.MaskedConvPlan.__call__
+
+    def timed(self, xin, topo_in, topo_out, pos, out, out_offset=0, step=None, first_step=None):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = orig(self, xin, topo_in, topo_out, pos, out, out_offset=out_offset, step=step, first_step=first_step)
+        e1.record()
+        events.append((e0, e1))
+        ti, to = topo_in.cpu().numpy(), topo_out.cpu().numpy()
+        H, W = ti.shape[1:]
+        pp = np.unique(pos.cpu().numpy() % (H * W))
+        first = first_step.cpu().numpy().reshape(-1) if step is not None else None
+        f = 0
+        for go in range(to.shape[0]):
+            tg = to[go].reshape(-1)
+            # the step rule evaluates only the (output group, position) pairs of this step (id-less groups at the first visit)
+            q = pp if step is None else [v for v in pp if tg[v] == step or (tg[v] < 0 and first[v] == step)]
+            if len(q):
+                f += masked_conv_flops(self.cin, self.cout // to.shape[0], self.k, ti, to[go:go + 1], self._same, q)
+        flops[0] += f * xin.shape[0]
+        return r
+    # allow_same is a plan property: remember it at construction for the FLOP count
+    yc._layers = None
+    orig_init = K.MaskedConvPlan.__init__
+
+    def init(self, weight, bias, in_groups, out_groups, allow_same, act=K.ACT_NONE):
+        orig_init(self, weight, bias, in_groups, out_groups, allow_same, act)
+        self._same = bool(allow_same)
+    K.MaskedConvPlan.__init__, K.MaskedConvPlan.__call__ = init, timed
+    yc.persistent_scanline_max_batch = 0
+    try:
+        yc._ready()
+        d2 = codec.compress(x)
+        codec.decompress(d2)
+        torch.cuda.synchronize()
+    finally:
+        K.MaskedConvPlan.__init__, K.MaskedConvPlan.__call__ = orig_init, orig
+    mc_ms = sum(e0.elapsed_time(e1) for e0, e1 in events)
+    ach = flops[0] / (mc_ms / 1e3) / 1e12 if mc_ms > 0 else 0.0
+    from cbench_basic_amd.nn import kernels as K2
+    mse = K2.mse_per_image(xhat, x)
+    out = dict(metric="encode+decode Mpix/s", value=pix / dt / 1e6, unit="Mpix/s", n_gpus=1, steps=args.steps, warmup=args.warmup,
+               ms_per_step=dt / args.steps * 1e3, higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+               config=dict(workload=f"{name}, synthetic 3x{args.size}x{args.size} images, {batch} images per step resident in HBM, one stream",
+                           images_per_gpu=batch, bpp=len(data) * 8 / (batch * args.size ** 2), psnr_db=float((-10 * torch.log10(mse.double())).mean())),
+               roofline=dict(bound="mfma", achieved=ach, peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_FP32_MFMA_TFLOPS, traffic=None,
+                             kernel="masked_conv_pos_kernel (+ masked_conv_reduce_kernel): the masked-convolution launches of one encode + decode pass "
+                                    "of the y-coder (context convolution + merger layers at the coded positions), HIP events per launch",
+                             flops_per_launch=flops[0] / max(1, len(events)), launches_per_pass=len(events), avg_launch_ms=mc_ms / max(1, len(events)),
+                             pass_ms=mc_ms, note="algorithmic FLOPs = 2 x the (output, input, tap) products the reference's masks keep at the positions a step codes"))
+    if not args.no_cpu_baseline:
+        from oracle.codec_oracle import BasicCodecOracle, TopoGroupCodecOracle
+        from cbench_basic_amd.presets import BASIC_WIDTHS
+        try:
+            cores = len(os.sched_getaffinity(0))
+        except AttributeError:
+            cores = os.cpu_count() or 1
+        cores = max(1, min(cores, 16))
+        torch.set_num_threads(cores)
+        oracle = TopoGroupCodecOracle(cpu_state, "checkerboard", 192, 1, True) if args.workload == "checkerboard" else BasicCodecOracle(cpu_state, BASIC_WIDTHS)
+        t0, done = time.time(), 0
+        for i in range(batch):
+            xi = image(i, args.size).unsqueeze(0)
+            oracle.decompress(oracle.compress(xi))
+            done += 1
+            if time.time() - t0 > 15.0:
+                break
+        cdt = time.time() - t0
+        out["cpu_baseline"] = dict(value=done * args.size ** 2 / cdt / 1e6, unit="Mpix/s", cores=cores, kind="port",
+                                   sample=f"images 0..{done - 1} of the same synthetic set, batch 1, PyTorch-CPU fp32 oracle of the same graph, {cdt:.1f} s wall")
+    print(json.dumps(out))
+
+
 def main():
     args = parse()
+    if args.workload != "hyperprior":
+        if args.gpus != 1:
+            raise SystemExit("the AR workloads are single-GPU extra lines")
+        return run_ar_workload(args)
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is None and args.gpus > 1:
         raise SystemExit(self_launch(args))
