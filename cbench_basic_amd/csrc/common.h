@@ -39,6 +39,11 @@ hipError_t ensure_max_lds(const void *kernel);
 // previous setting.
 int set_rans_waves(int waves_per_block);
 
+// Whether the calling thread's next launches of the persistent first-layer convolution hand their tiles out dynamically (a
+// device counter) instead of by a static stride; returns the previous setting.  Dynamic pays when other HIP streams hold
+// compute units for long (a late workgroup no longer drags the launch), static is faster alone on the chip.
+bool set_dynamic_tiles(bool on);
+
 constexpr int kWave = 64;  // CDNA wavefront
 
 // Device view of a table set's fast-decoder search image (rans.hip), for kernels outside rans.hip that decode in place.

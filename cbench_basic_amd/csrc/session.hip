@@ -200,10 +200,11 @@ struct TokenPhase {   // RAII: a phase of one session on one stream
     ~TokenPhase() { if (on) (void)close(); }
 };
 
-struct WavesGuard {   // the session's rANS geometry applies to this thread's launches for the duration of a call
+struct WavesGuard {   // the session's rANS geometry / tile hand-out apply to this thread's launches for the duration of a call
     int prev;
-    explicit WavesGuard(int w) : prev(set_rans_waves(w)) {}
-    ~WavesGuard() { set_rans_waves(prev); }
+    bool prev_dyn;
+    explicit WavesGuard(int w, bool concurrent = false) : prev(set_rans_waves(w)), prev_dyn(set_dynamic_tiles(concurrent)) {}
+    ~WavesGuard() { set_rans_waves(prev); set_dynamic_tiles(prev_dyn); }
 };
 
 // the stream the non-transform work of a call goes to: the caller's, or (token mode) the session's priority stream,
@@ -369,7 +370,7 @@ extern "C" int basic_hp_encode_images(basic_hp_session *s, const float *x, int x
     BASIC_REQUIRE(s && x && out_len && batch >= 1 && h >= 1 && w >= 1, "hp_encode_images: bad argument");
     s->res_batch = 0;
     hipStream_t st = as_stream(hip_stream);
-    WavesGuard guard(s->rans_waves);
+    WavesGuard guard(s->rans_waves, s->use_token);
     int rc;
     const float *d_x = x;
     if (x_on_host) {   // general_codec.py:46-47: the upload belongs to compress()
@@ -554,7 +555,7 @@ extern "C" int basic_hp_decode_images(basic_hp_session *s, const uint8_t *data, 
 {
     BASIC_REQUIRE(s && d_xhat, "hp_decode_images: bad argument");
     hipStream_t st = as_stream(hip_stream);
-    WavesGuard guard(s->rans_waves);
+    WavesGuard guard(s->rans_waves, s->use_token);
     Body z, y;
     int rc = split_bodies(data, len, &z, &y);
     if (rc) return rc;
