@@ -7,11 +7,14 @@ synthetic 3x256x256 images, N=128 / M=192, configs/lossy_graph_scalable_exp_hp.p
       `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same flags>` as a CHILD before it has
       touched the GPU and exits with the child's code (one rank per GPU, RCCL over xGMI for the metric reduction only).
 
-A "step" = every image of the rank's batch goes through codec.compress() and codec.decompress() once.  The batch is
-split over `--workers` concurrent stream workers (cbench_basic_amd/benchmark/stream_workers.py, the analogue of the
-reference's num_testing_workers pool, basic_benchmark.py:829-858): each worker loops compress -> decompress over its
-shard on its own HIP stream, so one worker's serial rANS chains run beside another worker's MFMA transforms.  The timed
-region is bracketed by barrier + synchronize on both sides and holds exactly K steps of every worker.
+A "step" = every image of the rank's batch goes through codec.compress() and codec.decompress() once.  The K steps are
+spread over `--workers` concurrent stream workers (cbench_basic_amd/benchmark/stream_workers.py, the analogue of the
+reference's num_testing_workers pool, basic_benchmark.py:829-858, which hands whole dataset items to its workers): step
+k runs on worker k mod W, each worker loops compress -> decompress over the whole batch on its own HIP stream, so W
+batches are in flight and one worker's serial rANS chains run beside another worker's MFMA transforms
+(`--shard-by images` cuts every step's batch into W shards instead).  The timed region is bracketed by barrier +
+synchronize on both sides and holds exactly K steps; `config.call_latency_ms` is the wall time of one
+compress+decompress call of one worker.
 
 `value` is measured with the input batch resident in HBM (the tier's contract); `pcie_inclusive` repeats the run with
 the batch in page-locked host memory, uploaded INSIDE compress() as the reference's timed region does
@@ -39,13 +42,17 @@ PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=256, help="images per GPU per step (weak scaling)")
     ap.add_argument("--total", type=int, default=256, help="images per step over ALL GPUs in the strong-scaling leg (cfg-5)")
     ap.add_argument("--size", type=int, default=256)
-    ap.add_argument("--workers", type=int, default=2, help="concurrent stream workers per GPU (1 = plain sequential calls)")
-    ap.add_argument("--rans-waves", type=int, default=-1, help="image streams per rANS workgroup (-1: 4 with workers > 1, else library default)")
+    ap.add_argument("--workers", type=int, default=3, help="concurrent stream workers per GPU (1 = plain sequential calls)")
+    ap.add_argument("--shard-by", default="steps", choices=["steps", "images"],
+                    help="how the K steps are spread over the workers: steps = every worker codes WHOLE batches, step k on worker k mod W "
+                         "(W batches in flight; the reference's pool also hands whole dataset items to its workers); "
+                         "images = every step's batch is cut into W contiguous shards")
+    ap.add_argument("--rans-waves", type=int, default=-1, help="image streams per rANS workgroup (-1: 8 for whole batches in flight, 4 for image shards, library default with one worker)")
     ap.add_argument("--cpu-images", type=int, default=2000, help="bounded CPU-baseline sample (images)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the pcie_inclusive and strong-scaling legs (profiling runs)")
@@ -354,7 +361,10 @@ def main():
     from cbench_basic_amd.utils.bytes_ops import split_merged_bytes
     from cbench_basic_amd.utils.dist_metrics import gather_per_image, reduce_metric_sums, shard_indices
 
-    waves = args.rans_waves if args.rans_waves >= 0 else (4 if workers > 1 else 0)
+    by_steps = args.shard_by == "steps" and workers > 1
+    # packing more image streams into one rANS workgroup frees compute units for the other workers' transforms at the
+    # price of a longer chain (+2 % at 4, +10 % at 8, x2 at 16): with whole batches in flight the chain has slack
+    waves = args.rans_waves if args.rans_waves >= 0 else (8 if by_steps else 4 if workers > 1 else 0)
 
     def make_codec():
         c = seed_synthetic_weights(hyperprior_codec(), seed=0).eval().to(dev)   # every replica: the same seeded weights
@@ -368,22 +378,34 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    def run_leg(pool, shards, steps, warmup):
-        """K steps of every worker over its shard; returns (seconds, bytes per step, last step's [(bytes, xhat)] per shard)."""
-        def loop(codec, shard, n):
-            out = None
+    def run_leg(pool, batch, steps, warmup):
+        """Exactly K steps (K x the whole batch through compress + decompress) spread over the workers; returns (seconds,
+        bytes of one step, [(bytes, xhat)] of one whole batch in image order, mean seconds of one compress+decompress call)."""
+        if by_steps:   # step k on worker k mod W: whole batches, W of them in flight
+            work = [(batch, len(range(w, steps, workers)), max(1, len(range(w, warmup, workers))) if warmup else 0)
+                    for w in range(workers)]
+        else:          # every step's batch cut into W shards
+            work = [(s, steps, warmup) for s in split_batch(batch, workers)]
+        lat = [0.0] * len(work)
+
+        def loop(i, codec, shard, n):
+            out, t = None, time.time()
             for _ in range(n):
                 data = codec.compress(shard)
                 out = (data, codec.decompress(data))
+            lat[i] = (time.time() - t) / max(n, 1)
             return out
-        if warmup:
-            pool.map(lambda c, s: loop(c, s, warmup), shards)
+        idx = list(range(len(work)))
+        pool.map(lambda c, i: loop(i, c, work[i][0], work[i][2]), idx)
         barrier()
         t0 = time.time()
-        last = pool.map(lambda c, s: loop(c, s, steps), shards)
+        last = pool.map(lambda c, i: loop(i, c, work[i][0], work[i][1]), idx)
         barrier()
         dt = time.time() - t0
-        return dt, sum(len(d) for d, _ in last), last
+        last = [l for l in last if l is not None]
+        if by_steps:
+            last = last[:1]
+        return dt, sum(len(d) for d, _ in last), last, sum(lat) / len(lat)
 
     # ---- the rank's images.  weak: ids rank*B .. rank*B+B-1;  strong: image i of `total` lives on rank i mod world
     weak_ids = list(range(rank * args.batch, (rank + 1) * args.batch))
@@ -393,8 +415,7 @@ def main():
     codec = pool.codecs[0]
     cpu_state = {k: v.detach().cpu().clone() for k, v in codec.entropy_coder.state_dict().items()}
 
-    shards = split_batch(x, workers)
-    dt, step_bytes, last = run_leg(pool, shards, args.steps, args.warmup)
+    dt, step_bytes, last, call_s = run_leg(pool, x, args.steps, args.warmup)
 
     # per-image (bytes, PSNR) of the last step, gathered over xGMI into image order: not part of the timed region
     xhat = torch.cat([xh for _, xh in last])
@@ -417,7 +438,7 @@ def main():
     extra = {}
     if not args.no_extra_legs:
         # (1) input in page-locked HOST memory, uploaded inside compress() (the reference's timed region)
-        hdt, _, _ = run_leg(pool, split_batch(x_host, workers), args.steps, 1)
+        hdt, _, _, _ = run_leg(pool, x_host, args.steps, 1)
         hred = reduce_metric_sums(dict(time_s=hdt, images=float(args.batch * args.steps)), device=dev)
         extra["pcie_inclusive"] = dict(value=hred["images"] * args.size ** 2 / hred["time_s"] / 1e6, unit="Mpix/s",
                                        ms_per_step=hred["time_s"] / args.steps * 1e3,
@@ -426,7 +447,7 @@ def main():
         if world > 1:
             ids = shard_indices(args.total, rank, world)
             xs = torch.stack([image(i, args.size) for i in ids]).to(dev)
-            sdt, _, _ = run_leg(pool, split_batch(xs, workers), args.steps, 1)
+            sdt, _, _, _ = run_leg(pool, xs, args.steps, 1)
             sred = reduce_metric_sums(dict(time_s=sdt, images=float(len(ids) * args.steps)), device=dev)
             extra["strong"] = dict(value=sred["images"] * args.size ** 2 / sred["time_s"] / 1e6, unit="Mpix/s", scaling="strong",
                                    images_total_per_step=args.total, images_per_gpu=len(ids),
@@ -451,8 +472,11 @@ def main():
             vs_baseline=None, dtype="f32", data="synthetic",
             config=dict(workload=f"hyperprior codec N=128 M=192 (lossy_graph_scalable_exp_hp), synthetic 3x{args.size}x{args.size} images "
                                  f"(image i = manual_seed(i), rand), {args.batch} images per GPU per step resident in HBM, "
-                                 f"compress+decompress incl. bitstream D2H/H2D, {workers} concurrent stream workers per GPU",
+                                 f"compress+decompress incl. bitstream D2H/H2D, {workers} concurrent stream workers per GPU "
+                                 + ("(step k on worker k mod W: whole batches, W in flight)" if by_steps else "(each step's batch cut into W shards)"),
                         images_per_gpu=args.batch, workers=workers, rans_waves_per_workgroup=waves,
+                        shard_by=args.shard_by if workers > 1 else None, batches_in_flight=workers if by_steps else 1,
+                        call_latency_ms=call_s * 1e3,
                         bpp=n_bytes * 8 / pix, psnr_db=red["psnr_sum"] / red["psnr_n"],
                         gathered_images=int(table.shape[0]),
                         gathered_bpp=float(table[:, 0].sum()) * 8 / (table.shape[0] * args.size * args.size),
