@@ -54,6 +54,9 @@ def parse():
                          "images = every step's batch is cut into W contiguous shards")
     ap.add_argument("--rans-waves", type=int, default=-1, help="image streams per rANS workgroup (-1: 8 for whole batches in flight, 4 for image shards, library default with one worker)")
     ap.add_argument("--cpu-images", type=int, default=2000, help="bounded CPU-baseline sample (images)")
+    ap.add_argument("--input", default="hbm", choices=["hbm", "host"],
+                    help="where the batch lives when the timed region starts: hbm = resident (the tier's contract for `value`), "
+                         "host = page-locked host memory, uploaded inside compress() (profiling the pcie_inclusive leg on its own)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the pcie_inclusive and strong-scaling legs (profiling runs)")
     ap.add_argument("--no-dominant", action="store_true", help="skip the single-launch roofline (counter passes: keeps the launch mix = timed passes)")
@@ -415,7 +418,7 @@ def main():
     codec = pool.codecs[0]
     cpu_state = {k: v.detach().cpu().clone() for k, v in codec.entropy_coder.state_dict().items()}
 
-    dt, step_bytes, last, call_s = run_leg(pool, x, args.steps, args.warmup)
+    dt, step_bytes, last, call_s = run_leg(pool, x if args.input == "hbm" else x_host, args.steps, args.warmup)
 
     # per-image (bytes, PSNR) of the last step, gathered over xGMI into image order: not part of the timed region
     xhat = torch.cat([xh for _, xh in last])
@@ -471,7 +474,9 @@ def main():
             warmup=args.warmup, ms_per_step=ms_step, higher_is_better=True, scaling="weak",
             vs_baseline=None, dtype="f32", data="synthetic",
             config=dict(workload=f"hyperprior codec N=128 M=192 (lossy_graph_scalable_exp_hp), synthetic 3x{args.size}x{args.size} images "
-                                 f"(image i = manual_seed(i), rand), {args.batch} images per GPU per step resident in HBM, "
+                                 f"(image i = manual_seed(i), rand), {args.batch} images per GPU per step "
+                                 + ("resident in HBM, " if args.input == "hbm" else "in page-locked HOST memory (uploaded inside compress()), ")
+                                 + 
                                  f"compress+decompress incl. bitstream D2H/H2D, {workers} concurrent stream workers per GPU "
                                  + ("(step k on worker k mod W: whole batches, W in flight)" if by_steps else "(each step's batch cut into W shards)"),
                         images_per_gpu=args.batch, workers=workers, rans_waves_per_workgroup=waves,

@@ -124,6 +124,12 @@ struct basic_hp_session {
     hipEvent_t fork = nullptr, join = nullptr;
     bool use_token = false;
     hipEvent_t enc_phase = nullptr, dec_phase = nullptr;   // close this session's transform phases (see TransformToken)
+    // Upload of a host-resident batch (general_codec.py:46-47): on its own stream, ordered only after the PREVIOUS call's
+    // analysis transform (the last reader of d_x), so it runs beside whatever the caller's stream still has queued (the
+    // previous decode's chains and synthesis transform) instead of between that and this call's first layer.
+    hipStream_t copy = nullptr;
+    hipEvent_t x_free = nullptr, x_ready = nullptr;
+    bool x_read_pending = false;
     ~basic_hp_session();
 };
 
@@ -321,9 +327,10 @@ basic_hp_session::~basic_hp_session()
             g_token.last = nullptr;
         }
     }
-    for (hipEvent_t e : {in_done, enc_phase, dec_phase, fork, join})
+    for (hipEvent_t e : {in_done, enc_phase, dec_phase, fork, join, x_free, x_ready})
         if (e) (void)hipEventDestroy(e);
     if (side) (void)hipStreamDestroy(side);
+    if (copy) (void)hipStreamDestroy(copy);
 }
 
 extern "C" void basic_hp_session_destroy(basic_hp_session *s) { delete s; }
@@ -377,7 +384,15 @@ extern "C" int basic_hp_encode_images(basic_hp_session *s, const float *x, int x
         const size_t bytes = sizeof(float) * static_cast<size_t>(batch) * s->x_channels * h * w;
         rc = s->d_x.ensure(bytes);
         if (rc) return rc;
-        BASIC_HIP_TRY(hipMemcpyAsync(s->d_x.p, x, bytes, hipMemcpyHostToDevice, st));
+        if (!s->copy) {
+            BASIC_HIP_TRY(hipStreamCreateWithFlags(&s->copy, hipStreamNonBlocking));
+            BASIC_HIP_TRY(hipEventCreateWithFlags(&s->x_free, hipEventDisableTiming));
+            BASIC_HIP_TRY(hipEventCreateWithFlags(&s->x_ready, hipEventDisableTiming));
+        }
+        if (s->x_read_pending) BASIC_HIP_TRY(hipStreamWaitEvent(s->copy, s->x_free, 0));
+        BASIC_HIP_TRY(hipMemcpyAsync(s->d_x.p, x, bytes, hipMemcpyHostToDevice, s->copy));
+        BASIC_HIP_TRY(hipEventRecord(s->x_ready, s->copy));
+        BASIC_HIP_TRY(hipStreamWaitEvent(st, s->x_ready, 0));
         d_x = s->d_x.as<float>();
     }
     // ---- inference pass x -> y -> z (latent_graph.py:721-758)
@@ -386,6 +401,10 @@ extern "C" int basic_hp_encode_images(basic_hp_session *s, const float *x, int x
     if (phase.rc) return phase.rc;
     rc = run_chain(s, s->g_a, d_x, batch, h, w, &s->d_y, nullptr, &yh, &yw, st);
     if (rc) return rc;
+    if (x_on_host) {
+        BASIC_HIP_TRY(hipEventRecord(s->x_free, st));
+        s->x_read_pending = true;
+    }
     rc = phase.close();   // the small hyper-path kernels and both rANS stages run beside the next holder's transforms
     if (rc) return rc;
     hipStream_t caller_st = st;
