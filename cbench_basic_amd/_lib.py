@@ -81,6 +81,15 @@ _SIGNATURES = {
     "basic_scanline_status": (_I, [_P, _P, _P]),
     "basic_scanline_plan_destroy": (None, [_P]),
     "basic_mse_per_image_dev": (_I, [_P, _P, _I, _L, _P, _P]),
+    "basic_tans_tables_create": (_I, [_P, _I, _I, _P, _P, _I, _I, _I, _I, _P]),
+    "basic_tans_tables_set_ar": (_I, [_P, _P, _I, _I, _I, _I]),
+    "basic_tans_tables_get_row": (_I, [_P, _I, _P, _P, _P, _P]),
+    "basic_tans_tables_destroy": (None, [_P]),
+    "basic_tans_encode_host": (_I, [_P, _P, _P, _L, _P, _P, _P, _L, _P, _L, _P, _P]),
+    "basic_tans_decode_host": (_I, [_P, _P, _L, _P, _L, _P, _P, _P, _P]),
+    "basic_tans_encode_bound_words": (_L, [_P, _L]),
+    "basic_tans_encode_batch_dev": (_I, [_P, _P, _P, _P, _I, _P, _L, _P, _P]),
+    "basic_tans_decode_batch_dev": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _P]),
 }
 
 

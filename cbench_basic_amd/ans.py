@@ -213,15 +213,141 @@ class Rans64Decoder(_Rans64Base):
         return out
 
 
-def _unsupported(name):
-    class _Unsupported:
-        def __init__(self, *a, **k):
-            raise NotImplementedError(
-                f"{name}: tANS (csrc/ans/tans.cpp) is out of scope of the MI355X hot path "
-                "(coder_type defaults to 'rans64', torch_ans.py:23)")
-    _Unsupported.__name__ = name
-    return _Unsupported
+class _TansBase:
+    """TansBase, csrc/ans/tans.hpp:37-71 (constructor defaults: FSE_DEFAULT_TABLELOG = 11, FSE_MAX_SYMBOL_VALUE = 255,
+    fse.h:590,610)."""
+
+    def __init__(self, table_log=11, max_symbol_value=255, bypass_coding=False, bypass_precision=4):
+        self._table_log = int(table_log)
+        self._max_symbol_value = int(max_symbol_value)
+        self._bypass_coding = bool(bypass_coding)
+        self._bypass_precision = int(bypass_precision)
+        self._tables = None
+        self._ar_order = 0
+
+    def __del__(self):
+        self._free()
+
+    def _free(self):
+        t, self._tables = getattr(self, "_tables", None), None
+        if t:
+            try:
+                _lib.lib().basic_tans_tables_destroy(t)
+            except Exception:
+                pass
+
+    def __reduce__(self):
+        raise TypeError("cannot pickle '%s' object" % type(self).__name__)
+
+    def init_params(self, freqs, num_symbols, offsets):
+        """tans.cpp:368-383: freqs [rows][>= max(num_symbols)]; the counts are normalised to 2^table_log per row."""
+        freqs, nsym, offsets = _i32(freqs), _i32(num_symbols).reshape(-1), _i32(offsets).reshape(-1)
+        if freqs.ndim != 2 or freqs.shape[0] != nsym.size:
+            raise ValueError("freqs should be 2-dimensional with shape (num_symbols.size(), >num_symbols.max())")
+        if offsets.size < nsym.size:
+            raise ValueError("offsets should have one entry per distribution")
+        h = ctypes.c_void_p()
+        _lib.check(_lib.lib().basic_tans_tables_create(
+            freqs.ctypes.data, freqs.shape[0], freqs.shape[1], nsym.ctypes.data, offsets.ctypes.data, self._table_log,
+            self._max_symbol_value, int(self._bypass_coding), self._bypass_precision, ctypes.byref(h)))
+        self._free()
+        self._tables = h
+        self._ar_order = 0
+
+    def init_ar_params(self, ar_table, ar_offsets):
+        """ANSBase::init_ar_params, csrc/ans/ans_interface.cpp:75-137."""
+        tab = _i32(ar_table)
+        ar_offsets = np.asarray(ar_offsets)
+        order = tab.ndim - 2
+        if ar_offsets.ndim != 3 or ar_offsets.shape[1] != order or ar_offsets.shape[0] != tab.shape[0]:
+            raise ValueError("ar_offset should be 3-dimensional with shape (ar_tables_size, ar_order, <=data_dims)")
+        if order <= 0:
+            raise ValueError("ar_tables should be at least 3-dimensional with shape (ar_tables_size, index_dim, *ar_order_dims)")
+        if order > 2:
+            raise ValueError("Too many dimensions!")
+        if self._tables is None:
+            raise ValueError("ANS not initialized!")
+        _lib.check(_lib.lib().basic_tans_tables_set_ar(self._tables, tab.ctypes.data, tab.shape[0], tab.shape[1], order, tab.shape[2]))
+        self._ar_order = order
+
+    def get_table_row(self, row):
+        """(next_state, delta_bits, delta_state, decode entries) of one distribution -- not part of the reference's bound
+        surface; the table-level parity tests read it."""
+        if self._tables is None:
+            raise ValueError("ANS not initialized!")
+        size = 1 << self._table_log
+        nxt, dec = np.zeros(size, np.uint16), np.zeros(size, np.uint32)
+        db, ds = np.zeros(65536, np.uint32), np.zeros(65536, np.int32)
+        _lib.check(_lib.lib().basic_tans_tables_get_row(self._tables, int(row), nxt.ctypes.data, db.ctypes.data, ds.ctypes.data,
+                                                        dec.ctypes.data))
+        return nxt, db, ds, dec
+
+    _ar_args = _Rans64Base._ar_args
 
 
-TansEncoder = _unsupported("TansEncoder")
-TansDecoder = _unsupported("TansDecoder")
+class TansEncoder(_TansBase):
+    def __init__(self, table_log=11, max_symbol_value=255, bypass_coding=False, bypass_precision=4):
+        super().__init__(table_log, max_symbol_value, bypass_coding, bypass_precision)
+        self._cache = []
+
+    def _encode(self, symbols, indexes, ar_indexes, ar_offsets, capacity_syms):
+        n = indexes.size
+        ai, o0, o1, keep = self._ar_args(ar_indexes, ar_offsets, n)
+        L = _lib.lib()
+        cap = 4 * int(L.basic_tans_encode_bound_words(self._tables, n)) + 8
+        out = np.empty(cap, dtype=np.uint8)
+        out_len, coded = ctypes.c_int64(), ctypes.c_int64()
+        _lib.check(L.basic_tans_encode_host(self._tables, symbols.ctypes.data, indexes.ctypes.data, n, ai, o0, o1, int(capacity_syms),
+                                            out.ctypes.data, cap, ctypes.byref(out_len), ctypes.byref(coded)))
+        return out[: out_len.value].tobytes(), coded.value
+
+    def encode_with_indexes(self, symbols, indexes, ar_indexes=None, ar_offsets=None, cache=0):
+        """csrc/ans/tans.cpp:527-680.  Like the reference: ``ValueError`` when the output budget ``len(indexes) * table_log
+        / 8`` is 8 bytes or less, and ``b""`` when the stream does not fit that budget.  ``cache`` truthy only buffers."""
+        if self._tables is None:
+            raise ValueError("ANS not initialized!")
+        symbols, indexes = _i32(symbols).reshape(-1), _i32(indexes).reshape(-1)
+        if cache:
+            if self._ar_order:
+                raise NotImplementedError("cached AR encoding")
+            self._cache.append((symbols.copy(), indexes.copy()))
+            return b""
+        return self._encode(symbols, indexes, ar_indexes, ar_offsets, -1)[0]
+
+    def flush(self):
+        """csrc/ans/tans.cpp:682-713 (not bound by PYBIND11_TANS_CLASSES, so unreachable from Python in the reference;
+        kept for the C++ semantics): the cached symbols -- each call stored in reverse -- are coded front to back, i.e. as
+        ONE encode over concat(last call, ..., first call), with the output budget counted in cached symbols incl. bypass
+        digits (:686)."""
+        if self._tables is None:
+            raise ValueError("ANS not initialized!")
+        chunks, self._cache = self._cache[::-1], []
+        if chunks:
+            symbols = np.concatenate([c[0] for c in chunks])
+            indexes = np.concatenate([c[1] for c in chunks])
+        else:
+            symbols = indexes = np.zeros(0, dtype=np.int32)
+        # the budget depends on the coded symbol count, known after a first pass with a budget that cannot fail
+        _, coded = self._encode(symbols, indexes, None, None, 1 << 40)
+        return self._encode(symbols, indexes, None, None, coded)[0]
+
+
+class TansDecoder(_TansBase):
+    def decode_with_indexes(self, encoded, indexes, ar_indexes=None, ar_offsets=None):
+        """csrc/ans/tans.cpp:715-815 -- int32 array shaped like ``indexes``."""
+        if self._tables is None:
+            raise ValueError("ANS not initialized!")
+        indexes = _i32(indexes)
+        n = indexes.size
+        out = np.empty(indexes.shape, dtype=np.int32)
+        buf = np.frombuffer(bytes(encoded), dtype=np.uint8)
+        ai, o0, o1, keep = self._ar_args(ar_indexes, ar_offsets, n)
+        _lib.check(_lib.lib().basic_tans_decode_host(self._tables, buf.ctypes.data, buf.size, indexes.ctypes.data, n, ai, o0, o1,
+                                                     out.ctypes.data))
+        return out
+
+    def set_stream(self, stream):
+        raise NotImplementedError("TansDecoder.decode_stream is an empty stub in the reference (tans.cpp:817-840)")
+
+    def decode_stream(self, indexes, ar_indexes=None, ar_offsets=None):
+        raise NotImplementedError("TansDecoder.decode_stream is an empty stub in the reference (tans.cpp:817-840)")

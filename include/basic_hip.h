@@ -340,6 +340,50 @@ int basic_scanline_decode_dev(basic_scanline_plan *p, const basic_rans_tables *t
 int basic_scanline_status(basic_scanline_plan *p, void *hip_stream, int *poisoned);
 void basic_scanline_plan_destroy(basic_scanline_plan *p);
 
+/* ======================================================================================
+ * 10. Table ANS (csrc/tans.hip) -- the drop-in for the reference's TansEncoder / TansDecoder
+ *       class surface            csrc/ans/tans.hpp:78-157 (PYBIND11_TANS_CLASSES :146-157)
+ *       TansBase::init_params    csrc/ans/tans.cpp:368-383, init_tables :385-525
+ *       encode_with_indexes      csrc/ans/tans.cpp:527-680      flush :682-713
+ *       decode_with_indexes      csrc/ans/tans.cpp:715-815
+ *     Tables (count normalisation, state / symbol-transform / decode tables, tans.cpp:27-318) are built on the host
+ *     and uploaded once; row `rows` of the images is the uniform bypass alphabet when bypass coding is on.
+ *     freqs int32 [rows][freq_stride]; nsym / offsets int32 [rows]; table_log in [5, 12].
+ * ==================================================================================== */
+typedef struct basic_tans_tables basic_tans_tables;
+int basic_tans_tables_create(const int32_t *freqs, int rows, int freq_stride, const int32_t *nsym, const int32_t *offsets,
+                             int table_log, int max_symbol_value, int bypass_coding, int bypass_precision,
+                             basic_tans_tables **out);
+/* ANSBase::init_ar_params (csrc/ans/ans_interface.cpp:75-137), as basic_rans_tables_set_ar. */
+int basic_tans_tables_set_ar(basic_tans_tables *t, const int32_t *ar_tab, int k, int rows, int order, int s1);
+/* One row of the device images back on the host: next_state u16 [2^L], delta_bits / delta_state [nsym],
+ * dec_packed u32 [2^L] = base | bits << 12 | symbol << 16 (any pointer may be NULL). */
+int basic_tans_tables_get_row(const basic_tans_tables *t, int row, uint16_t *next_state, uint32_t *delta_bits,
+                              int32_t *delta_state, uint32_t *dec_packed);
+void basic_tans_tables_destroy(basic_tans_tables *t);
+/* Host-buffer coder (arrays staged to HBM, coded by the HIP kernel, result copied back).  capacity_syms: the symbol
+ * count the reference sizes its output with (-1 = n; flush(): the cached count incl. bypass digits): capacity
+ * capacity_syms * table_log / 8 <= 8 bytes is its "Destination buffer is too small" error, a stream of capacity - 8
+ * whole bytes or more comes back EMPTY there (bitstream.h:192,245) and here (*out_len = 0). */
+int basic_tans_encode_host(const basic_tans_tables *t, const int32_t *symbols, const int32_t *indexes, int64_t n,
+                           const int32_t *ar_indexes, const int32_t *ar_off0, const int32_t *ar_off1,
+                           int64_t capacity_syms, uint8_t *out, int64_t out_capacity, int64_t *out_len, int64_t *coded_syms);
+int basic_tans_decode_host(const basic_tans_tables *t, const uint8_t *stream, int64_t stream_len, const int32_t *indexes,
+                           int64_t n, const int32_t *ar_indexes, const int32_t *ar_off0, const int32_t *ar_off1,
+                           int32_t *out_symbols);
+/* Batched device-pointer coder, one wavefront per stream (no AR remap).  Encoder: stream i goes LEFT-aligned into
+ * d_out_words[i * slot_words ..] (slot_words >= basic_tans_encode_bound_words(t, longest stream));
+ * d_out_info[2i] = its length in BITS incl. final state and end mark (-1 = slot overflow), d_out_info[2i+1] = symbols
+ * coded incl. bypass digits; bytes = ceil(bits / 8).  Decoder: stream i = d_bytes[d_byte_off[i] .. d_byte_off[i+1]);
+ * d_status[i] = 1 for an empty stream / missing end mark. */
+int64_t basic_tans_encode_bound_words(const basic_tans_tables *t, int64_t n);
+int basic_tans_encode_batch_dev(const basic_tans_tables *t, const int32_t *d_symbols, const int32_t *d_indexes,
+                                const int64_t *d_seg, int nstreams, uint32_t *d_out_words, int64_t slot_words,
+                                int64_t *d_out_info, void *hip_stream);
+int basic_tans_decode_batch_dev(const basic_tans_tables *t, const uint8_t *d_bytes, const int64_t *d_byte_off,
+                                const int32_t *d_indexes, const int64_t *d_seg, int nstreams, int32_t *d_out_symbols,
+                                int32_t *d_status, void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

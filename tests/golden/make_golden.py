@@ -678,8 +678,82 @@ def grouped():
     save("grouped_codec.npz", **out)
 
 
+def tans_kats():
+    """Known answers of the reference's compiled TansEncoder / TansDecoder (cbench/csrc/ans/tans.cpp in oracle/_ref):
+    bytes, decoded symbols, the error cases (too small an output budget -> ValueError; stream larger than its budget ->
+    b"") and two AR-remap cases."""
+    out, names = {}, []
+    rng = np.random.default_rng(4242)
+    cases = []
+    # (name, table_log, rows, max symbols, n, bypass, skewed counts)
+    for i, (L, nd, ns, n, byp, skew) in enumerate([(12, 8, 200, 3000, True, False), (11, 5, 40, 777, True, True), (10, 3, 9, 64, False, False),
+                                                   (12, 64, 64, 4096, True, True), (9, 2, 30, 2000, False, True), (12, 1, 2, 6, False, False),
+                                                   (12, 4, 17, 5, False, False), (5, 2, 8, 500, True, False), (11, 6, 120, 1500, False, True),
+                                                   (12, 3, 500, 900, True, True)]):
+        if skew:
+            freqs = np.maximum((rng.random((nd, ns)) ** 7 * 60000).astype(np.int64), 1)
+        else:
+            freqs = rng.integers(1, 1024, (nd, ns))
+        nsym = rng.integers(2, ns + 1, nd)
+        off = rng.integers(-6, 6, nd)
+        idx = rng.integers(0, nd, n)
+        if byp:
+            sym = off[idx] + rng.integers(-3, 1 << 30, n) % (nsym[idx] + 6)
+            sym[::11] = rng.integers(-70000, 70000, sym[::11].size)
+        else:
+            sym = off[idx] + rng.integers(0, 1 << 30, n) % nsym[idx]
+        cases.append((f"rand{i}", L, freqs, nsym, off, byp, sym, idx, None))
+    # incompressible input: the stream outgrows the reference's n * L / 8 budget and comes back empty
+    nd, ns, n, L = 2, 256, 400, 9
+    freqs = rng.integers(1, 1024, (nd, ns))
+    cases.append(("overflow", L, freqs, np.full(nd, ns), np.zeros(nd, np.int64), True, rng.integers(-5000, 5000, n), rng.integers(0, nd, n), None))
+    # AR remap, order 1 and 2 (ans_interface.cpp:75-137)
+    for order in (1, 2):
+        nd, ns, n, L = 4, 12, 800, 11
+        freqs = rng.integers(1, 500, (nd, ns))
+        tab = rng.integers(0, nd, (2, nd) + (ns + 1,) * order)
+        ai = rng.integers(0, 2, n)
+        aoff = np.stack([np.minimum(np.arange(n), 1 + k) for k in range(order)])
+        cases.append((f"ar{order}", L, freqs, np.full(nd, ns), np.zeros(nd, np.int64), False, rng.integers(0, ns, n), rng.integers(0, nd, n),
+                      (tab, np.ones((2, order, 1), np.int64), ai, aoff)))
+    for name, L, freqs, nsym, off, byp, sym, idx, ar in cases:
+        f, n_, o = (np.asarray(a).astype(np.int32) for a in (freqs, nsym, off))
+        s, ix = np.asarray(sym).astype(np.int32), np.asarray(idx).astype(np.int32)
+        print(f"  {name} ...", flush=True)
+        enc, dec = ref_ans.TansEncoder(L, 255, byp, 4), ref_ans.TansDecoder(L, 255, byp, 4)
+        rec = {f"{name}.freqs": f, f"{name}.nsym": n_, f"{name}.offsets": o, f"{name}.cfg": np.array([L, int(byp), 4]),
+               f"{name}.symbols": s, f"{name}.indexes": ix}
+        kw = {}
+        try:
+            enc.init_params(f, n_, o)
+            dec.init_params(f, n_, o)
+            if ar is not None:
+                tab, cfg, ai, aoff = (np.asarray(a).astype(np.int32) for a in ar)
+                enc.init_ar_params(tab, cfg)
+                dec.init_ar_params(tab, cfg)
+                kw = dict(ar_indexes=ai, ar_offsets=aoff)
+                rec.update({f"{name}.ar_table": tab, f"{name}.ar_cfg": cfg, f"{name}.ar_indexes": ai, f"{name}.ar_offsets": aoff})
+            data = enc.encode_with_indexes(s, ix, **kw)
+            rec[f"{name}.bytes"] = b2a(data)
+            rec[f"{name}.error"] = np.array(0)
+            if data:
+                back = dec.decode_with_indexes(data, ix, **kw)
+                rec[f"{name}.decoded"] = back.astype(np.int32)   # == symbols with bypass coding; clamped without it
+                if byp or ar is not None or name != "overflow":
+                    assert np.array_equal(back, s), name
+        except ValueError as e:
+            rec[f"{name}.bytes"] = np.zeros(0, np.uint8)
+            rec[f"{name}.error"] = np.array(1)
+            print(f"  {name}: reference raises ValueError({e})")
+        out.update(rec)
+        names.append(name)
+        print(f"  {name}: L={L} n={s.size} -> {rec[f'{name}.bytes'].size} bytes")
+    out["names"] = np.array(names)
+    save("tans_kat.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["rans", "tables", "topo", "mconv", "ar", "framing", "harness", "search", "arpgm", "arjoint", "codec", "grouped"]
-    fn = dict(rans=rans_kats, tables=gauss_tables, topo=topo_maps, mconv=masked_conv, ar=ar_coder, framing=framing, harness=harness, search=complexity_search, arpgm=ar_coder_pgm, arjoint=ar_coder_joint, codec=codec_graph, grouped=grouped)
+    which = sys.argv[1:] or ["rans", "tables", "topo", "mconv", "ar", "framing", "harness", "search", "arpgm", "arjoint", "codec", "grouped", "tans"]
+    fn = dict(rans=rans_kats, tables=gauss_tables, topo=topo_maps, mconv=masked_conv, ar=ar_coder, framing=framing, harness=harness, search=complexity_search, arpgm=ar_coder_pgm, arjoint=ar_coder_joint, codec=codec_graph, grouped=grouped, tans=tans_kats)
     for w in which:
         fn[w]()

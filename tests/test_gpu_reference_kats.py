@@ -130,3 +130,89 @@ def test_masked_conv_reference_outputs_on_hip():
         ref = torch.from_numpy(z[f"{k}.y"])
         err = float((out.cpu() - ref).abs().max())
         assert err <= 1e-4 * max(1.0, float(ref.abs().max())), (str(k), err)
+
+
+def test_tans_known_answers_on_hip():
+    """cbench.ans.TansEncoder / TansDecoder drop-ins (csrc/tans.hip) on the bytes of the reference's compiled classes:
+    10 random table sets (table_log 5..12, with / without bypass coding, skewed counts with rare symbols), the reference's
+    two budget rules (ValueError / empty result) and the order-1 / order-2 AR remap."""
+    from cbench_basic_amd import ans
+    import tans_cases
+    tans_cases.check_known_answers(ans)
+
+
+def test_tans_tables_and_random_streams_vs_oracle_on_hip():
+    from cbench_basic_amd import ans
+    from oracle import tans_oracle
+    import tans_cases
+    rng = np.random.default_rng(5)
+    coded = 0
+    for trial in range(40):
+        case = tans_cases.random_case(rng, trial)
+        L, freqs, nsym, off, byp, sym, idx = case
+        eo, bo, do = tans_cases.run(tans_oracle, case)
+        eh, bh, dh = tans_cases.run(ans, case)
+        assert (eo is None) == (eh is None) and bo == bh, trial
+        if bo:
+            coded += 1
+            assert np.array_equal(do, dh), trial
+        if eo is None and trial < 12:    # table level: every row of the device images == the oracle's tables
+            enc = ans.TansEncoder(L, 255, byp, 4)
+            enc.init_params(freqs, nsym, off)
+            for r in range(freqs.shape[0]):
+                t = tans_oracle.tables(freqs[r, : nsym[r]], L)
+                nxt, db, ds, dec = enc.get_table_row(r)
+                assert np.array_equal(nxt, t["next_state"]), (trial, r)
+                live = freqs[r, : nsym[r]] > 0
+                assert np.array_equal(db[: nsym[r]][live], t["delta_bits"][live]) and np.array_equal(ds[: nsym[r]][live], t["delta_state"][live])
+                assert np.array_equal(dec & 0xFFF, t["d_base"]) and np.array_equal((dec >> 12) & 0xF, t["d_bits"]) \
+                    and np.array_equal(dec >> 16, t["d_symbol"]), (trial, r)
+    assert coded >= 20
+
+
+def test_tans_batched_device_streams_on_hip():
+    """basic_tans_encode_batch_dev / decode_batch_dev: 37 ragged streams in one launch each == the one-stream drop-in."""
+    import ctypes
+    from cbench_basic_amd import _lib, ans
+    rng = np.random.default_rng(9)
+    L, nd, ns = 11, 6, 90
+    freqs = rng.integers(1, 1024, (nd, ns)).astype(np.int32)
+    nsym, off = np.full(nd, ns, np.int32), rng.integers(-4, 4, nd).astype(np.int32)
+    enc, dec = ans.TansEncoder(L, 255, True, 4), ans.TansDecoder(L, 255, True, 4)
+    enc.init_params(freqs, nsym, off)
+    dec.init_params(freqs, nsym, off)
+    lens = rng.integers(0, 700, 37)
+    lens[3] = 0
+    seg = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    n = int(seg[-1])
+    idx = rng.integers(0, nd, n).astype(np.int32)
+    sym = (off[idx] + rng.integers(-2, ns + 3, n)).astype(np.int32)
+    sym[::17] = rng.integers(-3000, 3000, sym[::17].size)
+    dev = torch.device("cuda")
+    d_sym, d_idx, d_seg = (torch.from_numpy(a).to(dev) for a in (sym, idx, seg))
+    lib = _lib.lib()
+    slot = int(lib.basic_tans_encode_bound_words(enc._tables, int(lens.max())))
+    d_words = torch.zeros(37 * slot, dtype=torch.int32, device=dev)
+    d_info = torch.zeros(37 * 2, dtype=torch.int64, device=dev)
+    _lib.check(lib.basic_tans_encode_batch_dev(enc._tables, d_sym.data_ptr(), d_idx.data_ptr(), d_seg.data_ptr(), 37, d_words.data_ptr(),
+                                               slot, d_info.data_ptr(), None))
+    torch.cuda.synchronize()
+    info = d_info.cpu().numpy().reshape(37, 2)
+    words = d_words.cpu().numpy().view(np.uint8).reshape(37, slot * 4)
+    streams = [words[i, : (info[i, 0] + 7) // 8].tobytes() for i in range(37)]
+    for i in (0, 3, 11, 36):
+        s, e = seg[i], seg[i + 1]
+        big = ans.TansEncoder(L, 255, True, 4)
+        big.init_params(freqs, nsym, off)
+        one, coded = big._encode(sym[s:e], idx[s:e], None, None, 1 << 40)   # no budget rule: the raw stream
+        assert streams[i] == one and coded == info[i, 1], i
+    blob = np.frombuffer(b"".join(streams), np.uint8)
+    boff = np.concatenate([[0], np.cumsum([len(b) for b in streams])]).astype(np.int64)
+    d_blob, d_boff = torch.from_numpy(blob.copy()).to(dev), torch.from_numpy(boff).to(dev)
+    d_out = torch.zeros(n, dtype=torch.int32, device=dev)
+    d_status = torch.full((37,), -1, dtype=torch.int32, device=dev)
+    _lib.check(lib.basic_tans_decode_batch_dev(dec._tables, d_blob.data_ptr(), d_boff.data_ptr(), d_idx.data_ptr(), d_seg.data_ptr(), 37,
+                                               d_out.data_ptr(), d_status.data_ptr(), None))
+    torch.cuda.synchronize()
+    assert (d_status.cpu().numpy() == 0).all()
+    assert np.array_equal(d_out.cpu().numpy(), sym)

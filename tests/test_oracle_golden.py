@@ -281,3 +281,30 @@ def test_codec_oracle_matches_reference_codec_graph():
             assert abs(ent["y"] - m["latent_node_entropy_coders/y/prior_entropy"]) <= 1e-4 * abs(ent["y"]) + 1e-3, (rec, ent, m)
             assert abs(ent["z"] - m["latent_node_entropy_coders/z/prior_entropy"]) <= 1e-4 * abs(ent["z"]) + 1e-3, (rec, ent, m)
             assert abs(ent["y"] + ent["z"] - m["prior_entropy"]) <= 1e-4 * m["prior_entropy"] + 1e-3, rec
+
+
+def test_tans_oracle_known_answers():
+    """oracle/tans_oracle.c against the bytes of the reference's compiled TansEncoder (tests/golden/tans_kat.npz)."""
+    from oracle import tans_oracle
+    import tans_cases
+    tans_cases.check_known_answers(tans_oracle)
+
+
+def test_tans_oracle_matches_reference_build_when_present(oracle):
+    """Random distributions / symbol streams: same bytes, same errors, same empty results as oracle/_ref's TansEncoder."""
+    from oracle import tans_oracle
+    import tans_cases
+    ans, _ = oracle.load_ref()
+    if ans is None:
+        pytest.skip("oracle/_ref not built")
+    rng = np.random.default_rng(11)
+    coded = 0
+    for trial in range(60):
+        case = tans_cases.random_case(rng, trial)
+        eo, bo, do = tans_cases.run(tans_oracle, case)
+        er, br, dr = tans_cases.run(ans, case)
+        assert (eo is None) == (er is None) and bo == br, trial
+        if br:
+            coded += 1
+            assert np.array_equal(do, dr), trial
+    assert coded >= 30
