@@ -165,6 +165,13 @@ class _GroupPlan:
         return self._pos_cache[key]
 
 
+class _Kernel:
+    """(weight, bias) standing in for a convolution module when the kernel comes with the call."""
+
+    def __init__(self, weight, bias):
+        self.weight, self.bias = weight, bias
+
+
 class GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(HotPathModule):
     accepts_buffer = True  # decode() reads the stream through the buffer protocol (bytes or memoryview)
 
@@ -173,8 +180,23 @@ class GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(HotPathModule):
                  use_param_merger=True, use_joint_ar_model_impl=False, param_merger_expand_bottleneck=False,
                  use_autoregressive_encode=True, use_bypass_coding=True, freq_precision=16, bypass_precision=4,
                  lower_bound_scale=0.11, quantizer_params=None, fixed_input_shape=None,
-                 force_input_prior_shape_aligned=True, batch_stream_mode="auto", topo_group_predictor=None, **kwargs):
+                 force_input_prior_shape_aligned=True, batch_stream_mode="auto", topo_group_predictor=None,
+                 pgm_include_dynamic_kernel=False, pgm_include_dynamic_kernel_full=False, pgm_dynamic_kernel_enable_tiling=False,
+                 pgm_dynamic_kernel_add_self=False, **kwargs):
         super().__init__()
+        # Dynamic-kernel PGMs (pgm_coder.py:996-1001,1314-1339,1941-1955): the pgm handed to encode / decode / forward is a
+        # tuple (topo groups, context-conv weight [1, 2C, C, k, k], bias [1, 2C]) -- the structure AND the kernel of the
+        # context model come with the call; with pgm_dynamic_kernel_add_self the module's own kernel is added to it.  The
+        # "full" variant (kernels for the merger layers too) leaves its kernels installed on the layers after the call in
+        # the reference (set_dynamic_kernel, :1947-1950) and the tiled variant is a per-position kernel (an unfold-matmul
+        # with a spatial axis, masked_conv.py:199-201): neither is offered.
+        if pgm_include_dynamic_kernel_full or pgm_dynamic_kernel_enable_tiling:
+            raise NotImplementedError("pgm_include_dynamic_kernel_full / pgm_dynamic_kernel_enable_tiling")
+        self.pgm_include_dynamic_kernel = bool(pgm_include_dynamic_kernel)
+        self.pgm_dynamic_kernel_add_self = bool(pgm_dynamic_kernel_add_self)
+        if self.pgm_include_dynamic_kernel and (topo_group_context_model is not None or use_joint_ar_model_impl):
+            raise NotImplementedError("dynamic kernels need the built-in context convolution")
+        self._dyn_layers = {}
         # use_joint_ar_model_impl (pgm_coder.py:1975-2070): raster-scan coding with a plain 1x1 entropy_parameters network
         # on cat(prior, ctx) and "chunk" parameters (scales, then means).  Raster order IS the scanline schedule, so the
         # coder runs on the same kernels: the layers are built from re-ordered views of the weights (_build_layers).
@@ -265,14 +287,17 @@ class GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(HotPathModule):
             self._layer_key = key
             self._graphs = {}
 
-    def _build_layers(self):
+    def _build_layers(self, ctx_kernel=None):
         """MaskedConvPlans of the context conv and the merger layers, with the activation that FOLLOWS a
-        layer fused into it."""
+        layer fused into it.  ctx_kernel = (weight, bias) replaces the context convolution's own parameters (dynamic-kernel
+        PGMs)."""
         G, C2 = self.channel_groups, self.out_channels
         L = dict()
         cm = self.topo_group_context_model
         if cm is None:
             cp = self.context_prediction
+            if ctx_kernel is not None:
+                cp = _Kernel(*ctx_kernel)
             L["ctx"] = K.MaskedConvPlan(cp.weight, cp.bias, G, G, False)
             if self.use_param_merger and self.use_joint_ar_model_impl:
                 e = self.entropy_parameters
@@ -321,6 +346,48 @@ class GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(HotPathModule):
                     L["dense"] = [(c.weight, c.bias, i + 1 < len(convs)) for i, c in enumerate(convs)]
         L["ctx_raw"] = (cp.weight, cp.bias)
         return L
+
+    def _split_dynamic_pgm(self, pgm):
+        """(topo-group part of the pgm, (weight, bias) of the context convolution or None) -- _preprocess_pgm,
+        pgm_coder.py:1300-1339."""
+        if not self.pgm_include_dynamic_kernel:
+            if isinstance(pgm, (tuple, list)):
+                raise ValueError("a (topo groups, kernel weight, kernel bias) pgm needs pgm_include_dynamic_kernel=True")
+            return pgm, None
+        if pgm is None:       # the reference then codes with its own kernel (:1302-1312)
+            return None, None
+        topo, w, b = pgm
+        cp = self.context_prediction
+        w, b = torch.as_tensor(w).detach().to(self.device, torch.float32), torch.as_tensor(b).detach().to(self.device, torch.float32)
+        if w.shape[0] != 1 or b.shape[0] != 1:
+            raise NotImplementedError("per-sample dynamic kernels")
+        if w.numel() != cp.weight.numel() or b.numel() != cp.bias.numel():
+            raise NotImplementedError("spatially varying dynamic kernels (a kernel per position)")
+        w, b = w.reshape(cp.weight.shape), b.reshape(cp.bias.shape)
+        if self.pgm_dynamic_kernel_add_self:
+            w, b = w + cp.weight.detach(), b + cp.bias.detach()
+        return topo, (w.contiguous(), b.contiguous())
+
+    def _enter_dynamic(self, kernel):
+        """Swaps in the layer plans built around a call's own context kernel; returns what _leave_dynamic restores.  The
+        plans are kept for the last few kernels seen (by content), so a kernel reused over many calls is packed once."""
+        self._ready()
+        if kernel is None:
+            return None
+        import zlib
+        key = (zlib.crc32(kernel[0].cpu().numpy().tobytes()), zlib.crc32(kernel[1].cpu().numpy().tobytes()), self._layer_key)
+        entry = self._dyn_layers.get(key)
+        if entry is None:
+            if len(self._dyn_layers) >= 4:
+                self._dyn_layers.pop(next(iter(self._dyn_layers)))
+            entry = self._dyn_layers[key] = (self._build_layers(ctx_kernel=kernel), {})
+        saved = (self._layers, self._graphs)
+        self._layers, self._graphs = entry
+        return saved
+
+    def _leave_dynamic(self, saved):
+        if saved is not None:
+            self._layers, self._graphs = saved
 
     def _topo_from_pgm(self, pgm, h, w) -> np.ndarray:
         """_preprocess_pgm in coding mode (pgm_coder.py:1340-1380, fast_mode=True): logits -> argmax over the last L
@@ -509,6 +576,30 @@ class GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(HotPathModule):
         return sym, idx, ws["ybuf"], plan
 
     def forward(self, input, prior=None, pgm=None, quantizer_params=None, **kwargs):
+        pgm, kernel = self._split_dynamic_pgm(pgm)
+        saved = self._enter_dynamic(kernel)
+        try:
+            return self._forward_impl(input, prior=prior, pgm=pgm, quantizer_params=quantizer_params, **kwargs)
+        finally:
+            self._leave_dynamic(saved)
+
+    def encode(self, input, *args, prior=None, pgm=None, quantizer_params=None, **kwargs) -> bytes:
+        pgm, kernel = self._split_dynamic_pgm(pgm)
+        saved = self._enter_dynamic(kernel)
+        try:
+            return self._encode_impl(input, *args, prior=prior, pgm=pgm, quantizer_params=quantizer_params, **kwargs)
+        finally:
+            self._leave_dynamic(saved)
+
+    def decode(self, byte_string: bytes, *args, prior=None, pgm=None, quantizer_params=None, **kwargs):
+        pgm, kernel = self._split_dynamic_pgm(pgm)
+        saved = self._enter_dynamic(kernel)
+        try:
+            return self._decode_impl(byte_string, *args, prior=prior, pgm=pgm, quantizer_params=quantizer_params, **kwargs)
+        finally:
+            self._leave_dynamic(saved)
+
+    def _forward_impl(self, input, prior=None, pgm=None, quantizer_params=None, **kwargs):
         """Eval-mode forward (pgm_coder.py:391-539): returns the dequantised latent round(y).  With
         ``self.estimate_rate = True`` it also evaluates the reference's rate estimate: ONE full-map pass of the
         context model on round(y) (:421-429), likelihood cdf(q+.5) - cdf(q-.5) under N(mu, max(sigma, 0.11)),
@@ -528,7 +619,7 @@ class GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(HotPathModule):
             self.update_cache("metric_dict", prior_entropy=nll.mean())
         return q
 
-    def encode(self, input, *args, prior=None, pgm=None, quantizer_params=None, **kwargs) -> bytes:
+    def _encode_impl(self, input, *args, prior=None, pgm=None, quantizer_params=None, **kwargs) -> bytes:
         self._ready()
         input = input.contiguous()
         prior = self._check_prior(input.shape, prior)
@@ -554,7 +645,7 @@ class GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(HotPathModule):
             head = struct.pack("B", len(spatial) + 1) + struct.pack("<H", B) + b"".join(struct.pack("<H", d) for d in spatial)
         return head + body
 
-    def decode(self, byte_string: bytes, *args, prior=None, pgm=None, quantizer_params=None, **kwargs):
+    def _decode_impl(self, byte_string: bytes, *args, prior=None, pgm=None, quantizer_params=None, **kwargs):
         self._ready()
         ptr = 0
         if self.fixed_input_shape is not None:

@@ -678,6 +678,68 @@ def grouped():
     save("grouped_codec.npz", **out)
 
 
+def ar_coder_dynamic():
+    """Dynamic-kernel PGMs (pgm_coder.py:996-1001,1314-1339,1941-1955): encode(..., pgm=(topo groups, context-conv weight
+    [1, 2C, C, k, k], bias [1, 2C])), with and without pgm_dynamic_kernel_add_self; forward() rate estimate with the same
+    pgm."""
+    def seeded(coder, seed):
+        names, shapes = [], []
+        torch.manual_seed(seed)
+        with torch.no_grad():
+            for name, p in coder.named_parameters():
+                p.copy_(torch.randn(p.shape) * (0.05 if p.dim() > 1 else 0.02))
+                names.append(name)
+                shapes.append(",".join(str(d) for d in p.shape))
+        return names, shapes
+
+    out, keys = {}, []
+    g = torch.Generator().manual_seed(99)
+    # (C, G, add_self, default method, (B, H, W), topo patch shape)
+    cases = [(16, 2, False, "none", (1, 4, 6), (4, 6)), (16, 1, True, "scanline", (1, 5, 5), (5, 5)),
+             (16, 2, True, "checkerboard", (2, 6, 6), (2, 2)), (16, 1, False, "none", (1, 4, 4), None)]
+    for i, (C, G, add_self, method, (B, H, W), patch) in enumerate(cases):
+        coder = GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(
+            in_channels=C, channel_groups=G, pgm_include_dynamic_kernel=True, pgm_dynamic_kernel_add_self=add_self,
+            default_topo_group_method=method).eval()
+        names, shapes = seeded(coder, 700 + i)
+        coder.update_state()
+        y = torch.randn(B, C, H, W, generator=g) * 3
+        prior = torch.randn(B, 2 * C, H, W, generator=g)
+        cp = coder.context_prediction
+        if patch is None:
+            pgm = None     # the coder then uses its own kernel and its default topo groups (:1302-1312)
+        else:
+            topo = torch.randint(0, 4, (1, G) + patch, generator=g)
+            pgm = (topo, torch.randn((1,) + tuple(cp.weight.shape), generator=g) * 0.05, torch.randn((1,) + tuple(cp.bias.shape), generator=g) * 0.02)
+        cap = {}
+        orig = coder.ans_encoder
+
+        class Spy:
+            def encode_with_indexes(self, data, indexes, **k):
+                cap["symbols"], cap["indexes"] = np.array(data), np.array(indexes)
+                return orig.encode_with_indexes(data, indexes, **k)
+        coder.ans_encoder = Spy()
+        with torch.no_grad():
+            data = coder.encode(y, prior=prior, pgm=pgm)
+            yhat = coder.decode(data, prior=prior, pgm=pgm)
+            coder(y, prior=prior, pgm=pgm)
+            pe = float(coder.get_raw_cache("metric_dict")["prior_entropy"])
+        assert float((yhat - y).abs().max()) <= 0.5 + 1e-5
+        k = f"d{i}"
+        out.update({f"{k}.pnames": np.array(names), f"{k}.pshapes": np.array(shapes),
+                    f"{k}.wsum": np.array([float(sum(p.double().sum() for p in coder.parameters()))]),
+                    f"{k}.cfg": np.array([C, G, int(add_self), B, H, W, int(pgm is None)]), f"{k}.method": np.array(method),
+                    f"{k}.seed": np.array(700 + i), f"{k}.y": y.numpy(), f"{k}.prior": prior.numpy(), f"{k}.bytes": b2a(data),
+                    f"{k}.symbols": cap["symbols"].astype(np.int32), f"{k}.indexes": cap["indexes"].astype(np.int32),
+                    f"{k}.yhat": yhat.numpy(), f"{k}.prior_entropy": np.array(pe)})
+        if pgm is not None:
+            out.update({f"{k}.topo": pgm[0].numpy(), f"{k}.kernel_weight": pgm[1].numpy(), f"{k}.kernel_bias": pgm[2].numpy()})
+        keys.append(k)
+        print(f"  {k}: {len(data)} bytes, prior_entropy {pe:.2f}")
+    out["keys"] = np.array(keys)
+    save("ar_coder_dynamic.npz", **out)
+
+
 def tans_kats():
     """Known answers of the reference's compiled TansEncoder / TansDecoder (cbench/csrc/ans/tans.cpp in oracle/_ref):
     bytes, decoded symbols, the error cases (too small an output budget -> ValueError; stream larger than its budget ->
@@ -753,7 +815,7 @@ def tans_kats():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["rans", "tables", "topo", "mconv", "ar", "framing", "harness", "search", "arpgm", "arjoint", "codec", "grouped", "tans"]
-    fn = dict(rans=rans_kats, tables=gauss_tables, topo=topo_maps, mconv=masked_conv, ar=ar_coder, framing=framing, harness=harness, search=complexity_search, arpgm=ar_coder_pgm, arjoint=ar_coder_joint, codec=codec_graph, grouped=grouped, tans=tans_kats)
+    which = sys.argv[1:] or ["rans", "tables", "topo", "mconv", "ar", "framing", "harness", "search", "arpgm", "arjoint", "codec", "grouped", "tans", "ardyn"]
+    fn = dict(rans=rans_kats, tables=gauss_tables, topo=topo_maps, mconv=masked_conv, ar=ar_coder, framing=framing, harness=harness, search=complexity_search, arpgm=ar_coder_pgm, arjoint=ar_coder_joint, codec=codec_graph, grouped=grouped, tans=tans_kats, ardyn=ar_coder_dynamic)
     for w in which:
         fn[w]()

@@ -194,3 +194,39 @@ def test_joint_ar_impl_vs_reference_golden():
         assert torch.equal(yhat.cpu(), ybuf.cpu()), k
         yref = coder.decode(z[f"{k}.bytes"].tobytes(), prior=prior)
         assert float((yref.cpu() - torch.from_numpy(z[f"{k}.yhat"])).abs().max()) < 1e-3, k
+
+
+def test_dynamic_kernel_pgms_vs_reference_golden():
+    """encode / decode / forward(..., pgm=(topo groups, context-conv weight, bias)) with pgm_include_dynamic_kernel
+    (pgm_coder.py:996-1001,1314-1339,1941-1955), with and without pgm_dynamic_kernel_add_self, and pgm=None on such a
+    coder: the reference's integer streams, bytes, reconstruction and rate estimate."""
+    from cbench_basic_amd.modules.prior_model.prior_coder.pgm_coder import GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder as Coder
+    from test_oracle_golden import dynamic_case
+    z = load("ar_coder_dynamic.npz")
+    for k in z["keys"]:
+        sd, _, (C, G, add_self, B, H, W), topo = dynamic_case(z, k)
+        coder = Coder(in_channels=C, channel_groups=G, default_topo_group_method=str(z[f"{k}.method"]), batch_stream_mode="reference",
+                      pgm_include_dynamic_kernel=True, pgm_dynamic_kernel_add_self=bool(add_self)).eval()
+        missing, unexpected = coder.load_state_dict(sd, strict=False)
+        assert not unexpected and not [m for m in missing if not m.startswith("_") and m != "lower_bound_scale.bound"], (missing, unexpected)
+        coder = coder.cuda()
+        coder.update_state()
+        pgm = None if topo is None else (topo.cuda(), torch.from_numpy(z[f"{k}.kernel_weight"]).cuda(), torch.from_numpy(z[f"{k}.kernel_bias"]).cuda())
+        y, prior = torch.from_numpy(z[f"{k}.y"]).cuda(), torch.from_numpy(z[f"{k}.prior"]).cuda()
+        data = coder.encode(y, prior=prior, pgm=pgm)
+        assert data == z[f"{k}.bytes"].tobytes(), k
+        yhat = coder.decode(z[f"{k}.bytes"].tobytes(), prior=prior, pgm=pgm)
+        assert float((yhat.cpu() - torch.from_numpy(z[f"{k}.yhat"])).abs().max()) < 1e-3, k
+        coder.estimate_rate = True
+        coder(y, prior=prior, pgm=pgm)
+        got, ref = float(coder.get_raw_cache("metric_dict")["prior_entropy"]), float(z[f"{k}.prior_entropy"])
+        assert abs(got - ref) <= 2e-3 * abs(ref), (k, got, ref)
+        if pgm is not None:      # the kernel really is the call's: the coder's own kernel gives other bytes, and is back afterwards
+            assert coder.encode(y, prior=prior, pgm=None) != data
+            assert coder.encode(y, prior=prior, pgm=pgm) == data
+    with pytest.raises(NotImplementedError):
+        Coder(in_channels=16, pgm_include_dynamic_kernel=True, pgm_include_dynamic_kernel_full=True)
+    with pytest.raises(ValueError):
+        c = Coder(in_channels=16).eval().cuda()
+        c.update_state()
+        c.encode(torch.zeros(1, 16, 4, 4).cuda(), prior=torch.ones(1, 32, 4, 4).cuda(), pgm=(torch.zeros(1, 1, 4, 4), None, None))

@@ -308,3 +308,33 @@ def test_tans_oracle_matches_reference_build_when_present(oracle):
             coded += 1
             assert np.array_equal(do, dr), trial
     assert coded >= 30
+
+
+def dynamic_case(z, k):
+    """(state dict with the EFFECTIVE context kernel, cfg, topo or None) of a dynamic-kernel case: what the reference
+    computes with pgm = (topo, weight, bias) equals a coder whose context convolution holds weight (+ its own with
+    pgm_dynamic_kernel_add_self)."""
+    sd = pgm_case(z, k, int(z[f"{k}.seed"]))
+    C, G, add_self, B, H, W, no_pgm = (int(v) for v in z[f"{k}.cfg"])
+    eff = dict(sd)
+    topo = None
+    if not no_pgm:
+        w, b = torch.from_numpy(z[f"{k}.kernel_weight"])[0], torch.from_numpy(z[f"{k}.kernel_bias"])[0]
+        eff["context_prediction.weight"] = w + sd["context_prediction.weight"] if add_self else w
+        eff["context_prediction.bias"] = b + sd["context_prediction.bias"] if add_self else b
+        topo = torch.from_numpy(z[f"{k}.topo"])
+    return sd, eff, (C, G, add_self, B, H, W), topo
+
+
+def test_ar_coder_dynamic_kernel_pgms_match_reference():
+    """Dynamic-kernel PGMs (pgm_coder.py:1314-1339,1941-1955): the oracle with the call's kernel in place of the context
+    convolution's reproduces the reference's integer streams and bytes."""
+    from oracle.pgm_oracle import TopoGroupGaussianOracle
+    z = load("ar_coder_dynamic.npz")
+    for k in z["keys"]:
+        sd, eff, (C, G, add_self, B, H, W), topo = dynamic_case(z, k)
+        o = TopoGroupGaussianOracle(eff, C, G, str(z[f"{k}.method"]), pgm=topo)
+        y, prior = torch.from_numpy(z[f"{k}.y"]), torch.from_numpy(z[f"{k}.prior"])
+        data, sym, idx, buf = o.encode(y, prior)
+        assert np.array_equal(sym, z[f"{k}.symbols"]) and np.array_equal(idx, z[f"{k}.indexes"]), k
+        assert data == z[f"{k}.bytes"].tobytes(), k
