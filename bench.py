@@ -47,7 +47,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=256, help="images per GPU per step (weak scaling)")
     ap.add_argument("--total", type=int, default=256, help="images per step over ALL GPUs in the strong-scaling leg (cfg-5)")
     ap.add_argument("--size", type=int, default=256)
-    ap.add_argument("--workers", type=int, default=3, help="concurrent stream workers per GPU (1 = plain sequential calls)")
+    ap.add_argument("--workers", type=int, default=None,
+                    help="concurrent stream workers per GPU (1 = plain sequential calls); default 3 for the headline, 4 for --workload checkerboard, "
+                         "always 1 for --workload basic")
     ap.add_argument("--shard-by", default="steps", choices=["steps", "images"],
                     help="how the K steps are spread over the workers: steps = every worker codes WHOLE batches, step k on worker k mod W "
                          "(W batches in flight; the reference's pool also hands whole dataset items to its workers); "
@@ -218,6 +220,10 @@ def masked_conv_flops(plan_cin, plan_cout, k, topo_in, topo_out, allow_same, pos
 def run_ar_workload(args):
     """Extra bench lines for the AR parity configurations: one codec, one stream (module path), HIP-event time of every
     masked-convolution launch of one measured encode + decode pass for the roofline of masked_conv_pos_kernel."""
+    workers = 1 if args.workload == "basic" else max(1, args.workers if args.workers is not None else 4)
+    if workers > 1:   # before HIP initialises: one hardware queue per stream; 8 image streams per rANS workgroup (CUs left to the others)
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+        os.environ.setdefault("BASIC_RANS_WPB", str(args.rans_waves if args.rans_waves > 0 else 8))
     import numpy as np
     import torch
     from cbench_basic_amd.nn import kernels as K
@@ -225,30 +231,46 @@ def run_ar_workload(args):
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
     if args.workload == "checkerboard":
-        codec, batch, name = topogroup_ar_codec("checkerboard"), args.batch, "topo-group AR codec, checkerboard + expand-bottleneck merger (lossy_latent_graph_topogroup)"
+        make, batch, name = (lambda: topogroup_ar_codec("checkerboard")), args.batch, "topo-group AR codec, checkerboard + expand-bottleneck merger (lossy_latent_graph_topogroup)"
     else:
-        codec, batch, name = basic_codec(), min(args.batch, 64), "BaSIC slimmable scan-line codec, complexity level 0 (lossy_latent_graph_scalable_ar_models)"
-    codec = seed_synthetic_weights(codec, seed=0).eval()
-    g = torch.Generator().manual_seed(1)
-    with torch.no_grad():
-        for n, p in codec.named_parameters():
-            if ".latent_node_entropy_coders.y." in n:
-                p.copy_(torch.randn(p.shape, generator=g) * (0.02 if p.dim() > 1 else 0.01))
-    cpu_state = {k: v.detach().cpu().clone() for k, v in codec.entropy_coder.state_dict().items()}
-    codec = codec.to(dev)
-    codec.update_state()
-    if args.workload == "basic":
-        codec.set_complex_level(0)
+        make, batch, name = basic_codec, min(args.batch, 64), "BaSIC slimmable scan-line codec, complexity level 0 (lossy_latent_graph_scalable_ar_models)"
+    cpu_state = {}
+
+    def make_codec():
+        codec = seed_synthetic_weights(make(), seed=0).eval()
+        g = torch.Generator().manual_seed(1)
+        with torch.no_grad():
+            for n, p in codec.named_parameters():
+                if ".latent_node_entropy_coders.y." in n:
+                    p.copy_(torch.randn(p.shape, generator=g) * (0.02 if p.dim() > 1 else 0.01))
+        if not cpu_state:
+            cpu_state.update({k: v.detach().cpu().clone() for k, v in codec.entropy_coder.state_dict().items()})
+        codec = codec.to(dev)
+        codec.update_state()
+        if args.workload == "basic":
+            codec.set_complex_level(0)
+        return codec
+    # Whole batches in flight on concurrent stream workers, as in the headline: one worker's rANS chains run beside another's
+    # convolutions.  The scan-line schedule replays HIP graphs, whose capture does not tolerate other threads' launches: one worker.
+    from cbench_basic_amd.benchmark.stream_workers import StreamWorkerPool
+    pool = StreamWorkerPool(make_codec, workers, dev)
+    codec = pool.codecs[0]
     x = torch.stack([image(i, args.size) for i in range(batch)]).to(dev)
-    for _ in range(args.warmup):
-        codec.decompress(codec.compress(x))
+
+    def loop(c, n):
+        out = None
+        for _ in range(n):
+            data = c.compress(x)
+            out = (data, c.decompress(data))
+        return out
+    counts = [len(range(w, args.steps, workers)) for w in range(workers)]
+    pool.map(lambda c, n: loop(c, max(1, -(-args.warmup // workers))), counts)
     torch.cuda.synchronize()
     t0 = time.time()
-    for _ in range(args.steps):
-        data = codec.compress(x)
-        xhat = codec.decompress(data)
+    data, xhat = pool.map(loop, counts)[0]
     torch.cuda.synchronize()
     dt = time.time() - t0
+    pool.close()
     pix = batch * args.size ** 2 * args.steps
     # ---- one instrumented pass (HIP graphs off): events around every masked-convolution launch, FLOPs from the masks
     yc = codec.entropy_coder.latent_node_entropy_coders["y"]
@@ -298,8 +320,9 @@ def run_ar_workload(args):
     mse = K2.mse_per_image(xhat, x)
     out = dict(metric="encode+decode Mpix/s", value=pix / dt / 1e6, unit="Mpix/s", n_gpus=1, steps=args.steps, warmup=args.warmup,
                ms_per_step=dt / args.steps * 1e3, higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
-               config=dict(workload=f"{name}, synthetic 3x{args.size}x{args.size} images, {batch} images per step resident in HBM, one stream",
-                           images_per_gpu=batch, bpp=len(data) * 8 / (batch * args.size ** 2), psnr_db=float((-10 * torch.log10(mse.double())).mean())),
+               config=dict(workload=f"{name}, synthetic 3x{args.size}x{args.size} images, {batch} images per step resident in HBM, "
+                                        + (f"{workers} concurrent stream workers (step k on worker k mod W: whole batches in flight)" if workers > 1 else "one stream"),
+                           images_per_gpu=batch, workers=workers, bpp=len(data) * 8 / (batch * args.size ** 2), psnr_db=float((-10 * torch.log10(mse.double())).mean())),
                roofline=dict(bound="mfma", achieved=ach, peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_FP32_MFMA_TFLOPS, traffic=None,
                              kernel="masked_conv_pos_kernel (+ masked_conv_reduce_kernel): the masked-convolution launches of one encode + decode pass "
                                     "of the y-coder (context convolution + merger layers at the coded positions), HIP events per launch",
@@ -343,7 +366,7 @@ def main():
                          f"(or run `python bench.py --gpus {args.gpus}` without a launcher)")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    workers = max(1, args.workers)
+    workers = max(1, args.workers if args.workers is not None else 3)
     if workers > 1:  # one hardware queue per worker stream (+ its entropy side stream); HIP's default 4 make streams share
         os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
