@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--workers", type=int, default=None,
                     help="concurrent stream workers per GPU (1 = plain sequential calls); default 3 for the headline, 4 for --workload checkerboard, "
-                         "always 1 for --workload basic")
+                         "3 for --workload basic")
     ap.add_argument("--shard-by", default="steps", choices=["steps", "images"],
                     help="how the K steps are spread over the workers: steps = every worker codes WHOLE batches, step k on worker k mod W "
                          "(W batches in flight; the reference's pool also hands whole dataset items to its workers); "
@@ -220,7 +220,9 @@ def masked_conv_flops(plan_cin, plan_cout, k, topo_in, topo_out, allow_same, pos
 def run_ar_workload(args):
     """Extra bench lines for the AR parity configurations: one codec, one stream (module path), HIP-event time of every
     masked-convolution launch of one measured encode + decode pass for the roofline of masked_conv_pos_kernel."""
-    workers = 1 if args.workload == "basic" else max(1, args.workers if args.workers is not None else 4)
+    # measured (profiles/r02_ar_codecs.txt): checkerboard 359 / 385 / 430 / 451 / 454 Mpix/s with 1 / 2 / 3 / 4 / 5 workers; scan-line
+    # BaSIC 61 / 92 / 109 / 62 with 1 / 2 / 3 / 4 (four graph-replaying streams fall back to the one-stream rate)
+    workers = max(1, args.workers if args.workers is not None else (4 if args.workload == "checkerboard" else 3))
     if workers > 1:   # before HIP initialises: one hardware queue per stream; 8 image streams per rANS workgroup (CUs left to the others)
         os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
         os.environ.setdefault("BASIC_RANS_WPB", str(args.rans_waves if args.rans_waves > 0 else 8))
@@ -251,7 +253,7 @@ def run_ar_workload(args):
             codec.set_complex_level(0)
         return codec
     # Whole batches in flight on concurrent stream workers, as in the headline: one worker's rANS chains run beside another's
-    # convolutions.  The scan-line schedule replays HIP graphs, whose capture does not tolerate other threads' launches: one worker.
+    # convolutions; the scan-line schedule's launch-bound step sequences (HIP graphs) of several workers interleave on the chip.
     from cbench_basic_amd.benchmark.stream_workers import StreamWorkerPool
     pool = StreamWorkerPool(make_codec, workers, dev)
     codec = pool.codecs[0]
@@ -264,6 +266,11 @@ def run_ar_workload(args):
             out = (data, c.decompress(data))
         return out
     counts = [len(range(w, args.steps, workers)) for w in range(workers)]
+    if workers > 1:   # HIP-graph capture does not tolerate other threads' launches: first call of every replica alone
+        for c, st in zip(pool.codecs, pool.streams):
+            with torch.cuda.stream(st):
+                loop(c, 1)
+            torch.cuda.synchronize()
     pool.map(lambda c, n: loop(c, max(1, -(-args.warmup // workers))), counts)
     torch.cuda.synchronize()
     t0 = time.time()
