@@ -170,7 +170,12 @@ __global__ void gauss_nll_per_image_kernel(const float *__restrict__ q, const fl
             const float *pp = scales_or_params + static_cast<int64_t>(img) * 2 * elems + (2 * c) * hw + pos;
             const float mu = pp[0], s = fmaxf(pp[hw], bound_s);
             const float r = 0.70710678118654752440f / s;  // 1 / (s sqrt2) as torch: (x - mu) * s.reciprocal() / sqrt2
-            p = 0.5f * (1.f + erff((pq[i] + 0.5f - mu) * r)) - 0.5f * (1.f + erff((pq[i] - 0.5f - mu) * r));
+            if (MODE == 2) {   // likelihood of the ROUNDED RESIDUAL under the zero-mean density (pgm_coder.py:376-387)
+                const float v = rintf(pq[i] - mu);
+                p = 0.5f * (1.f + erff((v + 0.5f) * r)) - 0.5f * (1.f + erff((v - 0.5f) * r));
+            } else {
+                p = 0.5f * (1.f + erff((pq[i] + 0.5f - mu) * r)) - 0.5f * (1.f + erff((pq[i] - 0.5f - mu) * r));
+            }
         }
         acc += -logf(fmaxf(p, bound_p));
     }
@@ -336,7 +341,10 @@ extern "C" int basic_gauss_nll_per_image_dev(const float *d_q, const float *d_sc
 {
     BASIC_REQUIRE(d_q && d_scales_or_params && d_nll && batch >= 1 && channels >= 1 && hw >= 1, "gauss_nll_per_image: bad argument");
     const int64_t elems = static_cast<int64_t>(channels) * hw;
-    if (interleaved_mean_scale)
+    if (interleaved_mean_scale == 2)
+        hipLaunchKernelGGL(gauss_nll_per_image_kernel<2>, dim3(batch), dim3(kBlock), 0, as_stream(hip_stream), d_q, d_scales_or_params,
+                           elems, hw, scale_bound, likelihood_bound, d_nll);
+    else if (interleaved_mean_scale)
         hipLaunchKernelGGL(gauss_nll_per_image_kernel<1>, dim3(batch), dim3(kBlock), 0, as_stream(hip_stream), d_q, d_scales_or_params,
                            elems, hw, scale_bound, likelihood_bound, d_nll);
     else

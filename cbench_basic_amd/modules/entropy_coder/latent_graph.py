@@ -124,6 +124,7 @@ class LatentGraphicalANSEntropyCoder(HotPathModule, VariableRateCodecInterface, 
                  complexity_level_greedy_search_add_controller_nodes_as_complexity_metric=True,
                  complexity_level_controller_nodes=(),
                  complexity_level_greedy_search_custom_params: Optional[List[Dict[str, int]]] = None,
+                 complexity_level_greedy_search_loss_mode="eval",
                  task_names: Optional[List[str]] = None,
                  **kwargs):
         super().__init__()
@@ -181,6 +182,11 @@ class LatentGraphicalANSEntropyCoder(HotPathModule, VariableRateCodecInterface, 
         self.complexity_level_greedy_search_iterative = complexity_level_greedy_search_iterative
         self.complexity_level_greedy_search_custom_constraint = complexity_level_greedy_search_custom_constraint
         self.complexity_level_greedy_search_custom_params = complexity_level_greedy_search_custom_params
+        # "eval": the loss on the rounded latents the codec codes (deterministic, the default here); "train": the reference's
+        # own evaluation (latent_graph.py:1322 self.train()): additive-uniform-noise proxies in every coder, a random variable
+        if complexity_level_greedy_search_loss_mode not in ("eval", "train"):
+            raise ValueError("complexity_level_greedy_search_loss_mode: 'eval' or 'train'")
+        self.complexity_level_greedy_search_loss_mode = complexity_level_greedy_search_loss_mode
         self.complexity_level_greedy_search_complexity_metric = complexity_level_greedy_search_complexity_metric
         self.complexity_level_greedy_search_performance_metric = complexity_level_greedy_search_performance_metric
         if complexity_level_greedy_search:
@@ -522,15 +528,17 @@ class LatentGraphicalANSEntropyCoder(HotPathModule, VariableRateCodecInterface, 
         return total
 
     def _test_dataset_complexity_performance(self, dataset, *args, performance_method="loss", complexity_method="FLOPs",
-                                             **node_params):
+                                             loss_mode=None, **node_params):
         """(complexity, performance) of one controller setting over a dataset, both divided by the number of input
         elements (latent_graph.py:1320-1395).
 
         performance "loss" = the rate and distortion loss terms: loss_rate = prior_entropy / ln 2 of every coded node
         (bits per image; compressai_coder.py:213-215, pgm_coder.py:516) + loss_distortion = lambda_rd * SSE per image
         (:83-88).  The reference evaluates them in train mode, i.e. with its additive-uniform-noise proxies, so its
-        number is a random variable; here they are evaluated on the ROUNDED latents the codec actually codes
-        (eval-mode forward), which is deterministic.  complexity "FLOPs" = get_current_flops(); the timing variants
+        number is a random variable (loss_mode "train": every coder's forward adds U(-.5, .5) instead of rounding --
+        torch_ans.py:127-136 and upstream quantize(..., "noise") -- drawn from torch's CUDA generator); the default
+        (loss_mode "eval", or complexity_level_greedy_search_loss_mode) evaluates them on the ROUNDED latents the codec
+        actually codes, which is deterministic.  complexity "FLOPs" = get_current_flops(); the timing variants
         ("compress_time", "decompress_time", "total_time") wall-clock encode / decode."""
         if performance_method != "loss":
             raise NotImplementedError(performance_method)
@@ -538,6 +546,10 @@ class LatentGraphicalANSEntropyCoder(HotPathModule, VariableRateCodecInterface, 
         saved = [c.estimate_rate for c in coders]
         for c in coders:
             c.estimate_rate = True
+        loss_mode = loss_mode or self.complexity_level_greedy_search_loss_mode
+        proxied = [m for c in self.latent_node_entropy_coders.values() if isinstance(c, nn.Module) for m in c.modules()]
+        for m in proxied:
+            m.rate_proxy = "noise" if loss_mode == "train" else "round"
         performance, complexity, total_dims = 0.0, 0.0, 0
         searching, self._searching = self._searching, True
         try:
@@ -571,6 +583,8 @@ class LatentGraphicalANSEntropyCoder(HotPathModule, VariableRateCodecInterface, 
                 self.reset_all_cache()
         finally:
             self._searching = searching
+            for m in proxied:
+                m.rate_proxy = "round"
             for c, v in zip(coders, saved):
                 c.estimate_rate = v
         if total_dims == 0:

@@ -217,7 +217,10 @@ class CompressAIEntropyBottleneckPriorCoder(HotPathModule):
         self._ready()
         if channel_gains is not None:
             input = input * channel_gains.reshape(1, -1, 1, 1)
-        _, _, zhat = K.eb_quantize_index(input, self._medians_dev)
+        if getattr(self, "rate_proxy", "round") == "noise":   # upstream quantize(..., "noise"): the train-mode proxy
+            zhat = input + (torch.rand_like(input) - 0.5)
+        else:
+            _, _, zhat = K.eb_quantize_index(input, self._medians_dev)
         if getattr(self, "_coef_dev", None) is None or self._coef_dev.device != self.device:
             self._coef_dev = self.entropy_bottleneck.likelihood_coefficients().to(self.device)
         self.update_cache("metric_dict", prior_entropy=K.eb_nll_per_image(zhat, self._coef_dev, 1e-9).mean())
@@ -332,7 +335,10 @@ class CompressAIGaussianConditionalCoder(HotPathModule):
         if channel_gains is not None:
             y = y * channel_gains.reshape(1, -1, 1, 1)
         scales = self._crop(prior, *y.shape[-2:])
-        _, _, yhat = K.gc_quantize_index(y, scales, self._scale_table_dev, self.scale_bound)
+        if getattr(self, "rate_proxy", "round") == "noise":   # upstream quantize(..., "noise"): the train-mode proxy
+            yhat = y + (torch.rand_like(y) - 0.5)
+        else:
+            _, _, yhat = K.gc_quantize_index(y, scales, self._scale_table_dev, self.scale_bound)
         self.update_cache("metric_dict", prior_entropy=K.gauss_nll_per_image(yhat, scales, False, self.scale_bound, 1e-9).mean())
         if channel_gains_inv is not None:
             yhat = yhat * channel_gains_inv.reshape(1, -1, 1, 1)

@@ -182,8 +182,16 @@ class GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(HotPathModule):
                  lower_bound_scale=0.11, quantizer_params=None, fixed_input_shape=None,
                  force_input_prior_shape_aligned=True, batch_stream_mode="auto", topo_group_predictor=None,
                  pgm_include_dynamic_kernel=False, pgm_include_dynamic_kernel_full=False, pgm_dynamic_kernel_enable_tiling=False,
-                 pgm_dynamic_kernel_add_self=False, **kwargs):
+                 pgm_dynamic_kernel_add_self=False, training_no_quantize_for_likelihood=False, **kwargs):
         super().__init__()
+        # pgm_coder.py:225,376-387,413-416: the rate estimate is taken on the residual y - mu under the zero-mean density
+        # (eval: round(y - mu); train-mode proxy: y - mu + fresh uniform noise) instead of on the quantised latent.  The
+        # BaSIC presets set it (lossy_latent_graph_scalable_ar_models.py:121,261-330).
+        self.training_no_quantize_for_likelihood = bool(training_no_quantize_for_likelihood)
+        # "round" = the eval-mode forward (the latents the codec really codes); "noise" = the reference's TRAIN-mode proxies
+        # (additive uniform noise, torch_ans.py:127-136), set by the complexity search when it is asked for the reference's
+        # loss (latent_graph.py:1322, complexity_level_greedy_search_loss_mode="train")
+        self.rate_proxy = "round"
         # Dynamic-kernel PGMs (pgm_coder.py:996-1001,1314-1339,1941-1955): the pgm handed to encode / decode / forward is a
         # tuple (topo groups, context-conv weight [1, 2C, C, k, k], bias [1, 2C]) -- the structure AND the kernel of the
         # context model come with the call; with pgm_dynamic_kernel_add_self the module's own kernel is added to it.  The
@@ -607,7 +615,8 @@ class GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(HotPathModule):
         self._ready()
         input = input.contiguous()
         prior = self._check_prior(input.shape, prior)
-        q = torch.round(input)
+        noise = getattr(self, "rate_proxy", "round") == "noise"
+        q = input + (torch.rand_like(input) - 0.5) if noise else torch.round(input)
         if getattr(self, "estimate_rate", False):
             B, C, H, W = input.shape
             plan = self._plan(H, W, pgm)   # logits are taken at their argmax here too (the coding-mode groups)
@@ -615,7 +624,12 @@ class GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(HotPathModule):
             ws["ybuf"] = q
             allpos = torch.arange(B * H * W, device=self.device, dtype=torch.int32)
             params = self._context_at(ws, plan, allpos, prior)
-            nll = K.gauss_nll_per_image(q, params, True, self._lower_bound_scale, self.eps)
+            if self.training_no_quantize_for_likelihood:
+                # the residual: eval round(y - mu); train-mode proxy y - mu + a SECOND noise draw (pgm_coder.py:383)
+                v, mode = (input + (torch.rand_like(input) - 0.5), True) if noise else (input, "round_residual")
+            else:
+                v, mode = q, True
+            nll = K.gauss_nll_per_image(v, params, mode, self._lower_bound_scale, self.eps)
             self.update_cache("metric_dict", prior_entropy=nll.mean())
         return q
 

@@ -330,7 +330,8 @@ def gauss_nll_per_image(q, scales_or_params, interleaved, scale_bound=0.11, like
     B, C = q.shape[0], q.shape[1]
     hw = q.numel() // (B * C)
     out = torch.empty((B,), device=q.device, dtype=torch.float32)
-    _lib.check(_lib.lib().basic_gauss_nll_per_image_dev(q.data_ptr(), sp.data_ptr(), B, C, hw, int(bool(interleaved)), float(scale_bound),
+    mode = 2 if interleaved == "round_residual" else int(bool(interleaved))
+    _lib.check(_lib.lib().basic_gauss_nll_per_image_dev(q.data_ptr(), sp.data_ptr(), B, C, hw, mode, float(scale_bound),
                                                         float(likelihood_bound), out.data_ptr(), _stream()))
     return out
 

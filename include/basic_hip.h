@@ -170,7 +170,10 @@ int basic_pgm_gauss_scatter_group_dev(const int32_t *d_symbols, const float *d_p
  *   interleaved_mean_scale == 0: CompressAI GaussianConditional likelihood (call site compressai_coder.py:352-375),
  *       zero mean, d_scales_or_params = scales [B][C][HW];
  *   interleaved_mean_scale == 1: PGM coder likelihood (pgm_coder.py:374-389), d_scales_or_params = [B][2C][HW] with
- *       channel 2c = mean, 2c+1 = scale.  d_q = the quantised latent [B][C][HW]. */
+ *       channel 2c = mean, 2c+1 = scale.  d_q = the quantised latent [B][C][HW] (or, for the train-mode proxy, the latent
+ *       plus uniform noise);
+ *   interleaved_mean_scale == 2: the same parameters, likelihood of the ROUNDED RESIDUAL round(d_q - mean) under the zero-mean
+ *       density (training_no_quantize_for_likelihood in eval mode, pgm_coder.py:376-387); d_q = the UNQUANTISED latent. */
 int basic_gauss_nll_per_image_dev(const float *d_q, const float *d_scales_or_params, int batch, int channels, int hw,
                                   int interleaved_mean_scale, float scale_bound, float likelihood_bound, float *d_nll,
                                   void *hip_stream);

@@ -232,6 +232,12 @@ class EntropyBottleneck(EntropyModel):
     def _get_medians(self):
         return self.quantiles[:, :, 1:2]
 
+    def loss(self):
+        """Auxiliary loss of the published algorithm: the learned quantiles should sit where the cumulative's logits equal
+        (-target, 0, target).  Only the reference's train-mode forward reads it (compressai_coder.py:126-128,186-198)."""
+        logits = self._logits_cumulative(self.quantiles, stop_gradient=True)
+        return torch.abs(logits - self.target).sum()
+
     def _logits_cumulative(self, inputs, stop_gradient=True):
         logits = inputs
         for i in range(len(self.filters) + 1):

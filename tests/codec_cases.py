@@ -28,8 +28,9 @@ def basic_cfg(z):
                 levels=[dict(zip(ctl, (int(v) for v in row))) for row in z["b0.levels"]])
 
 
-def build_codec(z, k):
-    """This repository's codec for fixture case k ("t0".."t2", "b0"), weights by the recipe, on the CPU (no compute)."""
+def build_codec(z, k, y_extra=None, **graph_extra):
+    """This repository's codec for fixture case k ("t0".."t2", "b0"), weights by the recipe, on the CPU (no compute).
+    y_extra: more constructor arguments of the y-coder; graph_extra: of the latent graph (BaSIC case)."""
     from cbench_basic_amd.codecs.general_codec import GeneralCodec
     from cbench_basic_amd.modules.entropy_coder.latent_graph import LatentGraphicalANSEntropyCoder, LossyDummyEntropyCoder
     from cbench_basic_amd.modules.prior_model.prior_coder.compressai_coder import CompressAIEntropyBottleneckPriorCoder
@@ -67,7 +68,7 @@ def build_codec(z, k):
             latent_node_entropy_coder_dict=dict(
                 y=GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(
                     in_channels=M, default_topo_group_method="scanline", batch_stream_mode="reference",
-                    topo_group_context_model=TopoGroupDynamicMaskConv2dContextModel(in_channels=M, out_channels=2 * M)),
+                    topo_group_context_model=TopoGroupDynamicMaskConv2dContextModel(in_channels=M, out_channels=2 * M), **(y_extra or {})),
                 z=CompressAIEntropyBottleneckPriorCoder(entropy_bottleneck_channels=M, use_inner_aux_opt=True)),
             latent_inference_dict=dict(
                 x_y=P.HyperpriorAnalysisSlimmableConv2dPGMModel(in_channels=3, out_channels=M, mid_channels_list=Wd),
@@ -79,7 +80,7 @@ def build_codec(z, k):
             latent_generative_input_mapping=dict(y_x={"pgmyx": "pgm"}, z_y={"pgmzy": "pgm"}, y={"z": "prior"}),
             complexity_level_greedy_search=True, complexity_level_greedy_search_custom_params=c["levels"],
             complexity_level_greedy_search_custom_constraint=[float(i) for i in range(len(c["levels"]))],
-            complexity_level_controller_nodes=c["controllers"])
+            complexity_level_controller_nodes=c["controllers"], **graph_extra)
     codec = GeneralCodec(entropy_coder=ec).eval()
     if hasattr(ec, "_complexity_param_valid"):   # as after post_training_process / a loaded checkpoint (the fixture does the same)
         ec._complexity_param_valid.fill_(True)

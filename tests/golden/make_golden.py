@@ -6,6 +6,7 @@ Only data is written (inputs and expected outputs as .npz); no reference source 
 Run:  python tests/golden/make_golden.py     (needs /root/reference; never runs on the GPU box)
 """
 import hashlib
+import math
 import os
 import sys
 
@@ -485,6 +486,62 @@ def ar_coder_joint():
 from recipe import named_seed_weights, recipe_input  # noqa: E402  (tests/golden/recipe.py)
 
 
+def _basic_graph(y_extra=None):
+    """The tiny BaSIC slimmable graph of the codec_graph fixture (presets/lossy_latent_graph_scalable_ar_models.py:73-197):
+    (codec, entropy coder, levels, controller names, touched parameter list, calibration, widths, M)."""
+    from cbench.codecs.general_codec import GeneralCodec
+    from cbench.modules.entropy_coder.latent_graph import LatentGraphicalANSEntropyCoder
+    from cbench.modules.prior_model.prior_coder.compressai_coder import CompressAIEntropyBottleneckPriorCoder
+    from cbench.nn.layers import pgm_layers as P
+    from cbench.nn.layers.param_generator import IndexSelectParameterGeneratorWrapper, NNParameterGenerator
+    Wd, M = [4, 6, 8, 12, 16], 16
+    n = len(Wd)
+
+    def slim_node():
+        return IndexSelectParameterGeneratorWrapper(
+            batched_generator=NNParameterGenerator(shape=(n, 1, 1, n), init_method="value",
+                                                   init_value=torch.eye(n).flip(-1).unsqueeze(1).unsqueeze(1), fix_params=True),
+            fix_for_inference=True)
+    ctl = ["pgmxy", "pgmyz", "pgmzy", "pgmyx"]
+    levels = [dict(zip(ctl, t)) for t in [(0, 0, 0, 0), (1, 1, 1, 1), (2, 2, 2, 2), (3, 3, 3, 3), (4, 4, 4, 4), (0, 2, 1, 4), (3, 0, 4, 1), (2, 4, 0, 3)]]
+    ec = LatentGraphicalANSEntropyCoder(
+        node_generator_dict={c: slim_node() for c in ["pgmxy", "pgmyx", "pgmyz", "pgmzy"]},
+        use_lossy_compression=True, lossy_compression_lambda_rd=145.2225,
+        latent_node_inference_topo_order=["x", "y", "z"], latent_node_generative_topo_order=["z", "y", "x"],
+        latent_node_entropy_coder_dict=dict(
+            y=GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(
+                in_channels=M, default_topo_group_method="scanline",
+                topo_group_context_model=TopoGroupDynamicMaskConv2dContextModel(in_channels=M, out_channels=2 * M), **(y_extra or {})),
+            z=CompressAIEntropyBottleneckPriorCoder(entropy_bottleneck_channels=M, use_inner_aux_opt=True)),
+        latent_inference_dict=dict(
+            x_y=P.HyperpriorAnalysisSlimmableConv2dPGMModel(in_channels=3, out_channels=M, mid_channels_list=Wd),
+            y_z=P.MeanScaleHyperpriorHyperAnalysisSlimmableConv2dPGMModel(in_channels=M, out_channels=M, mid_channels_list=Wd)),
+        latent_generative_dict=dict(
+            z_y=P.MeanScaleHyperpriorHyperSynthesisSlimmableConv2dPGMModel(in_channels=M, out_channels=2 * M, mid_channels_list=Wd),
+            y_x=P.HyperpriorSynthesisSlimmableConv2dPGMModel(in_channels=M, out_channels=3, mid_channels_list=Wd)),
+        latent_inference_input_mapping=dict(x_y={"pgmxy": "pgm"}, y_z={"pgmyz": "pgm"}),
+        latent_generative_input_mapping=dict(y_x={"pgmyx": "pgm"}, z_y={"pgmzy": "pgm"}, y={"z": "prior"}),
+        complexity_level_greedy_search=True, complexity_level_greedy_search_custom_params=levels,
+        complexity_level_greedy_search_custom_constraint=[float(i) for i in range(len(levels))],
+        complexity_level_controller_nodes=ctl)
+    codec = GeneralCodec(entropy_coder=ec).eval()
+    def last_conv(mod, prefix, first=False):
+        names = [nm for nm, p_ in mod.named_parameters() if p_.dim() == 4]
+        return prefix + (names[0] if first else names[-1])
+    pre, gen = "entropy_coder.latent_inference_modules.", "entropy_coder.latent_generative_modules."
+    w_hs = last_conv(ec.latent_generative_modules["z_y"], gen + "z_y.")
+    calib = [(last_conv(ec.latent_inference_modules["x_y"], pre + "x_y."), 8.0, 0.0),
+             ("entropy_coder.latent_node_entropy_coders.y.topo_group_context_model.param_merger_out.3.bias", 1.0, 1.2),
+             (last_conv(ec.latent_inference_modules["y_z"], pre + "y_z."), 6.0, 0.0),
+             (w_hs[:-len("weight")] + "bias", 1.0, 1.2),
+             (last_conv(ec.latent_generative_modules["y_x"], gen + "y_x.", first=True), 0.05, 0.0)]
+    touched = named_seed_weights(codec, 790, calib)
+    with torch.no_grad():
+        ec._complexity_param_valid.fill_(True)   # as after post_training_process / a loaded checkpoint (latent_graph.py:673-675)
+    codec.update_state()
+    return codec, ec, levels, ctl, touched, calib, Wd, M
+
+
 def codec_graph():
     """The reference's GeneralCodec(entropy_coder=LatentGraphicalANSEntropyCoder(...)) (general_codec.py:44-130,
     latent_graph.py:306,1232-1295) run end to end on CPU at tiny channel counts:
@@ -578,51 +635,7 @@ def codec_graph():
         finish(k, codec, touched, seed, 800 + ci, calib)
 
     # ---- BaSIC slimmable graph
-    Wd, M = [4, 6, 8, 12, 16], 16
-    n = len(Wd)
-
-    def slim_node():
-        return IndexSelectParameterGeneratorWrapper(
-            batched_generator=NNParameterGenerator(shape=(n, 1, 1, n), init_method="value",
-                                                   init_value=torch.eye(n).flip(-1).unsqueeze(1).unsqueeze(1), fix_params=True),
-            fix_for_inference=True)
-    ctl = ["pgmxy", "pgmyz", "pgmzy", "pgmyx"]
-    levels = [dict(zip(ctl, t)) for t in [(0, 0, 0, 0), (1, 1, 1, 1), (2, 2, 2, 2), (3, 3, 3, 3), (4, 4, 4, 4), (0, 2, 1, 4), (3, 0, 4, 1), (2, 4, 0, 3)]]
-    ec = LatentGraphicalANSEntropyCoder(
-        node_generator_dict={c: slim_node() for c in ["pgmxy", "pgmyx", "pgmyz", "pgmzy"]},
-        use_lossy_compression=True, lossy_compression_lambda_rd=145.2225,
-        latent_node_inference_topo_order=["x", "y", "z"], latent_node_generative_topo_order=["z", "y", "x"],
-        latent_node_entropy_coder_dict=dict(
-            y=GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(
-                in_channels=M, default_topo_group_method="scanline",
-                topo_group_context_model=TopoGroupDynamicMaskConv2dContextModel(in_channels=M, out_channels=2 * M)),
-            z=CompressAIEntropyBottleneckPriorCoder(entropy_bottleneck_channels=M, use_inner_aux_opt=True)),
-        latent_inference_dict=dict(
-            x_y=P.HyperpriorAnalysisSlimmableConv2dPGMModel(in_channels=3, out_channels=M, mid_channels_list=Wd),
-            y_z=P.MeanScaleHyperpriorHyperAnalysisSlimmableConv2dPGMModel(in_channels=M, out_channels=M, mid_channels_list=Wd)),
-        latent_generative_dict=dict(
-            z_y=P.MeanScaleHyperpriorHyperSynthesisSlimmableConv2dPGMModel(in_channels=M, out_channels=2 * M, mid_channels_list=Wd),
-            y_x=P.HyperpriorSynthesisSlimmableConv2dPGMModel(in_channels=M, out_channels=3, mid_channels_list=Wd)),
-        latent_inference_input_mapping=dict(x_y={"pgmxy": "pgm"}, y_z={"pgmyz": "pgm"}),
-        latent_generative_input_mapping=dict(y_x={"pgmyx": "pgm"}, z_y={"pgmzy": "pgm"}, y={"z": "prior"}),
-        complexity_level_greedy_search=True, complexity_level_greedy_search_custom_params=levels,
-        complexity_level_greedy_search_custom_constraint=[float(i) for i in range(len(levels))],
-        complexity_level_controller_nodes=ctl)
-    codec = GeneralCodec(entropy_coder=ec).eval()
-    def last_conv(mod, prefix, first=False):
-        names = [nm for nm, p_ in mod.named_parameters() if p_.dim() == 4]
-        return prefix + (names[0] if first else names[-1])
-    pre, gen = "entropy_coder.latent_inference_modules.", "entropy_coder.latent_generative_modules."
-    w_hs = last_conv(ec.latent_generative_modules["z_y"], gen + "z_y.")
-    calib = [(last_conv(ec.latent_inference_modules["x_y"], pre + "x_y."), 8.0, 0.0),
-             ("entropy_coder.latent_node_entropy_coders.y.topo_group_context_model.param_merger_out.3.bias", 1.0, 1.2),
-             (last_conv(ec.latent_inference_modules["y_z"], pre + "y_z."), 6.0, 0.0),
-             (w_hs[:-len("weight")] + "bias", 1.0, 1.2),
-             (last_conv(ec.latent_generative_modules["y_x"], gen + "y_x.", first=True), 0.05, 0.0)]
-    touched = named_seed_weights(codec, 790, calib)
-    with torch.no_grad():
-        ec._complexity_param_valid.fill_(True)   # as after post_training_process / a loaded checkpoint (latent_graph.py:673-675)
-    codec.update_state()
+    codec, ec, levels, ctl, touched, calib, Wd, M = _basic_graph()
     log = []
     spy_y(ec.latent_node_entropy_coders["y"], log)
     x = recipe_input(890, (1, 3, 64, 64))
@@ -740,6 +753,90 @@ def ar_coder_dynamic():
     save("ar_coder_dynamic.npz", **out)
 
 
+def train_mode():
+    """The reference's TRAIN-mode evaluation (additive-uniform-noise proxies): a random variable, recorded as draws.
+      c0 / c1  PGM y-coder alone (scanline, context model), training_no_quantize_for_likelihood False / True: eval-mode
+               prior_entropy (deterministic) and 24 draws of the train-mode loss_rate (pgm_coder.py:391-520)
+      g.l*     the tiny BaSIC graph with the presets' training_no_quantize_for_likelihood=True y-coder: 16 draws of
+               _test_dataset_complexity_performance(performance_method="loss", complexity_method="FLOPs") at three
+               controller settings (latent_graph.py:1320-1395) and the eval-mode forward metrics at the same settings"""
+    import copy
+    import logging
+    logging.disable(logging.CRITICAL)
+    out = {}
+    g = torch.Generator().manual_seed(31)
+    for ci, flag in enumerate((False, True)):
+        C, B, H, W = 16, 2, 8, 8
+        coder = GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(
+            in_channels=C, default_topo_group_method="scanline", training_no_quantize_for_likelihood=flag,
+            topo_group_context_model=TopoGroupDynamicMaskConv2dContextModel(in_channels=C, out_channels=2 * C))
+        names, shapes = [], []
+        torch.manual_seed(900 + ci)
+        with torch.no_grad():
+            for name, p in coder.named_parameters():
+                p.copy_(torch.randn(p.shape) * (0.05 if p.dim() > 1 else 0.02))
+                names.append(name)
+                shapes.append(",".join(str(d) for d in p.shape))
+        coder.update_state()
+        y = torch.randn(B, C, H, W, generator=g) * 3
+        prior = torch.cat([torch.randn(B, C, H, W, generator=g), torch.rand(B, C, H, W, generator=g) * 4 + 0.2], 1)
+        prior = prior.reshape(B, 2, C, H, W).transpose(1, 2).reshape(B, 2 * C, H, W).contiguous()
+        coder.eval()
+        with torch.no_grad():
+            coder(y, prior=prior)
+            pe = float(coder.get_raw_cache("metric_dict")["prior_entropy"])
+        coder.reset_all_cache()
+        coder.train()
+        draws = []
+        for d in range(24):
+            torch.manual_seed(3000 + d)
+            with torch.no_grad():
+                coder(y, prior=prior)
+            draws.append(float(coder.get_raw_cache("loss_dict")["loss_rate"]))
+            coder.reset_all_cache()
+        k = f"c{ci}"
+        out.update({f"{k}.pnames": np.array(names), f"{k}.pshapes": np.array(shapes), f"{k}.seed": np.array(900 + ci),
+                    f"{k}.wsum": np.array([float(sum(p.double().sum() for p in coder.parameters()))]),
+                    f"{k}.flag": np.array(int(flag)), f"{k}.y": y.numpy(), f"{k}.prior": prior.numpy(),
+                    f"{k}.eval_prior_entropy": np.array(pe), f"{k}.train_loss_rate": np.array(draws)})
+        print(f"  {k}: eval prior_entropy {pe:.2f} nats ({pe / math.log(2):.2f} bits), train loss_rate {np.mean(draws):.2f} +- {np.std(draws):.2f} bits")
+
+    codec, ec, levels, ctl, touched, calib, Wd, M = _basic_graph(dict(training_no_quantize_for_likelihood=True))
+    x = recipe_input(890, (1, 3, 64, 64))
+    state = copy.deepcopy(codec.state_dict())
+    for li in (0, 4, 6):
+        lv = levels[li]
+        codec.eval()
+        codec.set_complex_level(li)
+        codec.reset_all_cache()
+        with torch.no_grad():
+            codec(x)
+        met = {n.split("metric_dict/entropy_coder/")[-1]: float(v) for n, v in codec.get_cache("metric_dict").items()}
+        codec.reset_all_cache()
+        vals = []
+        for d in range(16):
+            codec.load_state_dict(state)     # the z-coder's inner aux optimiser moves its quantiles in train mode (compressai_coder.py:186-190)
+            torch.manual_seed(5000 + 16 * li + d)
+            params = {name: ec.node_generators[name](lv[name]) for name in ctl}
+            c, p_ = ec._test_dataset_complexity_performance([x], performance_method="loss", complexity_method="FLOPs", **params)
+            vals.append((c, p_))
+        codec.load_state_dict(state)
+        vals = np.array(vals, np.float64)
+        out[f"g.l{li}.train"] = vals
+        out[f"g.l{li}.eval_metric_names"] = np.array(list(met))
+        out[f"g.l{li}.eval_metric_values"] = np.array(list(met.values()), np.float64)
+        print(f"  g.l{li}: complexity {vals[0, 0]:.4f} (spread {np.ptp(vals[:, 0]):.2e}), train loss {vals[:, 1].mean():.5f} +- {vals[:, 1].std():.5f}; "
+              f"eval prior_entropy {met.get('prior_entropy', float('nan')):.2f}")
+    out["g.levels"] = np.array([0, 4, 6])
+    out["g.pnames"] = np.array([n for n, _ in touched])
+    out["g.pshapes"] = np.array([s_ for _, s_ in touched])
+    out["g.calib_names"] = np.array([c[0] for c in calib])
+    out["g.calib_mul"] = np.array([c[1] for c in calib])
+    out["g.calib_add_odd"] = np.array([c[2] for c in calib])
+    logging.disable(logging.NOTSET)
+    save("train_mode.npz", **out)
+
+
 def tans_kats():
     """Known answers of the reference's compiled TansEncoder / TansDecoder (cbench/csrc/ans/tans.cpp in oracle/_ref):
     bytes, decoded symbols, the error cases (too small an output budget -> ValueError; stream larger than its budget ->
@@ -815,7 +912,7 @@ def tans_kats():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["rans", "tables", "topo", "mconv", "ar", "framing", "harness", "search", "arpgm", "arjoint", "codec", "grouped", "tans", "ardyn"]
-    fn = dict(rans=rans_kats, tables=gauss_tables, topo=topo_maps, mconv=masked_conv, ar=ar_coder, framing=framing, harness=harness, search=complexity_search, arpgm=ar_coder_pgm, arjoint=ar_coder_joint, codec=codec_graph, grouped=grouped, tans=tans_kats, ardyn=ar_coder_dynamic)
+    which = sys.argv[1:] or ["rans", "tables", "topo", "mconv", "ar", "framing", "harness", "search", "arpgm", "arjoint", "codec", "grouped", "tans", "ardyn", "train"]
+    fn = dict(rans=rans_kats, tables=gauss_tables, topo=topo_maps, mconv=masked_conv, ar=ar_coder, framing=framing, harness=harness, search=complexity_search, arpgm=ar_coder_pgm, arjoint=ar_coder_joint, codec=codec_graph, grouped=grouped, tans=tans_kats, ardyn=ar_coder_dynamic, train=train_mode)
     for w in which:
         fn[w]()
