@@ -76,8 +76,10 @@ def basic_codec(widths=BASIC_WIDTHS, M=192, num_complex_levels=8, search_dataset
     n = len(widths)
 
     def ar_coder(**kw):
+        # training_no_quantize_for_likelihood as in the reference preset (lossy_latent_graph_scalable_ar_models.py:121,261-330): the
+        # forward() rate estimate is taken on round(y - mu) under the zero-mean density (no effect on the coded bytes)
         return GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(
-            in_channels=M, topo_group_context_model=TopoGroupDynamicMaskConv2dContextModel(in_channels=M, out_channels=2 * M), **kw)
+            in_channels=M, training_no_quantize_for_likelihood=True, topo_group_context_model=TopoGroupDynamicMaskConv2dContextModel(in_channels=M, out_channels=2 * M), **kw)
 
     nodes = dict(pgmxy=None, pgmyx=None, pgmyz=None, pgmzy=None)
     controllers = ["pgmxy", "pgmyz", "pgmzy", "pgmyx"]
