@@ -217,13 +217,17 @@ class TopoGroupGaussianOracle:
         full = pgm.unsqueeze(2).repeat(B // pgm.shape[0], 1, C // pgm.shape[1], 1, 1).reshape(shape)
         return [(full == i) for i in range(int(pgm.max()) + 1)]
 
-    def forward_entropy(self, y, prior):
-        """Eval forward's rate estimate (pgm_coder.py:391-429,374-389,520-522): nats per image."""
+    def forward_entropy(self, y, prior, residual=False):
+        """Eval forward's rate estimate (pgm_coder.py:391-429,374-389,520-522): nats per image.  residual: the coder was
+        built with training_no_quantize_for_likelihood -- likelihood of round(y - mu) under the zero-mean density (:376-387)."""
         B, C, H, W = y.shape
         pgm = self._pgm(H, W)
         q = torch.round(y)
         mean, scale = self._split(self._params(q, pgm, prior))
-        dist = D.Normal(mean, torch.max(scale, torch.tensor([0.11])))
+        if residual:
+            dist, q = D.Normal(torch.zeros_like(mean), torch.max(scale, torch.tensor([0.11]))), torch.round(y - mean)
+        else:
+            dist = D.Normal(mean, torch.max(scale, torch.tensor([0.11])))
         lik = dist.cdf(q + 0.5) - dist.cdf(q - 0.5)
         return (-torch.log(torch.max(lik, torch.tensor([1e-7])))).sum() / B
 

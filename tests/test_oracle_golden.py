@@ -338,3 +338,14 @@ def test_ar_coder_dynamic_kernel_pgms_match_reference():
         data, sym, idx, buf = o.encode(y, prior)
         assert np.array_equal(sym, z[f"{k}.symbols"]) and np.array_equal(idx, z[f"{k}.indexes"]), k
         assert data == z[f"{k}.bytes"].tobytes(), k
+
+
+def test_oracle_residual_likelihood_matches_reference_eval_forward():
+    """training_no_quantize_for_likelihood coders: the eval-mode rate estimate is taken on round(y - mu) (pgm_coder.py:376-387)."""
+    from oracle.pgm_oracle import TopoGroupGaussianOracle
+    z = load("train_mode.npz")
+    for k in ("c0", "c1"):
+        sd = pgm_case(z, k, int(z[f"{k}.seed"]))
+        o = TopoGroupGaussianOracle(sd, 16, 1, "scanline", context_model=True)
+        got = float(o.forward_entropy(torch.from_numpy(z[f"{k}.y"]), torch.from_numpy(z[f"{k}.prior"]), residual=bool(int(z[f"{k}.flag"]))))
+        assert abs(got - float(z[f"{k}.eval_prior_entropy"])) <= 1e-4 * got, (k, got)
