@@ -215,8 +215,19 @@ class GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(HotPathModule):
             default_topo_group_method = "scanline"
         if not use_autoregressive_encode:
             raise NotImplementedError("use_autoregressive_encode=False")
-        if quantizer_params is not None and list(quantizer_params)[0::2] != [0.0, 1.0]:
-            raise NotImplementedError("non-identity uniform quantiser")
+        # Quantiser (torch_ans.py:16-50,105-121,163-178): "uniform" params [offset, -, step] -> y' = (y - offset) / step,
+        # "uniform_scale" params [step] -> y' = y / step.  With pgm_input_dequantized=False (the only mode offered, the
+        # reference's default) the whole coder -- context model, parameters, symbols -- lives in the y' domain and only the
+        # returned latent is mapped back (y' * step + offset), so the quantiser is an affine map around the coding path.
+        if kwargs.get("pgm_input_dequantized", False):
+            raise NotImplementedError("pgm_input_dequantized=True")
+        quantizer_type = kwargs.get("quantizer_type", "uniform")
+        if quantizer_type not in ("uniform", "uniform_scale"):
+            raise NotImplementedError(f"quantizer_type {quantizer_type}")
+        self.quantizer_type = quantizer_type
+        if quantizer_params is None:
+            quantizer_params = [0.0, float(1 << (kwargs.get("data_precision", 8) - 1)), 1.0] if quantizer_type == "uniform" else [1.0]
+        assert len(quantizer_params) == (3 if quantizer_type == "uniform" else 1)
         self.in_channels = in_channels
         self.channel_groups = channel_groups
         self.default_topo_group_method = default_topo_group_method
@@ -229,6 +240,8 @@ class GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(HotPathModule):
         self.lower_bound_scale = nn.Module()
         self.lower_bound_scale.register_buffer("bound", torch.Tensor([float(lower_bound_scale)]))
         self._lower_bound_scale = float(lower_bound_scale)
+        self.register_buffer("quantizer_params", torch.as_tensor(quantizer_params, dtype=torch.float32), persistent=False)
+        self._quantizer_host = tuple(float(v) for v in quantizer_params)   # read per call: no device round trip on the hot path
         self.fixed_input_shape = fixed_input_shape
         self.force_input_prior_shape_aligned = force_input_prior_shape_aligned
         self.batch_stream_mode = batch_stream_mode
@@ -583,27 +596,48 @@ class GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(HotPathModule):
                 K._stream()))
         return sym, idx, ws["ybuf"], plan
 
+    def _quantizer(self, quantizer_params):
+        """(offset, step) of this call, or None for the identity (torch_ans.py:105-121: a call's quantizer_params override
+        the module's)."""
+        qp = self._quantizer_host if quantizer_params is None else \
+            [float(v) for v in torch.as_tensor(quantizer_params, dtype=torch.float32).reshape(-1).tolist()]
+        off, step = (qp[0], qp[2]) if self.quantizer_type == "uniform" else (0.0, qp[0])
+        return None if (off == 0.0 and step == 1.0) else (off, step)
+
+    def _to_coding_domain(self, input, q):     # _data_preprocess(transform=True, quantize=False), same float32 operations
+        if q is None:
+            return input
+        return (input - q[0]) / q[1] if self.quantizer_type == "uniform" else input / q[1]
+
+    def _from_coding_domain(self, out, q):     # _data_postprocess
+        if q is None:
+            return out
+        return out * q[1] + q[0] if self.quantizer_type == "uniform" else out * q[1]
+
     def forward(self, input, prior=None, pgm=None, quantizer_params=None, **kwargs):
         pgm, kernel = self._split_dynamic_pgm(pgm)
+        q = self._quantizer(quantizer_params)
         saved = self._enter_dynamic(kernel)
         try:
-            return self._forward_impl(input, prior=prior, pgm=pgm, quantizer_params=quantizer_params, **kwargs)
+            return self._from_coding_domain(self._forward_impl(self._to_coding_domain(input, q), prior=prior, pgm=pgm, **kwargs), q)
         finally:
             self._leave_dynamic(saved)
 
     def encode(self, input, *args, prior=None, pgm=None, quantizer_params=None, **kwargs) -> bytes:
         pgm, kernel = self._split_dynamic_pgm(pgm)
+        q = self._quantizer(quantizer_params)
         saved = self._enter_dynamic(kernel)
         try:
-            return self._encode_impl(input, *args, prior=prior, pgm=pgm, quantizer_params=quantizer_params, **kwargs)
+            return self._encode_impl(self._to_coding_domain(input, q), *args, prior=prior, pgm=pgm, **kwargs)
         finally:
             self._leave_dynamic(saved)
 
     def decode(self, byte_string: bytes, *args, prior=None, pgm=None, quantizer_params=None, **kwargs):
         pgm, kernel = self._split_dynamic_pgm(pgm)
+        q = self._quantizer(quantizer_params)
         saved = self._enter_dynamic(kernel)
         try:
-            return self._decode_impl(byte_string, *args, prior=prior, pgm=pgm, quantizer_params=quantizer_params, **kwargs)
+            return self._from_coding_domain(self._decode_impl(byte_string, *args, prior=prior, pgm=pgm, **kwargs), q)
         finally:
             self._leave_dynamic(saved)
 

@@ -837,6 +837,61 @@ def train_mode():
     save("train_mode.npz", **out)
 
 
+def ar_coder_quant():
+    """Non-identity quantisers of the PGM y-coder (torch_ans.py:16-50,105-121,163-178): "uniform" [offset, -, step] at
+    construction and overridden per call, "uniform_scale" [step]: bytes, integers, decode() output, forward() output and
+    rate estimate."""
+    out, keys = {}, []
+    g = torch.Generator().manual_seed(55)
+    # (quantizer_type, ctor params, per-call params or None, method, G)
+    cases = [("uniform", [0.3, 128.0, 0.5], None, "checkerboard", 1), ("uniform", None, [-1.25, 128.0, 2.0], "scanline", 1),
+             ("uniform_scale", [0.75], None, "none", 2)]
+    for i, (qt, qp, call_qp, method, G) in enumerate(cases):
+        C, B, H, W = 16, 1, 6, 6
+        kw = dict(in_channels=C, channel_groups=G, default_topo_group_method=method, quantizer_type=qt)
+        if qp is not None:
+            kw["quantizer_params"] = qp
+        coder = GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(**kw).eval()
+        names, shapes = [], []
+        torch.manual_seed(600 + i)
+        with torch.no_grad():
+            for name, p in coder.named_parameters():
+                p.copy_(torch.randn(p.shape) * (0.05 if p.dim() > 1 else 0.02))
+                names.append(name)
+                shapes.append(",".join(str(d) for d in p.shape))
+        coder.update_state()
+        y = torch.randn(B, C, H, W, generator=g) * 3
+        prior = torch.cat([torch.randn(B, C, H, W, generator=g), torch.rand(B, C, H, W, generator=g) * 4 + 0.2], 1)
+        prior = prior.reshape(B, 2, C, H, W).transpose(1, 2).reshape(B, 2 * C, H, W).contiguous()
+        cap = {}
+        orig = coder.ans_encoder
+
+        class Spy:
+            def encode_with_indexes(self, data, indexes, **k):
+                cap["symbols"], cap["indexes"] = np.array(data), np.array(indexes)
+                return orig.encode_with_indexes(data, indexes, **k)
+        coder.ans_encoder = Spy()
+        cq = None if call_qp is None else torch.tensor(call_qp)
+        with torch.no_grad():
+            data = coder.encode(y, prior=prior, quantizer_params=cq)
+            yhat = coder.decode(data, prior=prior, quantizer_params=cq)
+            yfwd = coder(y, prior=prior, quantizer_params=cq)
+            pe = float(coder.get_raw_cache("metric_dict")["prior_entropy"])
+        k = f"q{i}"
+        out.update({f"{k}.pnames": np.array(names), f"{k}.pshapes": np.array(shapes), f"{k}.seed": np.array(600 + i),
+                    f"{k}.wsum": np.array([float(sum(p.double().sum() for p in coder.parameters()))]),
+                    f"{k}.qtype": np.array(qt), f"{k}.ctor_params": np.array(qp if qp is not None else [], np.float32),
+                    f"{k}.call_params": np.array(call_qp if call_qp is not None else [], np.float32),
+                    f"{k}.method": np.array(method), f"{k}.cfg": np.array([C, G, B, H, W]),
+                    f"{k}.y": y.numpy(), f"{k}.prior": prior.numpy(), f"{k}.bytes": b2a(data),
+                    f"{k}.symbols": cap["symbols"].astype(np.int32), f"{k}.indexes": cap["indexes"].astype(np.int32),
+                    f"{k}.yhat": yhat.numpy(), f"{k}.yfwd": yfwd.numpy(), f"{k}.prior_entropy": np.array(pe)})
+        keys.append(k)
+        print(f"  {k}: {qt} {qp} call {call_qp}: {len(data)} bytes, max|yhat - y| {float((yhat - y).abs().max()):.3f}, prior_entropy {pe:.2f}")
+    out["keys"] = np.array(keys)
+    save("ar_coder_quant.npz", **out)
+
+
 def tans_kats():
     """Known answers of the reference's compiled TansEncoder / TansDecoder (cbench/csrc/ans/tans.cpp in oracle/_ref):
     bytes, decoded symbols, the error cases (too small an output budget -> ValueError; stream larger than its budget ->
@@ -912,7 +967,7 @@ def tans_kats():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["rans", "tables", "topo", "mconv", "ar", "framing", "harness", "search", "arpgm", "arjoint", "codec", "grouped", "tans", "ardyn", "train"]
-    fn = dict(rans=rans_kats, tables=gauss_tables, topo=topo_maps, mconv=masked_conv, ar=ar_coder, framing=framing, harness=harness, search=complexity_search, arpgm=ar_coder_pgm, arjoint=ar_coder_joint, codec=codec_graph, grouped=grouped, tans=tans_kats, ardyn=ar_coder_dynamic, train=train_mode)
+    which = sys.argv[1:] or ["rans", "tables", "topo", "mconv", "ar", "framing", "harness", "search", "arpgm", "arjoint", "codec", "grouped", "tans", "ardyn", "train", "arquant"]
+    fn = dict(rans=rans_kats, tables=gauss_tables, topo=topo_maps, mconv=masked_conv, ar=ar_coder, framing=framing, harness=harness, search=complexity_search, arpgm=ar_coder_pgm, arjoint=ar_coder_joint, codec=codec_graph, grouped=grouped, tans=tans_kats, ardyn=ar_coder_dynamic, train=train_mode, arquant=ar_coder_quant)
     for w in which:
         fn[w]()

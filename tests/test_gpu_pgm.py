@@ -230,3 +230,38 @@ def test_dynamic_kernel_pgms_vs_reference_golden():
         c = Coder(in_channels=16).eval().cuda()
         c.update_state()
         c.encode(torch.zeros(1, 16, 4, 4).cuda(), prior=torch.ones(1, 32, 4, 4).cuda(), pgm=(torch.zeros(1, 1, 4, 4), None, None))
+
+
+def test_non_identity_quantisers_vs_reference_golden():
+    """quantizer_type "uniform" ([offset, -, step], at construction and per call) and "uniform_scale" ([step]),
+    torch_ans.py:16-50,105-121,163-178: the reference's bytes, integers, decode() and forward() outputs, rate estimate."""
+    from cbench_basic_amd.modules.prior_model.prior_coder.pgm_coder import GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder as Coder
+    from test_oracle_golden import quant_case
+    z = load("ar_coder_quant.npz")
+    for k in z["keys"]:
+        sd, qt, off, step = quant_case(z, k)
+        C, G, B, H, W = (int(v) for v in z[f"{k}.cfg"])
+        kw = dict(in_channels=C, channel_groups=G, default_topo_group_method=str(z[f"{k}.method"]), quantizer_type=qt, batch_stream_mode="reference")
+        if z[f"{k}.ctor_params"].size:
+            kw["quantizer_params"] = [float(v) for v in z[f"{k}.ctor_params"]]
+        coder = Coder(**kw).eval()
+        missing, unexpected = coder.load_state_dict(sd, strict=False)
+        assert not unexpected and not [m for m in missing if not m.startswith("_") and m != "lower_bound_scale.bound"], (missing, unexpected)
+        coder = coder.cuda()
+        coder.update_state()
+        cq = torch.from_numpy(z[f"{k}.call_params"]) if z[f"{k}.call_params"].size else None
+        y, prior = torch.from_numpy(z[f"{k}.y"]).cuda(), torch.from_numpy(z[f"{k}.prior"]).cuda()
+        data = coder.encode(y, prior=prior, quantizer_params=cq)
+        assert data == z[f"{k}.bytes"].tobytes(), k
+        yhat = coder.decode(z[f"{k}.bytes"].tobytes(), prior=prior, quantizer_params=cq)
+        assert float((yhat.cpu() - torch.from_numpy(z[f"{k}.yhat"])).abs().max()) < 1e-4, k
+        assert float((yhat.cpu() - y.cpu()).abs().max()) <= 0.5 * step + 1e-4
+        coder.estimate_rate = True
+        yf = coder(y, prior=prior, quantizer_params=cq)
+        assert float((yf.cpu() - torch.from_numpy(z[f"{k}.yfwd"])).abs().max()) < 1e-5, k
+        got, ref = float(coder.get_raw_cache("metric_dict")["prior_entropy"]), float(z[f"{k}.prior_entropy"])
+        assert abs(got - ref) <= 2e-3 * abs(ref), (k, got, ref)
+    with pytest.raises(NotImplementedError):
+        Coder(in_channels=16, pgm_input_dequantized=True)
+    with pytest.raises(NotImplementedError):
+        Coder(in_channels=16, quantizer_type="nonuniform")

@@ -349,3 +349,30 @@ def test_oracle_residual_likelihood_matches_reference_eval_forward():
         o = TopoGroupGaussianOracle(sd, 16, 1, "scanline", context_model=True)
         got = float(o.forward_entropy(torch.from_numpy(z[f"{k}.y"]), torch.from_numpy(z[f"{k}.prior"]), residual=bool(int(z[f"{k}.flag"]))))
         assert abs(got - float(z[f"{k}.eval_prior_entropy"])) <= 1e-4 * got, (k, got)
+
+
+def quant_case(z, k):
+    sd = pgm_case(z, k, int(z[f"{k}.seed"]))
+    qt = str(z[f"{k}.qtype"])
+    qp = z[f"{k}.call_params"] if z[f"{k}.call_params"].size else z[f"{k}.ctor_params"]
+    off, step = (float(qp[0]), float(qp[2])) if qt == "uniform" else (0.0, float(qp[0]))
+    return sd, qt, off, step
+
+
+def test_ar_coder_non_identity_quantisers_match_reference():
+    """torch_ans.py:105-121,163-178 with pgm_input_dequantized=False: the coder works on y' = (y - offset) / step and maps
+    the result back -- the oracle fed y' reproduces the reference's integers and bytes, its buffer * step + offset the
+    reference's decode()."""
+    from oracle.pgm_oracle import TopoGroupGaussianOracle
+    z = load("ar_coder_quant.npz")
+    for k in z["keys"]:
+        sd, qt, off, step = quant_case(z, k)
+        C, G, B, H, W = (int(v) for v in z[f"{k}.cfg"])
+        o = TopoGroupGaussianOracle(sd, C, G, str(z[f"{k}.method"]))
+        y, prior = torch.from_numpy(z[f"{k}.y"]), torch.from_numpy(z[f"{k}.prior"])
+        yp = (y - off) / step if qt == "uniform" else y / step
+        data, sym, idx, buf = o.encode(yp, prior)
+        assert np.array_equal(sym, z[f"{k}.symbols"]) and np.array_equal(idx, z[f"{k}.indexes"]), k
+        assert data == z[f"{k}.bytes"].tobytes(), k
+        back = buf * step + off if qt == "uniform" else buf * step
+        assert torch.allclose(back, torch.from_numpy(z[f"{k}.yhat"]), atol=1e-5), k
