@@ -7,7 +7,15 @@ Step metrics (basic_benchmark.py:121-260): ``original_length`` (bytes of the inp
 data), the distortion metric (``psnr``), and with ``nn_codec_use_forward_pass`` the ``*_nn_forward`` pair from
 ``codec.forward_estimate_bitlen``.  Level loop and key prefixes (``sclevel{c}_vrlevel{r}_<metric>``) follow
 :913-1026, including BD-rate over the rate levels when there are more than three of them.
+
+``num_testing_workers`` (:829-858): the reference hands contiguous index ranges of the dataloader to a multiprocessing pool --
+and switches the pool off when testing on a device (``force_testing_device is None`` is required, :836).  Here the workers are
+concurrent stream workers on the ONE GPU (stream_workers.py: host threads, each with its own HIP stream and its own replica of
+the codec built by ``codec_builder``), so dataset items are coded concurrently: one item's serial rANS chains and launch-bound
+AR steps run beside another item's transforms.  Per-item times are the latencies of the calls as they ran (concurrently);
+``time_wall_dataset`` / ``speed_wall_dataset`` give the wall time and MiB/s of the whole dataset pass.
 """
+import copy
 import csv
 import os
 import pickle
@@ -24,7 +32,8 @@ class BasicLosslessCompressionBenchmark:
     def __init__(self, codec, dataloader, *args, distortion_metric=None, skip_decompress=False,
                  nn_codec_use_forward_pass=False, nn_codec_forward_pass_skip_compression=False,
                  testing_variable_rate_levels=None, testing_variable_rate_bj_delta_metric=None,
-                 testing_complexity_levels=None, force_testing_device="cuda", output_dir=None, num_repeats=1, **kwargs):
+                 testing_complexity_levels=None, force_testing_device="cuda", output_dir=None, num_repeats=1,
+                 num_testing_workers=0, codec_builder=None, **kwargs):
         self.codec = codec
         self.dataloader = dataloader
         self.distortion_metric = distortion_metric
@@ -38,6 +47,12 @@ class BasicLosslessCompressionBenchmark:
         self.output_dir = output_dir
         self.num_repeats = num_repeats
         self.metric_logger = MetricLogger()
+        self.num_testing_workers = int(num_testing_workers or 0)
+        self.codec_builder = codec_builder
+        if self.num_testing_workers > 1 and codec_builder is None:
+            raise ValueError("num_testing_workers > 1 needs codec_builder: a callable returning a fresh codec of the same "
+                             "architecture (every worker codes with its own replica; weights and levels are copied from `codec`)")
+        self._pool = None
 
     # ---- files (base.py:41-52)
     @property
@@ -65,16 +80,17 @@ class BasicLosslessCompressionBenchmark:
         if torch.cuda.is_available():
             torch.cuda.synchronize()  # the device queue is empty before and after every timed region
 
-    def _run_step(self, step, data, metric_logger):
+    def _run_step(self, step, data, metric_logger, codec=None, distortion_metric=None):
+        codec = self.codec if codec is None else codec
         # the batch stays where the loader left it (the host): codec.compress() uploads it INSIDE the timed region, as the
         # reference's does (general_codec.py:46-47 under basic_benchmark.py:199-202); only the metric's target is moved
         data_input = data
         data_target = data.to(self.force_testing_device) if self.force_testing_device else data
         original_length = self._estimate_byte_length(data_input)
         metric_logger.update(original_length=original_length)
-        dm = self.distortion_metric
-        if self.nn_codec_use_forward_pass and hasattr(self.codec, "forward_estimate_bitlen"):
-            decompressed, compressed_length = self.codec.forward_estimate_bitlen(data_input)
+        dm = self.distortion_metric if distortion_metric is None else distortion_metric
+        if self.nn_codec_use_forward_pass and hasattr(codec, "forward_estimate_bitlen"):
+            decompressed, compressed_length = codec.forward_estimate_bitlen(data_input)
             compressed_length = float(compressed_length)
             metric_logger.update(compression_ratio_nn_forward=compressed_length / original_length,
                                  compressed_length_nn_forward=compressed_length)
@@ -84,7 +100,7 @@ class BasicLosslessCompressionBenchmark:
                 return
         self._sync()
         t0 = time.time()
-        compressed = self.codec.compress(data_input)
+        compressed = codec.compress(data_input)
         self._sync()
         time_compress = time.time() - t0
         compressed_length = self._estimate_byte_length(compressed)
@@ -93,7 +109,7 @@ class BasicLosslessCompressionBenchmark:
                              speed_compress=original_length / time_compress / 1024 / 1024)
         if not self.skip_decompress:
             t0 = time.time()
-            decompressed = self.codec.decompress(compressed)
+            decompressed = codec.decompress(compressed)
             self._sync()
             time_decompress = time.time() - t0
             metric_logger.update(time_decompress=time_decompress * 1000,
@@ -103,11 +119,79 @@ class BasicLosslessCompressionBenchmark:
             if dm is not None:
                 dm(decompressed, data_target)
 
+    def _worker_pool(self):
+        """The stream workers and their codec replicas, brought to the main codec's weights, levels and tables."""
+        from .stream_workers import StreamWorkerPool
+        if self._pool is None:
+            def make():
+                c = self.codec_builder()
+                if hasattr(c, "eval"):
+                    c.eval()
+                return c.to(self.force_testing_device or "cuda") if hasattr(c, "to") else c
+            self._pool = StreamWorkerPool(make, self.num_testing_workers, torch.device(self.force_testing_device or "cuda"))
+        for r in self._pool.codecs:
+            if hasattr(r, "load_state_dict"):
+                ec, rec = getattr(self.codec, "entropy_coder", None), getattr(r, "entropy_coder", None)
+                if ec is not None and hasattr(ec, "_complexity_param_all_levels"):   # searched levels: modules made after construction
+                    rec._complexity_param_all_levels = copy.deepcopy(ec._complexity_param_all_levels)
+                    rec._num_complex_levels = ec._num_complex_levels
+                r.load_state_dict(self.codec.state_dict(), strict=False)
+                if rec is not None and hasattr(rec, "_valid_host"):
+                    rec._valid_host = None
+            for name in ("_current_complex_level", "_current_rate_level", "_current_task_idx"):
+                for src, dst in ((self.codec, r), (getattr(self.codec, "entropy_coder", None), getattr(r, "entropy_coder", None))):
+                    if src is not None and dst is not None and hasattr(src, name):
+                        setattr(dst, name, getattr(src, name))
+            r.update_state()
+        return self._pool
+
     def _run_dataset(self):
         logger = MetricLogger()
-        for step, data in enumerate(self.dataloader):
-            self._run_step(step, data, logger)
-        return logger.get_global_average()
+        n_items, n_bytes = 0, 0
+        self._sync()
+        t0 = time.time()
+        if self.num_testing_workers > 1 and (self.force_testing_device or "cuda").startswith("cuda"):
+            items = list(self.dataloader)
+            pool = self._worker_pool()
+            W = min(self.num_testing_workers, max(1, len(items)))
+            base, extra = divmod(len(items), W)
+            # contiguous index ranges as in the reference (:851-852), remainder spread (the reference drops len % W items)
+            bounds = [0]
+            for w in range(W):
+                bounds.append(bounds[-1] + base + (1 if w < extra else 0))
+            loggers = [MetricLogger() for _ in range(W)]
+            dms = [copy.deepcopy(self.distortion_metric) if self.distortion_metric is not None else None for _ in range(W)]
+            codec_of = {id(c): i for i, c in enumerate(pool.codecs)}
+            self._sync()
+            t0 = time.time()
+
+            def work(codec, w):
+                for step in range(bounds[w], bounds[w + 1]):
+                    self._run_step(step, items[step], loggers[w], codec=codec, distortion_metric=dms[w])
+                return None
+            pool.map(work, list(range(W)))
+            for w in range(W):
+                logger.merge(loggers[w])
+                if dms[w] is not None:
+                    self.distortion_metric.metric_logger.merge(dms[w].metric_logger)
+            for d in items:
+                n_items, n_bytes = n_items + 1, n_bytes + self._estimate_byte_length(d)
+        else:
+            for step, data in enumerate(self.dataloader):
+                self._run_step(step, data, logger)
+                n_items, n_bytes = n_items + 1, n_bytes + self._estimate_byte_length(data)
+        self._sync()
+        wall = time.time() - t0
+        out = logger.get_global_average()
+        if n_items:
+            out["time_wall_dataset"] = wall * 1000
+            out["speed_wall_dataset"] = n_bytes / wall / 1024 / 1024
+        return out
+
+    def close(self):
+        if self._pool is not None:
+            self._pool.close()
+            self._pool = None
 
     # ---- level loop (basic_benchmark.py:640-1030): rate levels innermost, then complexity levels
     def run_testing(self, *args, **kwargs):

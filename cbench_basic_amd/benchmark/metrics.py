@@ -30,6 +30,12 @@ class MetricLogger:
         self._sum.clear()
         self._cnt.clear()
 
+    def merge(self, other):
+        """Adds another logger's sums and counts (the per-worker loggers of a parallel run)."""
+        for k in other._sum:
+            self._sum[k] = self._sum.get(k, 0.0) + other._sum[k]
+            self._cnt[k] = self._cnt.get(k, 0) + other._cnt[k]
+
 
 class PytorchBatchedDistortion:
     """pytorch_distortion.py:21-68 for ``metrics="psnr"``: PSNR of the mean squared error over the whole batch."""

@@ -21,6 +21,10 @@ class StreamWorkerPool:
         """make_codec(): a NEW codec on ``device`` with update_state() done (called n_workers times).
         priorities: HIP stream priority per worker (lower = more urgent); default: all equal."""
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        if self.device.type != "cuda":
+            raise ValueError("stream workers live on a GPU")
+        if self.device.index is None:   # torch.cuda.set_device() in the worker threads needs the ordinal
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.n = int(n_workers)
         lo, hi = torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else (0, 0)
         self._jobs, self._threads, self._done = [], [], queue.Queue()
@@ -37,7 +41,11 @@ class StreamWorkerPool:
             self._threads.append(t)
 
     def _loop(self, i, q):
-        torch.cuda.set_device(self.device)
+        setup_error = None
+        try:
+            torch.cuda.set_device(self.device)
+        except BaseException as e:   # reported with every job: a worker that could not start must not leave map() waiting
+            setup_error = e
         with torch.cuda.stream(self.streams[i]):
             while True:
                 job = q.get()
@@ -45,6 +53,8 @@ class StreamWorkerPool:
                     return
                 fn, arg, ticket = job
                 try:
+                    if setup_error is not None:
+                        raise setup_error
                     out = fn(self.codecs[i], arg)
                     self.streams[i].synchronize()   # the worker's results are complete when it reports them
                     self._done.put((ticket, i, out, None))

@@ -21,6 +21,8 @@
 // polling wave joins.  One workgroup per compute unit (the LDS footprint guarantees it); every spin is bounded.
 #include "common.h"
 
+#include <mutex>
+
 #include <cstdlib>
 #include <vector>
 
@@ -477,7 +479,35 @@ struct basic_scanline_plan {
     float *d_scratch = nullptr;
     size_t scratch_cap = 0;
     unsigned *d_bar = nullptr;   // [0] barrier counter, [1] error flag
+    hipEvent_t done = nullptr;   // completion of this plan's last launch (see ScanChain)
 };
+
+namespace {
+
+// At most ONE persistent launch runs at a time per process: its workgroups spin on a device-wide barrier and must all be
+// resident, so two such grids started from different HIP streams (concurrent stream workers) could each hold compute units
+// the other is waiting for until both give up.  Launches are therefore chained in GPU time -- a stream-wait on the event
+// that closes the previously enqueued launch -- in host enqueue order; nothing blocks on the host.  Ordinary kernels of other
+// streams are no hazard: they drain, and the barrier's spin bound (seconds) covers the wait for their compute units.
+struct ScanChain {
+    std::mutex mu;
+    hipEvent_t last = nullptr;
+};
+ScanChain g_scan_chain;
+
+template <typename Launch> int chained_launch(basic_scanline_plan *p, hipStream_t st, Launch &&launch)
+{
+    std::lock_guard<std::mutex> lock(g_scan_chain.mu);
+    if (!p->done) BASIC_HIP_TRY(hipEventCreateWithFlags(&p->done, hipEventDisableTiming));
+    if (g_scan_chain.last && g_scan_chain.last != p->done) BASIC_HIP_TRY(hipStreamWaitEvent(st, g_scan_chain.last, 0));
+    launch();
+    BASIC_HIP_TRY(hipGetLastError());
+    BASIC_HIP_TRY(hipEventRecord(p->done, st));
+    g_scan_chain.last = p->done;
+    return BASIC_OK;
+}
+
+}  // namespace
 
 extern "C" void basic_scanline_plan_destroy(basic_scanline_plan *p)
 {
@@ -488,6 +518,14 @@ extern "C" void basic_scanline_plan_destroy(basic_scanline_plan *p)
     }
     if (p->d_scratch) (void)hipFree(p->d_scratch);
     if (p->d_bar) (void)hipFree(p->d_bar);
+    if (p->done) {
+        std::lock_guard<std::mutex> lock(g_scan_chain.mu);
+        if (g_scan_chain.last == p->done) {
+            (void)hipEventSynchronize(p->done);   // whoever waits on it has been released
+            g_scan_chain.last = nullptr;
+        }
+        (void)hipEventDestroy(p->done);
+    }
     delete p;
 }
 
@@ -689,9 +727,7 @@ extern "C" int basic_scanline_encode_dev(basic_scanline_plan *p, const float *d_
     // more than half of a compute unit's LDS per workgroup: exactly one workgroup per unit, as the barrier protocol assumes
     if (lds_bytes < 96 * 1024) lds_bytes = 96 * 1024;
     BASIC_HIP_TRY(ensure_max_lds(reinterpret_cast<const void *>(scanline_persistent_kernel<false>)));
-    hipLaunchKernelGGL(scanline_persistent_kernel<false>, dim3(p->nwg), dim3(kThreads), lds_bytes, st, a);
-    BASIC_HIP_TRY(hipGetLastError());
-    return BASIC_OK;
+    return chained_launch(p, st, [&] { hipLaunchKernelGGL(scanline_persistent_kernel<false>, dim3(p->nwg), dim3(kThreads), lds_bytes, st, a); });
 }
 
 extern "C" int basic_scanline_decode_dev(basic_scanline_plan *p, const basic_rans_tables *tables, const uint32_t *d_words,
@@ -720,9 +756,7 @@ extern "C" int basic_scanline_decode_dev(basic_scanline_plan *p, const basic_ran
     if (lds_bytes < 96 * 1024) lds_bytes = 96 * 1024;
     BASIC_REQUIRE(lds_bytes <= 160 * 1024, "scanline_decode: the search image does not fit the LDS");
     BASIC_HIP_TRY(ensure_max_lds(reinterpret_cast<const void *>(scanline_persistent_kernel<true>)));
-    hipLaunchKernelGGL(scanline_persistent_kernel<true>, dim3(p->nwg + ndec), dim3(kThreads), lds_bytes, st, a);
-    BASIC_HIP_TRY(hipGetLastError());
-    return BASIC_OK;
+    return chained_launch(p, st, [&] { hipLaunchKernelGGL(scanline_persistent_kernel<true>, dim3(p->nwg + ndec), dim3(kThreads), lds_bytes, st, a); });
 }
 
 // 0 = the last launch on this plan completed its barriers; 1 = a barrier timed out (results invalid).  Synchronises `hip_stream`.

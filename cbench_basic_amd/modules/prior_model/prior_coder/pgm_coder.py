@@ -555,6 +555,7 @@ class GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(HotPathModule):
         sl = self._scanline_plan(plan, prior, y.shape[0])
         if sl is not None:
             sym, idx, ybuf = sl.encode(y, prior, self._scale_table_dev)
+            sl.check()   # a launch whose grid never became resident gave up on its barriers: fail loudly, never code garbage
             return sym, idx, ybuf, plan
         if len(plan.groups) < self.GRAPH_MIN_GROUPS or not getattr(self, "use_hip_graphs", True):
             return self._run_encode_impl(y, prior, plan)
@@ -733,6 +734,7 @@ class GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(HotPathModule):
             self._tables._pin_in_event.record(torch.cuda.current_stream(dev))
             d_woff = torch.from_numpy(woff).to(dev)
             _, _, ybuf = sl.decode(self._tables, d_words, d_woff, prior, B, H, W, self._scale_table_dev)
+            sl.check()
             return ybuf
         use_graph = len(plan.groups) >= self.GRAPH_MIN_GROUPS and getattr(self, "use_hip_graphs", True) and per_image
         if not use_graph:

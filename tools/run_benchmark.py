@@ -39,8 +39,14 @@ def main():
     ap.add_argument("--warmup", action="store_true",
                     help="code the first batch once before the timed run (plan building, table upload, graph capture are "
                          "one-time costs; the reference's harness has no such step)")
+    ap.add_argument("--workers", type=int, default=0,
+                    help="num_testing_workers: concurrent stream workers on the GPU, each with its own replica of the codec; dataset "
+                         "items are coded concurrently (the reference's multiprocessing pool, basic_benchmark.py:829-858, GPU-native)")
     ap.add_argument("--out", required=True)
     args = ap.parse_args()
+    if args.workers > 1:   # before HIP initialises: one hardware queue per worker stream
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+        os.environ.setdefault("BASIC_RANS_WPB", "8")
     if not torch.cuda.is_available():
         raise SystemExit("needs an MI355X: the codec has no CPU path")
 
@@ -52,9 +58,9 @@ def main():
     else:
         ds = RandomImageDataset(num=args.synthetic or 8, size=(3, args.height or args.size, args.width or args.size))
     batches = list(batched(ds, args.batch_size))
-    codec = dict(hyperprior=presets.hyperprior_codec,
-                 basic=lambda: presets.basic_codec(search_dataset=batches if args.complexity_search else None),
-                 topogroup=lambda: presets.topogroup_ar_codec(method=args.method))[args.codec]()
+    builders = dict(hyperprior=presets.hyperprior_codec, basic=presets.basic_codec,
+                    topogroup=lambda: presets.topogroup_ar_codec(method=args.method))
+    codec = presets.basic_codec(search_dataset=batches) if (args.codec == "basic" and args.complexity_search) else builders[args.codec]()
     if args.checkpoint:
         sd = torch.load(args.checkpoint, map_location="cpu")
         sd = sd.get("state_dict", sd)
@@ -74,8 +80,20 @@ def main():
                                               distortion_metric=PytorchBatchedDistortion(),
                                               nn_codec_use_forward_pass=args.forward_pass,
                                               testing_complexity_levels=args.complexity_levels,
-                                              testing_variable_rate_levels=args.rate_levels, output_dir=args.out)
+                                              testing_variable_rate_levels=args.rate_levels, output_dir=args.out,
+                                              num_testing_workers=args.workers,
+                                              codec_builder=(lambda: presets.seed_synthetic_weights(builders[args.codec](), seed=0)) if args.workers > 1 else None)
+    if args.workers > 1 and args.warmup:   # the replicas' one-time costs too, one replica at a time (HIP-graph capture)
+        pool = bench._worker_pool()
+        for r, st in zip(pool.codecs, pool.streams):
+            with torch.cuda.stream(st):
+                for lvl in (args.complexity_levels or [None]):
+                    if lvl is not None:
+                        r.set_complex_level(lvl)
+                    r.decompress(r.compress(batches[0].to("cuda")))
+            torch.cuda.synchronize()
     metrics = bench.run_benchmark(ignore_exist_metrics=True)
+    bench.close()
     print(json.dumps(metrics, indent=1))
 
 
