@@ -77,8 +77,11 @@ class BasicLosslessCompressionBenchmark:
         raise ValueError("Bitstream of data {} in type {} cannot be estimated!".format(data, type(data)))
 
     def _sync(self):
+        # the queue of THIS caller is empty before and after every timed region: the current stream -- the default stream in a
+        # sequential run (where it is the only one in use), the worker's own stream in a parallel one (a device-wide
+        # synchronisation there would make every worker wait for all the others at every item)
         if torch.cuda.is_available():
-            torch.cuda.synchronize()  # the device queue is empty before and after every timed region
+            torch.cuda.current_stream().synchronize()
 
     def _run_step(self, step, data, metric_logger, codec=None, distortion_metric=None):
         codec = self.codec if codec is None else codec

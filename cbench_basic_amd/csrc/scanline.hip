@@ -21,6 +21,7 @@
 // polling wave joins.  One workgroup per compute unit (the LDS footprint guarantees it); every spin is bounded.
 #include "common.h"
 
+#include <algorithm>
 #include <mutex>
 
 #include <cstdlib>
@@ -484,26 +485,35 @@ struct basic_scanline_plan {
 
 namespace {
 
-// At most ONE persistent launch runs at a time per process: its workgroups spin on a device-wide barrier and must all be
-// resident, so two such grids started from different HIP streams (concurrent stream workers) could each hold compute units
-// the other is waiting for until both give up.  Launches are therefore chained in GPU time -- a stream-wait on the event
-// that closes the previously enqueued launch -- in host enqueue order; nothing blocks on the host.  Ordinary kernels of other
-// streams are no hazard: they drain, and the barrier's spin bound (seconds) covers the wait for their compute units.
+// Persistent launches spin on a device-wide barrier and must be fully resident (one workgroup per compute unit), so grids
+// started from different HIP streams (concurrent stream workers) could each hold compute units the other is waiting for
+// until both give up.  They are therefore admitted in GPU time, in host enqueue order: the chip is cut into three slots of
+// CUs / 3 compute units; a launch of G workgroups takes ceil(G / (CUs / 3)) consecutive slots (round robin), waits -- a
+// stream-wait, nothing blocks on the host -- for the launches that last held them and leaves its own completion event
+// there.  Launches in flight hold disjoint slots, so together they never need more compute units than the chip has.
+// Ordinary kernels of other streams are no hazard: they drain, and the barrier's spin bound (seconds) covers the wait.
 struct ScanChain {
     std::mutex mu;
-    hipEvent_t last = nullptr;
+    hipEvent_t slot[3] = {nullptr, nullptr, nullptr};
+    int cursor = 0;
 };
 ScanChain g_scan_chain;
 
-template <typename Launch> int chained_launch(basic_scanline_plan *p, hipStream_t st, Launch &&launch)
+template <typename Launch> int chained_launch(basic_scanline_plan *p, hipStream_t st, int grid, int cus, Launch &&launch)
 {
     std::lock_guard<std::mutex> lock(g_scan_chain.mu);
     if (!p->done) BASIC_HIP_TRY(hipEventCreateWithFlags(&p->done, hipEventDisableTiming));
-    if (g_scan_chain.last && g_scan_chain.last != p->done) BASIC_HIP_TRY(hipStreamWaitEvent(st, g_scan_chain.last, 0));
+    const int per_slot = cus / 3 > 0 ? cus / 3 : 1;
+    const int need = std::min(3, (grid + per_slot - 1) / per_slot);
+    for (int j = 0; j < need; ++j) {
+        hipEvent_t e = g_scan_chain.slot[(g_scan_chain.cursor + j) % 3];
+        if (e && e != p->done) BASIC_HIP_TRY(hipStreamWaitEvent(st, e, 0));   // (its own previous launch: same stream, already ordered)
+    }
     launch();
     BASIC_HIP_TRY(hipGetLastError());
     BASIC_HIP_TRY(hipEventRecord(p->done, st));
-    g_scan_chain.last = p->done;
+    for (int j = 0; j < need; ++j) g_scan_chain.slot[(g_scan_chain.cursor + j) % 3] = p->done;
+    g_scan_chain.cursor = (g_scan_chain.cursor + need) % 3;
     return BASIC_OK;
 }
 
@@ -520,10 +530,11 @@ extern "C" void basic_scanline_plan_destroy(basic_scanline_plan *p)
     if (p->d_bar) (void)hipFree(p->d_bar);
     if (p->done) {
         std::lock_guard<std::mutex> lock(g_scan_chain.mu);
-        if (g_scan_chain.last == p->done) {
-            (void)hipEventSynchronize(p->done);   // whoever waits on it has been released
-            g_scan_chain.last = nullptr;
-        }
+        for (int i = 0; i < 3; ++i)
+            if (g_scan_chain.slot[i] == p->done) {
+                (void)hipEventSynchronize(p->done);   // whoever waits on it has been released
+                g_scan_chain.slot[i] = nullptr;
+            }
         (void)hipEventDestroy(p->done);
     }
     delete p;
@@ -727,7 +738,7 @@ extern "C" int basic_scanline_encode_dev(basic_scanline_plan *p, const float *d_
     // more than half of a compute unit's LDS per workgroup: exactly one workgroup per unit, as the barrier protocol assumes
     if (lds_bytes < 96 * 1024) lds_bytes = 96 * 1024;
     BASIC_HIP_TRY(ensure_max_lds(reinterpret_cast<const void *>(scanline_persistent_kernel<false>)));
-    return chained_launch(p, st, [&] { hipLaunchKernelGGL(scanline_persistent_kernel<false>, dim3(p->nwg), dim3(kThreads), lds_bytes, st, a); });
+    return chained_launch(p, st, p->nwg, cus, [&] { hipLaunchKernelGGL(scanline_persistent_kernel<false>, dim3(p->nwg), dim3(kThreads), lds_bytes, st, a); });
 }
 
 extern "C" int basic_scanline_decode_dev(basic_scanline_plan *p, const basic_rans_tables *tables, const uint32_t *d_words,
@@ -756,7 +767,7 @@ extern "C" int basic_scanline_decode_dev(basic_scanline_plan *p, const basic_ran
     if (lds_bytes < 96 * 1024) lds_bytes = 96 * 1024;
     BASIC_REQUIRE(lds_bytes <= 160 * 1024, "scanline_decode: the search image does not fit the LDS");
     BASIC_HIP_TRY(ensure_max_lds(reinterpret_cast<const void *>(scanline_persistent_kernel<true>)));
-    return chained_launch(p, st, [&] { hipLaunchKernelGGL(scanline_persistent_kernel<true>, dim3(p->nwg + ndec), dim3(kThreads), lds_bytes, st, a); });
+    return chained_launch(p, st, p->nwg + ndec, cus, [&] { hipLaunchKernelGGL(scanline_persistent_kernel<true>, dim3(p->nwg + ndec), dim3(kThreads), lds_bytes, st, a); });
 }
 
 // 0 = the last launch on this plan completed its barriers; 1 = a barrier timed out (results invalid).  Synchronises `hip_stream`.
