@@ -283,7 +283,7 @@ def run_ar_workload(args):
     yc = codec.entropy_coder.latent_node_entropy_coders["y"]
     yc.use_hip_graphs = False
     yc._graphs = {}
-    events, flops = [], [0]
+    events, flops, per_launch = [], [0], []
     orig = K.MaskedConvPlan.__call__
 
     def timed(self, xin, topo_in, topo_out, pos, out, out_offset=0, step=None, first_step=None):
@@ -304,6 +304,7 @@ def run_ar_workload(args):
             if len(q):
                 f += masked_conv_flops(self.cin, self.cout // to.shape[0], self.k, ti, to[go:go + 1], self._same, q)
         flops[0] += f * xin.shape[0]
+        per_launch.append((self.cin, self.cout, self.k, int(len(pp)), f * xin.shape[0]))
         return r
     # allow_same is a plan property: remember it at construction for the FLOP count
     yc._layers = None
@@ -334,7 +335,10 @@ def run_ar_workload(args):
                              kernel="masked_conv_pos_kernel (+ masked_conv_reduce_kernel): the masked-convolution launches of one encode + decode pass "
                                     "of the y-coder (context convolution + merger layers at the coded positions), HIP events per launch",
                              flops_per_launch=flops[0] / max(1, len(events)), launches_per_pass=len(events), avg_launch_ms=mc_ms / max(1, len(events)),
-                             pass_ms=mc_ms, note="algorithmic FLOPs = 2 x the (output, input, tap) products the reference's masks keep at the positions a step codes"))
+                             pass_ms=mc_ms, note="algorithmic FLOPs = 2 x the (output, input, tap) products the reference's masks keep at the positions a step codes",
+                             launches=None if len(events) > 64 else [
+                                 dict(cin=ci, cout=co, k=kk, positions_per_image=npos, gflop=fl / 1e9, ms=e0.elapsed_time(e1),
+                                      tflops=fl / 1e9 / max(e0.elapsed_time(e1), 1e-6)) for (ci, co, kk, npos, fl), (e0, e1) in zip(per_launch, events)]))
     if not args.no_cpu_baseline:
         from oracle.codec_oracle import BasicCodecOracle, TopoGroupCodecOracle
         from cbench_basic_amd.presets import BASIC_WIDTHS
