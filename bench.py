@@ -66,6 +66,10 @@ def parse():
                     help="hyperprior = the headline (BASELINE configs[4] shape); checkerboard = configs[2] topo-group AR codec; "
                          "basic = configs[3] BaSIC slimmable scan-line codec at complexity level 0 (parity-test configurations, extra lines)")
     ap.add_argument("--master-port", type=int, default=29533)
+    ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend of the metric reduction ('nccl' IS RCCL on ROCm)")
+    ap.add_argument("--same-device", action="store_true",
+                    help="REHEARSAL ONLY: every rank uses GPU 0 (with --dist-backend gloo: RCCL refuses two ranks on one GPU), to walk the "
+                         "N > 1 code path on a one-GPU box; the line it prints is not a measurement")
     return ap.parse_args()
 
 
@@ -385,11 +389,16 @@ def main():
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or "RANK" in os.environ:  # launched by torch.distributed.run: one rank per GPU
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # "nccl" IS RCCL on ROCm (xGMI)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # "nccl" IS RCCL on ROCm (xGMI)
+        else:
+            dist.init_process_group(args.dist_backend)
     dev = torch.device("cuda", local_rank)
 
     from cbench_basic_amd.benchmark.stream_workers import StreamWorkerPool, split_batch
