@@ -309,6 +309,10 @@ extern "C" int basic_mconv_plan_create(const float *weight, const float *bias, i
     if (const char *e = std::getenv("BASIC_MCONV_MAX_MT")) {  // tests: one tile per wave as the comparison point
         if (p->mt > std::atoi(e)) p->mt = 1;
     }
+    if (const char *e = std::getenv("BASIC_MCONV_FORCE_MT")) {  // tuning: another pack factor where it divides the group's tiles
+        const int f = std::atoi(e);
+        if (f >= 1 && f <= 5 && gs_out % (32 * f) == 0) p->mt = f;
+    }
     const int span = 32 * p->mt;
     std::vector<float> wp(static_cast<size_t>(ntaps) * cin * p->coutp, 0.f), hb(p->coutp, 0.f);
     std::vector<float> w1(p->mt > 1 ? wp.size() : 0, 0.f);
