@@ -25,6 +25,47 @@ def pmf_to_quantized_cdf(pmf, precision=16):
     return out.tolist()
 
 
+class ar_op_default:
+    """csrc/ans/lib.cpp:17-18 (``ar_op<int32>``): an op that does nothing; kept for import compatibility."""
+
+
+class ar_linear_op(ar_op_default):
+    """csrc/ans/ar_funcs.hpp:29-53, lib.cpp:20-22: callable on a list of ints; NOT accepted by init_custom_ar_ops in the
+    reference either (its binding takes ar_limited_scaled_add_linear_op only, ans_interface.hpp:40)."""
+
+    def __init__(self, weight, bias, scale):
+        self.weight, self.bias, self.scale = [float(w) for w in weight], float(bias), float(scale)
+
+    def __call__(self, values):
+        ret = np.float32(0)
+        for v, w in zip(values, self.weight):    # (sic) the bias is added once per element, ar_funcs.hpp:47
+            ret = np.float32(ret + np.float32(np.float32(np.float32(v) * np.float32(w)) + np.float32(self.bias)))
+        return int(np.float32(ret * np.float32(self.scale)))
+
+
+class ar_limited_scaled_add_linear_op(ar_op_default):
+    """csrc/ans/ar_funcs.hpp:58-87, lib.cpp:23-25: index' = index + (round(clamp(floor(index / scale) + w . v + bias, min, max))
+    - floor(index / scale)) * scale, in float32.  ``__call__`` evaluates it on the host (tests, table design); the coders
+    evaluate it on the GPU."""
+
+    def __init__(self, weight, bias, scale, min, max):
+        self.weight, self.bias, self.scale, self.min, self.max = [float(w) for w in weight], float(bias), float(scale), float(min), float(max)
+
+    def __call__(self, values):
+        f = np.float32
+        base = f(values[0])
+        unscaled = f(np.floor(base / f(self.scale)))
+        adder = f(0)
+        for v, w in zip(values[1:], self.weight):
+            adder = f(adder + f(f(v) * f(w)))
+        adder = f(adder + f(self.bias))
+        lim = f(unscaled + adder)
+        lim = lim if lim < f(self.max) else f(self.max)
+        lim = f(self.min) if f(self.min) > lim else lim
+        r = f(np.copysign(np.floor(np.abs(lim) + f(0.5)), lim))   # std::round: halves away from zero
+        return int(f(base + f(f(r - unscaled) * f(self.scale))))
+
+
 class _Rans64Base:
     def __init__(self, freq_precision=16, bypass_coding=True, bypass_precision=4):
         self._freq_precision = int(freq_precision)
@@ -88,8 +129,22 @@ class _Rans64Base:
         self._ar_order = order
 
     def init_custom_ar_ops(self, ops):
-        if len(ops) > 0:
-            raise NotImplementedError("custom AR ops (csrc/ans/ar_funcs.hpp) are outside the MI355X hot path")
+        """ANSBase::init_custom_ar_ops (csrc/ans/ans_interface.hpp:40-48): a list of ``ar_limited_scaled_add_linear_op`` (the
+        only type the reference's binding accepts); the table row of an element becomes op(index, previous raw symbols)."""
+        ops = list(ops)
+        if not ops:
+            return
+        if self._tables is None:
+            raise ValueError("ANS not initialized!")
+        for o in ops:
+            if not isinstance(o, ar_limited_scaled_add_linear_op):
+                raise TypeError("init_custom_ar_ops(): incompatible function arguments (a list of ar_limited_scaled_add_linear_op)")
+            if len(o.weight) > 3:
+                raise ValueError("Too many dimensions!")
+        arr = np.ascontiguousarray([list(o.weight) + [0.0] * (3 - len(o.weight)) + [o.bias, o.scale, o.min, o.max] for o in ops],
+                                   dtype=np.float32)
+        _lib.check(_lib.lib().basic_rans_tables_set_ar_ops(self._tables, arr.ctypes.data, arr.shape[0]))
+        self._ar_order = -1   # custom ops: the arity is the number of ar_offsets rows of a call
 
     def get_cdfs(self):
         if self._tables is None:
@@ -101,14 +156,17 @@ class _Rans64Base:
         return out
 
     def _ar_args(self, ar_indexes, ar_offsets, n):
+        """(ar_indexes, off0, off1, off2 addresses, keep-alive) of a call."""
         if not self._ar_order:
-            return None, None, None, ()
+            return None, None, None, None, ()
         if ar_offsets is None:
             raise ValueError("ar_offsets is required for ar coding!")
-        off = _i32(ar_offsets).reshape(self._ar_order, n)
+        off = _i32(ar_offsets).reshape(-1, n) if self._ar_order < 0 else _i32(ar_offsets).reshape(self._ar_order, n)
+        if off.shape[0] > 3:
+            raise ValueError("Too many dimensions!")
         ai = _i32(ar_indexes).reshape(-1) if ar_indexes is not None else None
-        o1 = off[1].ctypes.data if self._ar_order == 2 else None
-        return (ai.ctypes.data if ai is not None else None), off[0].ctypes.data, o1, (off, ai)
+        rows = [off[i].ctypes.data if i < off.shape[0] else None for i in range(3)]
+        return (ai.ctypes.data if ai is not None else None), rows[0], rows[1], rows[2], (off, ai)
 
 
 class Rans64Encoder(_Rans64Base):
@@ -129,12 +187,12 @@ class Rans64Encoder(_Rans64Base):
             self._cache.append((symbols.copy(), indexes.copy()))
             return b""
         n = indexes.size
-        ai, o0, o1, keep = self._ar_args(ar_indexes, ar_offsets, n)
+        ai, o0, o1, o2, keep = self._ar_args(ar_indexes, ar_offsets, n)
         cap = _lib.lib().basic_rans_encode_bound(n)
         out = np.empty(cap, dtype=np.uint8)
         out_len = ctypes.c_int64()
-        _lib.check(_lib.lib().basic_rans_encode_host(self._tables, symbols.ctypes.data, indexes.ctypes.data, n, ai, o0, o1,
-                                                     out.ctypes.data, cap, ctypes.byref(out_len)))
+        _lib.check(_lib.lib().basic_rans_encode_host_ex(self._tables, symbols.ctypes.data, indexes.ctypes.data, n, ai, o0, o1, o2,
+                                                        out.ctypes.data, cap, ctypes.byref(out_len)))
         return out[: out_len.value].tobytes()
 
     def flush(self):
@@ -186,9 +244,9 @@ class Rans64Decoder(_Rans64Base):
         n = indexes.size
         out = np.empty(indexes.shape, dtype=np.int32)
         buf = np.frombuffer(bytes(encoded), dtype=np.uint8)
-        ai, o0, o1, keep = self._ar_args(ar_indexes, ar_offsets, n)
-        _lib.check(_lib.lib().basic_rans_decode_host(self._tables, buf.ctypes.data, buf.size, indexes.ctypes.data, n, ai, o0, o1,
-                                                     out.ctypes.data))
+        ai, o0, o1, o2, keep = self._ar_args(ar_indexes, ar_offsets, n)
+        _lib.check(_lib.lib().basic_rans_decode_host_ex(self._tables, buf.ctypes.data, buf.size, indexes.ctypes.data, n, ai, o0, o1, o2,
+                                                        out.ctypes.data))
         return out
 
     def set_stream(self, stream):
@@ -292,7 +350,7 @@ class TansEncoder(_TansBase):
 
     def _encode(self, symbols, indexes, ar_indexes, ar_offsets, capacity_syms):
         n = indexes.size
-        ai, o0, o1, keep = self._ar_args(ar_indexes, ar_offsets, n)
+        ai, o0, o1, _, keep = self._ar_args(ar_indexes, ar_offsets, n)
         L = _lib.lib()
         cap = 4 * int(L.basic_tans_encode_bound_words(self._tables, n)) + 8
         out = np.empty(cap, dtype=np.uint8)
@@ -341,7 +399,7 @@ class TansDecoder(_TansBase):
         n = indexes.size
         out = np.empty(indexes.shape, dtype=np.int32)
         buf = np.frombuffer(bytes(encoded), dtype=np.uint8)
-        ai, o0, o1, keep = self._ar_args(ar_indexes, ar_offsets, n)
+        ai, o0, o1, _, keep = self._ar_args(ar_indexes, ar_offsets, n)
         _lib.check(_lib.lib().basic_tans_decode_host(self._tables, buf.ctypes.data, buf.size, indexes.ctypes.data, n, ai, o0, o1,
                                                      out.ctypes.data))
         return out

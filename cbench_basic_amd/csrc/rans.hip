@@ -35,6 +35,7 @@ struct basic_rans_tables {
     std::vector<int32_t> cdfs, sizes, offsets;  // host copies
     int32_t *d_cdfs = nullptr, *d_sizes = nullptr, *d_offsets = nullptr;
     int ar_k = 0, ar_rows = 0, ar_order = 0, ar_s1 = 0;
+    bool ar_custom = false;   // d_ar holds float [k][7] custom-op parameters (init_custom_ar_ops) instead of a remap table
     std::vector<int32_t> ar;
     int32_t *d_ar = nullptr;
     // Packed copy for the LDS-resident decoder: rows back to back as uint16 (the final entry 2^precision
@@ -302,9 +303,24 @@ extern "C" int basic_rans_tables_set_ar(basic_rans_tables *t, const int32_t *ar_
     size_t n = static_cast<size_t>(k) * rows * s1 * (order == 2 ? s1 : 1);
     t->ar.assign(ar_tab, ar_tab + n);
     t->ar_k = k; t->ar_rows = rows; t->ar_order = order; t->ar_s1 = s1;
+    t->ar_custom = false;
     if (t->d_ar) { (void)hipFree(t->d_ar); t->d_ar = nullptr; }
     BASIC_HIP_TRY(hipMalloc(&t->d_ar, n * sizeof(int32_t)));
     BASIC_HIP_TRY(hipMemcpy(t->d_ar, t->ar.data(), n * sizeof(int32_t), hipMemcpyHostToDevice));
+    return BASIC_OK;
+}
+
+// ANSBase::init_custom_ar_ops (ans_interface.hpp:40-48): k ops of type ar_limited_scaled_add_linear_op, ops float [k][7] =
+// (w0, w1, w2, bias, scale, min, max).  The number of predecessors (1..3) is the number of ar_offsets rows of a call.
+extern "C" int basic_rans_tables_set_ar_ops(basic_rans_tables *t, const float *ops, int k)
+{
+    BASIC_REQUIRE(t && ops && k >= 1, "init_custom_ar_ops: null/empty argument");
+    for (int i = 0; i < k; ++i) BASIC_REQUIRE(ops[i * 7 + 4] != 0.f, "init_custom_ar_ops: scale must not be zero");
+    if (t->d_ar) { (void)hipFree(t->d_ar); t->d_ar = nullptr; }
+    BASIC_HIP_TRY(hipMalloc(&t->d_ar, static_cast<size_t>(k) * 7 * sizeof(float)));
+    BASIC_HIP_TRY(hipMemcpy(t->d_ar, ops, static_cast<size_t>(k) * 7 * sizeof(float), hipMemcpyHostToDevice));
+    t->ar_k = k; t->ar_rows = t->rows; t->ar_order = 0; t->ar_s1 = 0;
+    t->ar_custom = true;
     return BASIC_OK;
 }
 
@@ -371,6 +387,8 @@ struct ArDev {
     const int32_t *tab;  // nullptr = no AR remap
     int k, order, rows, s1;
     const int32_t *ar_indexes, *off0, *off1;  // per stream-element arrays (global element ids)
+    const int32_t *off2;                       // third back distance (custom ops only)
+    int custom;                                // tab = float [k][7]: w0 w1 w2 bias scale min max (init_custom_ar_ops)
 };
 
 
@@ -386,6 +404,25 @@ __device__ __forceinline__ int32_t ar_row(const ArDev &ar, int32_t a, int32_t ro
     if (ar.order == 1) return ar.tab[(static_cast<int64_t>(a) * ar.rows + row) * ar.s1 + v0];
     v1 = clampi(v1, 0, ar.s1 - 1);
     return ar.tab[((static_cast<int64_t>(a) * ar.rows + row) * ar.s1 + v0) * ar.s1 + v1];
+}
+
+// ar_limited_scaled_add_linear_op::op on (index, the RAW previous symbols), csrc/ans/ar_funcs.hpp:58-87 called from
+// ar_update_index (ans_interface.hpp:60-84).  float arithmetic with every product and sum rounded on its own, as the
+// reference's x86 build does (no fused multiply-add: the intrinsics keep hipcc from contracting).
+__device__ __forceinline__ int32_t ar_custom_row(const ArDev &ar, int32_t a, int32_t row, int32_t v0, int32_t v1, int32_t v2)
+{
+    const float *op = reinterpret_cast<const float *>(ar.tab) + static_cast<int64_t>(clampi(a, 0, ar.k - 1)) * 7;
+    const float base = static_cast<float>(row), scale = op[4];
+    const float base_unscaled = floorf(__fdiv_rn(base, scale));
+    float adder = __fadd_rn(0.f, __fmul_rn(static_cast<float>(v0), op[0]));
+    if (ar.order > 1) adder = __fadd_rn(adder, __fmul_rn(static_cast<float>(v1), op[1]));
+    if (ar.order > 2) adder = __fadd_rn(adder, __fmul_rn(static_cast<float>(v2), op[2]));
+    adder = __fadd_rn(adder, op[3]);
+    float lim = __fadd_rn(base_unscaled, adder);
+    lim = lim < op[6] ? lim : op[6];
+    lim = op[5] > lim ? op[5] : lim;
+    const float step = __fmul_rn(__fsub_rn(roundf(lim), base_unscaled), scale);
+    return static_cast<int32_t>(__fadd_rn(base, step));
 }
 
 __device__ __forceinline__ uint32_t bcast_u32(uint32_t v, int lane)
@@ -480,14 +517,19 @@ __global__ __launch_bounds__(64) void rans_encode_kernel(TablesDev T, ArDev ar, 
             if (ar.tab) {
                 const int64_t g = beg + i;
                 const int32_t a = ar.ar_indexes ? ar.ar_indexes[g] : 0;
+                const int32_t one = ar.custom ? 0 : 1;   // the table flavour indexes with symbol + 1 (0 = no predecessor)
                 const int32_t d0 = ar.off0[g];
-                const int32_t v0 = (d0 > 0 && d0 <= i) ? sym[i - d0] + 1 : 0;
-                int32_t v1 = 0;
-                if (ar.order == 2) {
+                const int32_t v0 = (d0 > 0 && d0 <= i) ? sym[i - d0] + one : 0;
+                int32_t v1 = 0, v2 = 0;
+                if (ar.order >= 2) {
                     const int32_t d1 = ar.off1[g];
-                    v1 = (d1 > 0 && d1 <= i) ? sym[i - d1] + 1 : 0;
+                    v1 = (d1 > 0 && d1 <= i) ? sym[i - d1] + one : 0;
                 }
-                row = ar_row(ar, a, row, v0, v1);
+                if (ar.order >= 3) {
+                    const int32_t d2 = ar.off2[g];
+                    v2 = (d2 > 0 && d2 <= i) ? sym[i - d2] + one : 0;
+                }
+                row = ar.custom ? ar_custom_row(ar, a, row, v0, v1, v2) : ar_row(ar, a, row, v0, v1);
             }
             row = clampi(row, 0, T.rows - 1);
             const int32_t *cdf = T.cdfs + static_cast<int64_t>(row) * T.stride;
@@ -761,14 +803,19 @@ __global__ __launch_bounds__(64) void rans_decode_kernel(TablesDev T, ArDev ar, 
                 // remap from already-decoded symbols (ans_interface.hpp:89-104); lane-uniform loads
                 const int64_t e = c0 + j, g = beg + e;
                 const int32_t a = ar.ar_indexes ? ar.ar_indexes[g] : 0;
+                const int32_t one = ar.custom ? 0 : 1;
                 const int32_t d0 = ar.off0[g];
-                const int32_t v0 = (d0 > 0 && d0 <= e) ? __hip_atomic_load(out + (e - d0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 : 0;
-                int32_t v1 = 0;
-                if (ar.order == 2) {
+                const int32_t v0 = (d0 > 0 && d0 <= e) ? __hip_atomic_load(out + (e - d0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + one : 0;
+                int32_t v1 = 0, v2 = 0;
+                if (ar.order >= 2) {
                     const int32_t d1 = ar.off1[g];
-                    v1 = (d1 > 0 && d1 <= e) ? __hip_atomic_load(out + (e - d1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 : 0;
+                    v1 = (d1 > 0 && d1 <= e) ? __hip_atomic_load(out + (e - d1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + one : 0;
                 }
-                row = ar_row(ar, a, row, v0, v1);
+                if (ar.order >= 3) {
+                    const int32_t d2 = ar.off2[g];
+                    v2 = (d2 > 0 && d2 <= e) ? __hip_atomic_load(out + (e - d2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + one : 0;
+                }
+                row = ar.custom ? ar_custom_row(ar, a, row, v0, v1, v2) : ar_row(ar, a, row, v0, v1);
                 row = __builtin_amdgcn_readfirstlane(clampi(row, 0, T.rows - 1));
                 size = T.sizes[row];
                 offset = T.offsets[row];
@@ -1341,16 +1388,22 @@ extern "C" int basic_rans_decode_batch_strided_dev(const basic_rans_tables *t, c
 namespace {
 
 int stage_ar(const basic_rans_tables *t, int64_t n, const int32_t *ar_indexes, const int32_t *ar_off0,
-             const int32_t *ar_off1, DevBuf &b_ai, DevBuf &b_o0, DevBuf &b_o1, ArDev &ar)
+             const int32_t *ar_off1, const int32_t *ar_off2, DevBuf &b_ai, DevBuf &b_o0, DevBuf &b_o1, DevBuf &b_o2, ArDev &ar)
 {
     ar = ArDev{};
     if (!t->d_ar) return BASIC_OK;
-    if (!ar_off0 || (t->ar_order == 2 && !ar_off1)) {
+    if (!ar_off0 || (!t->ar_custom && t->ar_order == 2 && !ar_off1)) {
         set_error("ar_offsets is required for ar coding!");
         return BASIC_ERR_INVALID;
     }
     const size_t bytes = static_cast<size_t>(n) * sizeof(int32_t);
     ar.tab = t->d_ar; ar.k = t->ar_k; ar.order = t->ar_order; ar.rows = t->ar_rows; ar.s1 = t->ar_s1;
+    if (t->ar_custom) {   // the op's arity is the number of offset rows of this call (ans_interface.hpp:70-84)
+        ar.custom = 1;
+        ar.order = ar_off2 ? 3 : ar_off1 ? 2 : 1;
+        if (ar_off2 && !ar_off1) { set_error("ar_offsets rows must be given in order"); return BASIC_ERR_INVALID; }
+    }
+    const int order = ar.order;
     if (ar_indexes) {
         BASIC_HIP_TRY(b_ai.alloc(bytes));
         BASIC_HIP_TRY(hipMemcpy(b_ai.p, ar_indexes, bytes, hipMemcpyHostToDevice));
@@ -1359,10 +1412,15 @@ int stage_ar(const basic_rans_tables *t, int64_t n, const int32_t *ar_indexes, c
     BASIC_HIP_TRY(b_o0.alloc(bytes));
     BASIC_HIP_TRY(hipMemcpy(b_o0.p, ar_off0, bytes, hipMemcpyHostToDevice));
     ar.off0 = b_o0.as<int32_t>();
-    if (t->ar_order == 2) {
+    if (order >= 2) {
         BASIC_HIP_TRY(b_o1.alloc(bytes));
         BASIC_HIP_TRY(hipMemcpy(b_o1.p, ar_off1, bytes, hipMemcpyHostToDevice));
         ar.off1 = b_o1.as<int32_t>();
+    }
+    if (order >= 3) {
+        BASIC_HIP_TRY(b_o2.alloc(bytes));
+        BASIC_HIP_TRY(hipMemcpy(b_o2.p, ar_off2, bytes, hipMemcpyHostToDevice));
+        ar.off2 = b_o2.as<int32_t>();
     }
     return BASIC_OK;
 }
@@ -1373,10 +1431,17 @@ extern "C" int basic_rans_encode_host(const basic_rans_tables *t, const int32_t 
                                       int64_t n, const int32_t *ar_indexes, const int32_t *ar_off0,
                                       const int32_t *ar_off1, uint8_t *out, int64_t out_capacity, int64_t *out_len)
 {
+    return basic_rans_encode_host_ex(t, symbols, indexes, n, ar_indexes, ar_off0, ar_off1, nullptr, out, out_capacity, out_len);
+}
+
+extern "C" int basic_rans_encode_host_ex(const basic_rans_tables *t, const int32_t *symbols, const int32_t *indexes,
+                                         int64_t n, const int32_t *ar_indexes, const int32_t *ar_off0, const int32_t *ar_off1,
+                                         const int32_t *ar_off2, uint8_t *out, int64_t out_capacity, int64_t *out_len)
+{
     if (!t) { set_error("ANS not initialized!"); return BASIC_ERR_NOT_INIT; }
     BASIC_REQUIRE(n >= 0 && out && out_len && (n == 0 || (symbols && indexes)), "encode_with_indexes: bad argument");
     const int64_t slot_words = basic_rans_encode_bound(n) / 4;
-    DevBuf b_sym, b_idx, b_seg, b_out, b_nw, b_ai, b_o0, b_o1;
+    DevBuf b_sym, b_idx, b_seg, b_out, b_nw, b_ai, b_o0, b_o1, b_o2;
     const size_t bytes = static_cast<size_t>(n) * sizeof(int32_t);
     BASIC_HIP_TRY(b_sym.alloc(bytes));
     BASIC_HIP_TRY(b_idx.alloc(bytes));
@@ -1390,7 +1455,7 @@ extern "C" int basic_rans_encode_host(const basic_rans_tables *t, const int32_t 
     const int64_t seg[2] = {0, n};
     BASIC_HIP_TRY(hipMemcpy(b_seg.p, seg, sizeof(seg), hipMemcpyHostToDevice));
     ArDev ar;
-    int rc = stage_ar(t, n, ar_indexes, ar_off0, ar_off1, b_ai, b_o0, b_o1, ar);
+    int rc = stage_ar(t, n, ar_indexes, ar_off0, ar_off1, ar_off2, b_ai, b_o0, b_o1, b_o2, ar);
     if (rc) return rc;
     if (!ar.tab && t->fast_enc_ok)  // same kernel choice as the batched device entry point
         hipLaunchKernelGGL(rans_encode_fast_kernel<1>, dim3(1), dim3(64), static_cast<size_t>(t->rows) * sizeof(int2), nullptr,
@@ -1441,12 +1506,12 @@ extern "C" int basic_rans_stream_open(const basic_rans_tables *t, const uint8_t 
 
 namespace {
 int stream_decode(basic_rans_stream *s, const int32_t *indexes, int64_t n, const int32_t *ar_indexes,
-                  const int32_t *ar_off0, const int32_t *ar_off1, int32_t *out_symbols)
+                  const int32_t *ar_off0, const int32_t *ar_off1, const int32_t *ar_off2, int32_t *out_symbols)
 {
     BASIC_REQUIRE(s && n >= 0 && (n == 0 || (indexes && out_symbols)), "decode: bad argument");
     if (n == 0) return BASIC_OK;
     const basic_rans_tables *t = s->t;
-    DevBuf b_idx, b_seg, b_out, b_ai, b_o0, b_o1;
+    DevBuf b_idx, b_seg, b_out, b_ai, b_o0, b_o1, b_o2;
     const size_t bytes = static_cast<size_t>(n) * sizeof(int32_t);
     BASIC_HIP_TRY(b_idx.alloc(bytes));
     BASIC_HIP_TRY(b_out.alloc(bytes));
@@ -1455,7 +1520,7 @@ int stream_decode(basic_rans_stream *s, const int32_t *indexes, int64_t n, const
     const int64_t seg[2] = {0, n};
     BASIC_HIP_TRY(hipMemcpy(b_seg.p, seg, sizeof(seg), hipMemcpyHostToDevice));
     ArDev ar;
-    int rc = stage_ar(t, n, ar_indexes, ar_off0, ar_off1, b_ai, b_o0, b_o1, ar);
+    int rc = stage_ar(t, n, ar_indexes, ar_off0, ar_off1, ar_off2, b_ai, b_o0, b_o1, b_o2, ar);
     if (rc) return rc;
     rc = launch_decode(t, ar, 1, nullptr, s->words.as<uint32_t>(), s->woff.as<int64_t>(), b_idx.as<int32_t>(),
                        b_seg.as<int64_t>(), b_out.as<int32_t>(), s->state.as<uint64_t>(), s->pos.as<int64_t>());
@@ -1470,7 +1535,7 @@ extern "C" int basic_rans_stream_decode(basic_rans_stream *s, const int32_t *ind
     // decode_stream ignores AR parameters in the reference (rans64.cpp:529,537)
     if (!s) { set_error("set_stream was not called"); return BASIC_ERR_NOT_INIT; }
     BASIC_REQUIRE(!s->t->d_ar, "decode_stream does not support AR tables (reference: rans64.cpp:529)");
-    return stream_decode(s, indexes, n, nullptr, nullptr, nullptr, out_symbols);
+    return stream_decode(s, indexes, n, nullptr, nullptr, nullptr, nullptr, out_symbols);
 }
 
 extern "C" void basic_rans_stream_close(basic_rans_stream *s) { delete s; }
@@ -1479,10 +1544,17 @@ extern "C" int basic_rans_decode_host(const basic_rans_tables *t, const uint8_t 
                                       const int32_t *indexes, int64_t n, const int32_t *ar_indexes,
                                       const int32_t *ar_off0, const int32_t *ar_off1, int32_t *out_symbols)
 {
+    return basic_rans_decode_host_ex(t, stream, stream_len, indexes, n, ar_indexes, ar_off0, ar_off1, nullptr, out_symbols);
+}
+
+extern "C" int basic_rans_decode_host_ex(const basic_rans_tables *t, const uint8_t *stream, int64_t stream_len,
+                                         const int32_t *indexes, int64_t n, const int32_t *ar_indexes, const int32_t *ar_off0,
+                                         const int32_t *ar_off1, const int32_t *ar_off2, int32_t *out_symbols)
+{
     basic_rans_stream *s = nullptr;
     int rc = basic_rans_stream_open(t, stream, stream_len, &s);
     if (rc) return rc;
-    rc = stream_decode(s, indexes, n, ar_indexes, ar_off0, ar_off1, out_symbols);
+    rc = stream_decode(s, indexes, n, ar_indexes, ar_off0, ar_off1, ar_off2, out_symbols);
     basic_rans_stream_close(s);
     return rc;
 }

@@ -52,6 +52,10 @@ int basic_rans_tables_from_cdfs(const int32_t *cdfs, int rows, int cdf_stride, c
 /* AR index-remap tables, ANSBase::init_ar_params (csrc/ans/ans_interface.cpp:75-137):
  * ar_tab int32 [k][rows][s1] (order 1) or [k][rows][s1][s1] (order 2). */
 int basic_rans_tables_set_ar(basic_rans_tables *t, const int32_t *ar_tab, int k, int rows, int order, int s1);
+/* Custom AR ops, ANSBase::init_custom_ar_ops (csrc/ans/ans_interface.hpp:40-48; the op: ar_limited_scaled_add_linear_op,
+ * csrc/ans/ar_funcs.hpp:58-87): ops float32 [k][7] = (w0, w1, w2, bias, scale, min, max).  The table row of an element becomes
+ * op(index, previous symbols) -- RAW symbol values at the back distances of the call's ar_offsets rows (1..3 of them). */
+int basic_rans_tables_set_ar_ops(basic_rans_tables *t, const float *ops, int k);
 int basic_rans_tables_info(const basic_rans_tables *t, int *rows, int *max_cdf_len);
 /* get_cdfs(): out int32 [rows][out_stride], padding written as 0. */
 int basic_rans_tables_get_cdfs(const basic_rans_tables *t, int32_t *out, int out_stride);
@@ -70,6 +74,13 @@ void basic_rans_tables_destroy(basic_rans_tables *t);
 int basic_rans_encode_host(const basic_rans_tables *t, const int32_t *symbols, const int32_t *indexes,
                            int64_t n, const int32_t *ar_indexes, const int32_t *ar_off0,
                            const int32_t *ar_off1, uint8_t *out, int64_t out_capacity, int64_t *out_len);
+/* The same with a third ar_offsets row (custom AR ops take up to three predecessors). */
+int basic_rans_encode_host_ex(const basic_rans_tables *t, const int32_t *symbols, const int32_t *indexes, int64_t n,
+                              const int32_t *ar_indexes, const int32_t *ar_off0, const int32_t *ar_off1,
+                              const int32_t *ar_off2, uint8_t *out, int64_t out_capacity, int64_t *out_len);
+int basic_rans_decode_host_ex(const basic_rans_tables *t, const uint8_t *stream, int64_t stream_len, const int32_t *indexes,
+                              int64_t n, const int32_t *ar_indexes, const int32_t *ar_off0, const int32_t *ar_off1,
+                              const int32_t *ar_off2, int32_t *out_symbols);
 /* Upper bound of the encoded size in bytes for n symbols (always sufficient). */
 int64_t basic_rans_encode_bound(int64_t n);
 int basic_rans_decode_host(const basic_rans_tables *t, const uint8_t *stream, int64_t stream_len,

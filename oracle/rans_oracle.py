@@ -31,6 +31,8 @@ def lib():
         L.orc_rans64_encode_ar.restype = ctypes.c_int64
         L.orc_rans64_decode.restype = ctypes.c_int
         L.orc_rans64_decode_ar.restype = ctypes.c_int
+        L.orc_rans64_encode_arop.restype = ctypes.c_int64
+        L.orc_rans64_decode_arop.restype = ctypes.c_int
         L.orc_pmf_to_quantized_cdf.restype = ctypes.c_int
         L.orc_tables_from_freqs.restype = ctypes.c_int
         _LIB = L
@@ -84,8 +86,26 @@ class _Base:
             raise ValueError("Too many dimensions!")
         self.ar = (tab, order)
 
+    def init_custom_ar_ops(self, ops):
+        """ANSBase::init_custom_ar_ops (ans_interface.hpp:40-48): a list of ar_limited_scaled_add_linear_op."""
+        if len(ops):
+            self.arops = np.ascontiguousarray([list(o.weight) + [0.0] * (3 - len(o.weight)) + [o.bias, o.scale, o.min, o.max] for o in ops],
+                                              dtype=np.float32)
+
     def get_cdfs(self):
         return self.cdfs[:, : int(self.sizes.max())].copy()
+
+    def _aropargs(self, ar_indexes, ar_offsets, n):
+        if ar_offsets is None:
+            raise ValueError("ar_offsets is required for ar coding!")
+        off = _i32(ar_offsets).reshape(-1, n)
+        if off.shape[0] > 3:
+            raise ValueError("Too many dimensions!")
+        rows = [np.ascontiguousarray(r) for r in off]
+        ai = _i32(ar_indexes).reshape(-1) if ar_indexes is not None else None
+        keep = [rows, ai, self.arops]
+        return keep, (_p(self.arops), ctypes.c_int(off.shape[0]), _p(ai) if ai is not None else None, _p(rows[0]),
+                      _p(rows[1]) if len(rows) > 1 else None, _p(rows[2]) if len(rows) > 2 else None)
 
     def _targs(self):
         return (_p(self.cdfs), ctypes.c_int(self.cdfs.shape[1]), _p(self.sizes), _p(self.offsets),
@@ -114,7 +134,10 @@ class Rans64Encoder(_Base):
         n = idx.size
         cap = 2 * n + 8
         out = np.empty(cap, dtype=np.uint32)
-        if self.ar is not None:
+        if getattr(self, "arops", None) is not None:
+            keep, a = self._aropargs(ar_indexes, ar_offsets, n)
+            nw = lib().orc_rans64_encode_arop(*self._targs(), *a, _p(sym), _p(idx), ctypes.c_int64(n), _p(out), ctypes.c_int64(cap))
+        elif self.ar is not None:
             keep, a = self._arargs(ar_indexes, ar_offsets, n)
             nw = lib().orc_rans64_encode_ar(*self._targs(), *a, _p(sym), _p(idx), ctypes.c_int64(n), _p(out),
                                             ctypes.c_int64(cap))
@@ -133,6 +156,10 @@ class Rans64Decoder(_Base):
         idx = _i32(indexes)
         words = np.frombuffer(encoded, dtype=np.uint32).copy()
         out = np.empty(idx.shape, dtype=np.int32)
+        if getattr(self, "arops", None) is not None:
+            keep, a = self._aropargs(ar_indexes, ar_offsets, idx.size)
+            lib().orc_rans64_decode_arop(*self._targs(), *a, _p(words), _p(idx), ctypes.c_int64(idx.size), _p(out))
+            return out
         if self.ar is not None:
             keep, a = self._arargs(ar_indexes, ar_offsets, idx.size)
             lib().orc_rans64_decode_ar(*self._targs(), *a, _p(words), _p(idx), ctypes.c_int64(idx.size), _p(out))
@@ -172,3 +199,10 @@ def load_ref():
         spec.loader.exec_module(m)
         mods.append(m)
     return tuple(mods)
+
+
+class ar_limited_scaled_add_linear_op:
+    """csrc/ans/ar_funcs.hpp:58-87 (the only op type init_custom_ar_ops accepts, ans_interface.hpp:40)."""
+
+    def __init__(self, weight, bias, scale, min, max):
+        self.weight, self.bias, self.scale, self.min, self.max = [float(w) for w in weight], float(bias), float(scale), float(min), float(max)

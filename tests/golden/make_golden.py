@@ -892,6 +892,47 @@ def ar_coder_quant():
     save("ar_coder_quant.npz", **out)
 
 
+def ar_ops_kats():
+    """Custom AR ops (csrc/ans/ar_funcs.hpp:29-87, ANSBase::init_custom_ar_ops ans_interface.hpp:40-84): bytes of the reference's
+    compiled Rans64Encoder with ar_limited_scaled_add_linear_op index remaps of 1, 2 and 3 predecessors, and direct calls of the
+    two bound op classes."""
+    out, names = {}, []
+    rng = np.random.default_rng(606)
+    for order in (1, 2, 3):
+        nd, ns, n, k = 16, 24, 1200, 3
+        freqs = rng.integers(1, 600, (nd, ns)).astype(np.int32)
+        nsym, off = np.full(nd, ns, np.int32), rng.integers(-3, 3, nd).astype(np.int32)
+        ops = []
+        for j in range(k):
+            sc = float([1.0, 2.0, 4.0][j])
+            ops.append(((rng.random(order) * 0.6 - 0.3).round(4).tolist(), float(np.round(rng.random() - 0.5, 4)), sc, 0.0, float(nd // int(sc) - 1)))
+        sym = (rng.integers(-2, ns + 2, n)).astype(np.int32)
+        idx = rng.integers(0, nd, n).astype(np.int32)
+        ai = rng.integers(0, k, n).astype(np.int32)
+        aoff = np.stack([np.minimum(np.arange(n), 1 + 2 * q) for q in range(order)]).astype(np.int32)
+        enc, dec = ref_ans.Rans64Encoder(16, True, 4), ref_ans.Rans64Decoder(16, True, 4)
+        for c in (enc, dec):
+            c.init_params(freqs, nsym, off)
+            c.init_custom_ar_ops([ref_ans.ar_limited_scaled_add_linear_op(*o) for o in ops])
+        data = enc.encode_with_indexes(sym, idx, ai, aoff)
+        assert np.array_equal(dec.decode_with_indexes(data, idx, ai, aoff), sym)
+        name = f"o{order}"
+        out.update({f"{name}.freqs": freqs, f"{name}.nsym": nsym, f"{name}.offsets": off, f"{name}.symbols": sym, f"{name}.indexes": idx,
+                    f"{name}.ar_indexes": ai, f"{name}.ar_offsets": aoff, f"{name}.bytes": b2a(data),
+                    f"{name}.ops": np.array([list(o[0]) + [0.0] * (3 - order) + list(o[1:]) for o in ops], np.float64)})
+        names.append(name)
+        print(f"  {name}: {len(data)} bytes")
+    # direct calls
+    lim = ref_ans.ar_limited_scaled_add_linear_op([0.37, -0.21], 0.4, 2.0, 0.0, 7.0)
+    lin = ref_ans.ar_linear_op([1.0, 0.5, -0.25], 0.125, 2.0)
+    vecs = rng.integers(-6, 16, (40, 3)).astype(np.int32)
+    out["call.vectors"] = vecs
+    out["call.limited"] = np.array([lim(v.tolist()) for v in vecs], np.int32)
+    out["call.linear"] = np.array([lin(v.tolist()) for v in vecs], np.int32)
+    out["names"] = np.array(names)
+    save("ar_ops_kat.npz", **out)
+
+
 def tans_kats():
     """Known answers of the reference's compiled TansEncoder / TansDecoder (cbench/csrc/ans/tans.cpp in oracle/_ref):
     bytes, decoded symbols, the error cases (too small an output budget -> ValueError; stream larger than its budget ->
@@ -967,7 +1008,7 @@ def tans_kats():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["rans", "tables", "topo", "mconv", "ar", "framing", "harness", "search", "arpgm", "arjoint", "codec", "grouped", "tans", "ardyn", "train", "arquant"]
-    fn = dict(rans=rans_kats, tables=gauss_tables, topo=topo_maps, mconv=masked_conv, ar=ar_coder, framing=framing, harness=harness, search=complexity_search, arpgm=ar_coder_pgm, arjoint=ar_coder_joint, codec=codec_graph, grouped=grouped, tans=tans_kats, ardyn=ar_coder_dynamic, train=train_mode, arquant=ar_coder_quant)
+    which = sys.argv[1:] or ["rans", "tables", "topo", "mconv", "ar", "framing", "harness", "search", "arpgm", "arjoint", "codec", "grouped", "tans", "ardyn", "train", "arquant", "arops"]
+    fn = dict(rans=rans_kats, tables=gauss_tables, topo=topo_maps, mconv=masked_conv, ar=ar_coder, framing=framing, harness=harness, search=complexity_search, arpgm=ar_coder_pgm, arjoint=ar_coder_joint, codec=codec_graph, grouped=grouped, tans=tans_kats, ardyn=ar_coder_dynamic, train=train_mode, arquant=ar_coder_quant, arops=ar_ops_kats)
     for w in which:
         fn[w]()

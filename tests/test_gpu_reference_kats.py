@@ -216,3 +216,21 @@ def test_tans_batched_device_streams_on_hip():
     torch.cuda.synchronize()
     assert (d_status.cpu().numpy() == 0).all()
     assert np.array_equal(d_out.cpu().numpy(), sym)
+
+
+def test_custom_ar_ops_on_hip():
+    """cbench.ans.init_custom_ar_ops / ar_limited_scaled_add_linear_op / ar_linear_op (lib.cpp:17-25, ar_funcs.hpp:29-87) on the
+    bytes and call results of the reference's compiled module."""
+    from cbench_basic_amd import ans
+    from test_oracle_golden import _ar_ops_case
+    z = load("ar_ops_kat.npz")
+    for name in z["names"]:
+        _ar_ops_case(z, str(name), ans)
+    lim = ans.ar_limited_scaled_add_linear_op([0.37, -0.21], 0.4, 2.0, 0.0, 7.0)
+    lin = ans.ar_linear_op([1.0, 0.5, -0.25], 0.125, 2.0)
+    assert [lim(v.tolist()) for v in z["call.vectors"]] == z["call.limited"].tolist()
+    assert [lin(v.tolist()) for v in z["call.vectors"]] == z["call.linear"].tolist()
+    enc = ans.Rans64Encoder(16, True, 4)
+    enc.init_params(z["o1.freqs"], z["o1.nsym"], z["o1.offsets"])
+    with pytest.raises(TypeError):
+        enc.init_custom_ar_ops([lin])

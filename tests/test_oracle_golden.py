@@ -376,3 +376,23 @@ def test_ar_coder_non_identity_quantisers_match_reference():
         assert data == z[f"{k}.bytes"].tobytes(), k
         back = buf * step + off if qt == "uniform" else buf * step
         assert torch.allclose(back, torch.from_numpy(z[f"{k}.yhat"]), atol=1e-5), k
+
+
+def _ar_ops_case(z, name, mod):
+    ops = [mod.ar_limited_scaled_add_linear_op([float(w) for w in row[:3]][: int(name[1:])], float(row[3]), float(row[4]), float(row[5]), float(row[6]))
+           for row in z[f"{name}.ops"]]
+    enc, dec = mod.Rans64Encoder(16, True, 4), mod.Rans64Decoder(16, True, 4)
+    for c in (enc, dec):
+        c.init_params(z[f"{name}.freqs"], z[f"{name}.nsym"], z[f"{name}.offsets"])
+        c.init_custom_ar_ops(ops)
+    args = (z[f"{name}.ar_indexes"], z[f"{name}.ar_offsets"])
+    data = enc.encode_with_indexes(z[f"{name}.symbols"], z[f"{name}.indexes"], *args)
+    assert data == z[f"{name}.bytes"].tobytes(), name
+    assert np.array_equal(dec.decode_with_indexes(data, z[f"{name}.indexes"], *args), z[f"{name}.symbols"]), name
+
+
+def test_custom_ar_ops_oracle_matches_reference(oracle):
+    """init_custom_ar_ops with ar_limited_scaled_add_linear_op index remaps of 1, 2, 3 predecessors (ar_funcs.hpp:58-87)."""
+    z = load("ar_ops_kat.npz")
+    for name in z["names"]:
+        _ar_ops_case(z, str(name), oracle)
