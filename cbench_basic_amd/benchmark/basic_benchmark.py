@@ -132,19 +132,27 @@ class BasicLosslessCompressionBenchmark:
                     c.eval()
                 return c.to(self.force_testing_device or "cuda") if hasattr(c, "to") else c
             self._pool = StreamWorkerPool(make, self.num_testing_workers, torch.device(self.force_testing_device or "cuda"))
+        level_attrs = ("_current_complex_level", "_current_rate_level", "_current_task_idx", "active_codec_idx")
         for r in self._pool.codecs:
-            if hasattr(r, "load_state_dict"):
-                ec, rec = getattr(self.codec, "entropy_coder", None), getattr(r, "entropy_coder", None)
-                if ec is not None and hasattr(ec, "_complexity_param_all_levels"):   # searched levels: modules made after construction
-                    rec._complexity_param_all_levels = copy.deepcopy(ec._complexity_param_all_levels)
-                    rec._num_complex_levels = ec._num_complex_levels
+            if hasattr(r, "named_modules"):
+                theirs = dict(r.named_modules())
+                for name, src in self.codec.named_modules():   # the codec itself, grouped members, their entropy coders
+                    dst = theirs.get(name)
+                    if dst is None:
+                        continue
+                    if hasattr(src, "_complexity_param_all_levels"):   # searched levels: modules made after construction
+                        dst._complexity_param_all_levels = copy.deepcopy(src._complexity_param_all_levels)
+                        dst._num_complex_levels = src._num_complex_levels
+                    for a in level_attrs:
+                        if hasattr(src, a):
+                            setattr(dst, a, getattr(src, a))
+                    if hasattr(dst, "_valid_host"):
+                        dst._valid_host = None
                 r.load_state_dict(self.codec.state_dict(), strict=False)
-                if rec is not None and hasattr(rec, "_valid_host"):
-                    rec._valid_host = None
-            for name in ("_current_complex_level", "_current_rate_level", "_current_task_idx"):
-                for src, dst in ((self.codec, r), (getattr(self.codec, "entropy_coder", None), getattr(r, "entropy_coder", None))):
-                    if src is not None and dst is not None and hasattr(src, name):
-                        setattr(dst, name, getattr(src, name))
+            else:
+                for a in level_attrs:
+                    if hasattr(self.codec, a):
+                        setattr(r, a, getattr(self.codec, a))
             r.update_state()
         return self._pool
 
