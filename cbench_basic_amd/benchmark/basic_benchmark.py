@@ -33,7 +33,7 @@ class BasicLosslessCompressionBenchmark:
                  nn_codec_use_forward_pass=False, nn_codec_forward_pass_skip_compression=False,
                  testing_variable_rate_levels=None, testing_variable_rate_bj_delta_metric=None,
                  testing_complexity_levels=None, force_testing_device="cuda", output_dir=None, num_repeats=1,
-                 num_testing_workers=0, codec_builder=None, **kwargs):
+                 num_testing_workers=0, codec_builder=None, worker_transform_token=None, **kwargs):
         self.codec = codec
         self.dataloader = dataloader
         self.distortion_metric = distortion_metric
@@ -49,6 +49,10 @@ class BasicLosslessCompressionBenchmark:
         self.metric_logger = MetricLogger()
         self.num_testing_workers = int(num_testing_workers or 0)
         self.codec_builder = codec_builder
+        # concurrent sessions with ordered MFMA phases + packed rANS workgroups: pays for batches (measured: 48
+        # images in batches of 8, 3 workers: 248 -> 297 MiB/s), costs at batch 1 where everything is latency (Kodak-shaped,
+        # 4 workers: 21.7 -> 13.8 Mpix/s).  None = on for batches of 8 or more
+        self.worker_transform_token = worker_transform_token
         if self.num_testing_workers > 1 and codec_builder is None:
             raise ValueError("num_testing_workers > 1 needs codec_builder: a callable returning a fresh codec of the same "
                              "architecture (every worker codes with its own replica; weights and levels are copied from `codec`)")
@@ -122,14 +126,20 @@ class BasicLosslessCompressionBenchmark:
             if dm is not None:
                 dm(decompressed, data_target)
 
-    def _worker_pool(self):
+    def _worker_pool(self, first_item=None):
         """The stream workers and their codec replicas, brought to the main codec's weights, levels and tables."""
         from .stream_workers import StreamWorkerPool
         if self._pool is None:
+            self._token_on = self.worker_transform_token if self.worker_transform_token is not None else \
+                bool(first_item is not None and hasattr(first_item, "shape") and len(first_item.shape) == 4 and first_item.shape[0] >= 8)
             def make():
                 c = self.codec_builder()
                 if hasattr(c, "eval"):
                     c.eval()
+                if self._token_on:
+                    for m in (c.modules() if hasattr(c, "modules") else []):   # concurrent sessions: ordered MFMA phases, packed rANS workgroups
+                        if hasattr(m, "fused_transform_token"):
+                            m.fused_transform_token, m.fused_rans_waves = True, 8
                 return c.to(self.force_testing_device or "cuda") if hasattr(c, "to") else c
             self._pool = StreamWorkerPool(make, self.num_testing_workers, torch.device(self.force_testing_device or "cuda"))
         level_attrs = ("_current_complex_level", "_current_rate_level", "_current_task_idx", "active_codec_idx")
@@ -163,7 +173,7 @@ class BasicLosslessCompressionBenchmark:
         t0 = time.time()
         if self.num_testing_workers > 1 and (self.force_testing_device or "cuda").startswith("cuda"):
             items = list(self.dataloader)
-            pool = self._worker_pool()
+            pool = self._worker_pool(items[0] if items else None)
             W = min(self.num_testing_workers, max(1, len(items)))
             base, extra = divmod(len(items), W)
             # contiguous index ranges as in the reference (:851-852), remainder spread (the reference drops len % W items)

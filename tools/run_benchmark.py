@@ -84,7 +84,7 @@ def main():
                                               num_testing_workers=args.workers,
                                               codec_builder=(lambda: presets.seed_synthetic_weights(builders[args.codec](), seed=0)) if args.workers > 1 else None)
     if args.workers > 1 and args.warmup:   # the replicas' one-time costs too, one replica at a time (HIP-graph capture)
-        pool = bench._worker_pool()
+        pool = bench._worker_pool(batches[0])
         for r, st in zip(pool.codecs, pool.streams):
             with torch.cuda.stream(st):
                 for lvl in (args.complexity_levels or [None]):
