@@ -402,3 +402,24 @@ def test_bench_gpus_flag_launches_children_or_refuses(monkeypatch):
     with pytest.raises(SystemExit) as e:
         bench.main()
     assert "WORLD_SIZE=2" in str(e.value.code)
+
+
+def test_ar_op_classes_evaluate_like_the_reference_binding():
+    """cbench.ans.ar_linear_op / ar_limited_scaled_add_linear_op are callable on the host (lib.cpp:20-25): float32 arithmetic
+    with the reference's operation order; vectors and results from the reference's compiled module (tests/golden/ar_ops_kat.npz)."""
+    import os
+    from cbench_basic_amd import ans
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ar_ops_kat.npz"), allow_pickle=False)
+    lim = ans.ar_limited_scaled_add_linear_op([0.37, -0.21], 0.4, 2.0, 0.0, 7.0)
+    lin = ans.ar_linear_op([1.0, 0.5, -0.25], 0.125, 2.0)
+    assert [lim(v.tolist()) for v in z["call.vectors"]] == z["call.limited"].tolist()
+    assert [lin(v.tolist()) for v in z["call.vectors"]] == z["call.linear"].tolist()
+    assert isinstance(lim, ans.ar_op_default) and isinstance(lin, ans.ar_op_default)
+
+
+def test_harness_workers_need_a_codec_builder():
+    from cbench_basic_amd.benchmark import BasicLosslessCompressionBenchmark
+    with pytest.raises(ValueError):
+        BasicLosslessCompressionBenchmark(object(), [], num_testing_workers=2)
+    b = BasicLosslessCompressionBenchmark(object(), [], num_testing_workers=2, codec_builder=lambda: object())
+    assert b.num_testing_workers == 2 and b._pool is None
