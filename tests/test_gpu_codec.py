@@ -74,7 +74,8 @@ def test_transforms_and_symbols(setup, shape):
         assert _rel(xhat.cpu(), xhat_ref) < 1e-4
 
 
-@pytest.mark.parametrize("shape", [(1, 3, 64, 64), (3, 3, 64, 96), (2, 3, 192, 128), (5, 3, 64, 64), (1, 3, 128, 256), (4, 3, 128, 64)])
+@pytest.mark.parametrize("shape", [(1, 3, 64, 64), (3, 3, 64, 96), (2, 3, 192, 128), (5, 3, 64, 64), (1, 3, 128, 256), (4, 3, 128, 64),
+                                   (1, 3, 70, 93), (2, 3, 129, 67)])   # the last two: sizes no layer divides evenly
 def test_compress_decompress_vs_oracle(setup, shape):
     from oracle.codec_oracle import psnr
     codec, oracle = setup
@@ -84,12 +85,15 @@ def test_compress_decompress_vs_oracle(setup, shape):
     assert isinstance(data, bytes)
     ref = oracle.compress(x)
     xhat = codec.decompress(data)
-    assert xhat.shape == x.shape and xhat.is_cuda
     xref = oracle.decompress(ref)
+    # sizes a stride-2 layer does not divide come back LARGER (4 x "2n" of ceil(n / 16)), as from the reference, which does not crop
+    # either (the distortion metric does, pytorch_distortion.py:12-15)
+    assert xhat.shape == xref.shape and xhat.is_cuda and (xhat.shape == x.shape or (shape[2] % 16 or shape[3] % 16))
     # cross decoding: the oracle decodes OUR stream to (nearly) our reconstruction
     xcross = oracle.decompress(data)
     assert _rel(xhat.cpu(), xcross) < 1e-3
-    assert float((psnr(xhat.cpu(), x) - psnr(xref, x)).abs().max()) < 0.01
+    crop = lambda t: t[..., : shape[2], : shape[3]]
+    assert float((psnr(crop(xhat.cpu()), x) - psnr(crop(xref), x)).abs().max()) < 0.01
     a = oracle.analyse(x)
     # byte-identical to the CPU oracle, or every difference is a located fp32 rounding tie (printed with -s)
     flips = _assert_identical_or_located_ties(codec, oracle, x, data, ref, a, f"shape {shape}")

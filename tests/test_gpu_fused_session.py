@@ -15,7 +15,7 @@ def codec():
     return c
 
 
-@pytest.mark.parametrize("shape", [(1, 3, 64, 64), (3, 3, 128, 192), (2, 3, 80, 112), (7, 3, 64, 64), (1, 3, 48, 272), (16, 3, 256, 256)])
+@pytest.mark.parametrize("shape", [(1, 3, 64, 64), (3, 3, 128, 192), (2, 3, 80, 112), (7, 3, 64, 64), (1, 3, 48, 272), (16, 3, 256, 256), (2, 3, 77, 131)])
 def test_fused_equals_module_path(codec, shape):
     ec = codec.entropy_coder
     torch.manual_seed(sum(shape))
