@@ -234,3 +234,52 @@ def test_custom_ar_ops_on_hip():
     enc.init_params(z["o1.freqs"], z["o1.nsym"], z["o1.offsets"])
     with pytest.raises(TypeError):
         enc.init_custom_ar_ops([lin])
+
+
+def test_tans_full_size_round_trip_property():
+    """BASELINE configs[4] size through the batched tANS entry points: 256 image streams x 49,152 symbols over 64 distributions
+    (table_log 12, bypass coding on), encode -> decode == input; stream 0 equals the one-stream drop-in (which is pinned to the
+    reference by the known answers).  Prints the kernel rates."""
+    import time
+    from cbench_basic_amd import _lib, ans
+    rng = np.random.default_rng(77)
+    L, nd, ns, S, n = 12, 64, 64, 256, 49152
+    freqs = rng.integers(1, 1024, (nd, ns)).astype(np.int32)
+    nsym, off = np.full(nd, ns, np.int32), np.zeros(nd, np.int32)
+    enc, dec = ans.TansEncoder(L, 255, True, 4), ans.TansDecoder(L, 255, True, 4)
+    enc.init_params(freqs, nsym, off)
+    dec.init_params(freqs, nsym, off)
+    dev = torch.device("cuda")
+    sym = torch.from_numpy(rng.integers(-2, ns + 2, (S, n)).astype(np.int32)).to(dev)
+    idx = torch.from_numpy(rng.integers(0, nd, (S, n)).astype(np.int32)).to(dev)
+    seg = torch.arange(0, (S + 1) * n, n, dtype=torch.int64, device=dev)
+    lib = _lib.lib()
+    slot = int(lib.basic_tans_encode_bound_words(enc._tables, n))
+    words = torch.zeros(S * slot, dtype=torch.int32, device=dev)
+    info = torch.zeros(S * 2, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    _lib.check(lib.basic_tans_encode_batch_dev(enc._tables, sym.data_ptr(), idx.data_ptr(), seg.data_ptr(), S, words.data_ptr(), slot,
+                                               info.data_ptr(), None))
+    torch.cuda.synchronize()
+    t_enc = time.time() - t0
+    bits = info.cpu().numpy().reshape(S, 2)[:, 0]
+    assert (bits > 0).all()
+    nbytes = (bits + 7) // 8
+    host = words.cpu().numpy().view(np.uint8).reshape(S, slot * 4)
+    streams = [host[i, : nbytes[i]].tobytes() for i in range(S)]
+    one, _ = enc._encode(sym[0].cpu().numpy(), idx[0].cpu().numpy(), None, None, 1 << 40)
+    assert streams[0] == one
+    blob = torch.from_numpy(np.frombuffer(b"".join(streams), np.uint8).copy()).to(dev)
+    boff = torch.from_numpy(np.concatenate([[0], np.cumsum(nbytes)]).astype(np.int64)).to(dev)
+    out = torch.zeros_like(sym)
+    status = torch.full((S,), -1, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    _lib.check(lib.basic_tans_decode_batch_dev(dec._tables, blob.data_ptr(), boff.data_ptr(), idx.data_ptr(), seg.data_ptr(), S,
+                                               out.data_ptr(), status.data_ptr(), None))
+    torch.cuda.synchronize()
+    t_dec = time.time() - t0
+    assert int(status.abs().sum()) == 0 and torch.equal(out, sym)
+    print(f"tANS, 256 streams x 49,152 symbols: encode {t_enc * 1e3:.1f} ms ({t_enc / n * 1e9:.0f} ns per symbol and stream), "
+          f"decode {t_dec * 1e3:.1f} ms ({t_dec / n * 1e9:.0f} ns), {nbytes.sum() / S / n * 8:.2f} bits per symbol")
