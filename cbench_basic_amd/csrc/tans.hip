@@ -16,6 +16,7 @@
 #include "common.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -263,6 +264,7 @@ struct TansDev {
     const uint32_t *dec;
     const int2 *rowinfo;
     int rows, log, bypass, bypass_precision, max_nsym;
+    int lds_words;           // > 0: the state-dependent image (encoder: next, decoder: dec) is copied to LDS by every workgroup
     const int32_t *ar_tab;   // nullptr = no AR remap
     int ar_k, ar_order, ar_s1;
     const int32_t *ar_indexes, *off0, *off1;
@@ -334,6 +336,13 @@ __global__ __launch_bounds__(64) void tans_encode_kernel(TansDev T, const int32_
                                                          const int64_t *__restrict__ seg, uint32_t *out_words, int64_t slot_words,
                                                          int64_t *out_info)
 {
+    extern __shared__ uint32_t tans_lds[];
+    if (T.lds_words > 0) {   // a lookup that depends on the previous state then costs an LDS access instead of an L2 round trip
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(T.next);
+        for (int e = threadIdx.x; e < T.lds_words; e += 64) tans_lds[e] = src[e];
+        __syncthreads();
+        T.next = reinterpret_cast<const uint16_t *>(tans_lds);
+    }
     const int stream = blockIdx.x, lane = threadIdx.x;
     const int64_t beg = seg[stream], n = seg[stream + 1] - beg;
     const int32_t *sym = symbols + beg, *idx = indexes + beg;
@@ -443,6 +452,12 @@ __global__ __launch_bounds__(64) void tans_decode_kernel(TansDev T, const uint8_
                                                          const int32_t *__restrict__ indexes, const int64_t *__restrict__ seg,
                                                          int32_t *out_symbols, int32_t *status)
 {
+    extern __shared__ uint32_t tans_lds[];
+    if (T.lds_words > 0) {
+        for (int e = threadIdx.x; e < T.lds_words; e += 64) tans_lds[e] = T.dec[e];
+        __syncthreads();
+        T.dec = tans_lds;
+    }
     const int stream = blockIdx.x, lane = threadIdx.x;
     const int64_t beg = seg[stream], n = seg[stream + 1] - beg;
     const int32_t *idx = indexes + beg;
@@ -511,6 +526,14 @@ __global__ __launch_bounds__(64) void tans_decode_kernel(TansDev T, const uint8_
     if (lane == 0) status[stream] = 0;
 }
 
+// bytes of the state-dependent image when it fits a workgroup's LDS (else 0): encoder 2 bytes, decoder 4 bytes per state and row
+size_t tans_lds_bytes(const basic_tans_tables *t, bool decoder)
+{
+    const size_t rows = static_cast<size_t>(t->rows) + (t->bypass ? 1 : 0);
+    const size_t bytes = rows * (size_t{1} << t->log) * (decoder ? 4 : 2);
+    return bytes <= 144 * 1024 && !std::getenv("BASIC_TANS_NO_LDS") ? bytes : 0;
+}
+
 TansDev dev_view(const basic_tans_tables *t)
 {
     TansDev T{};
@@ -538,7 +561,11 @@ extern "C" int basic_tans_encode_batch_dev(const basic_tans_tables *t, const int
     BASIC_REQUIRE(!t->d_ar, "tans_encode_batch_dev: AR remap needs the host entry point (per-element AR arrays)");
     BASIC_REQUIRE(nstreams >= 0 && slot_words >= 1 && d_seg && d_out_words && d_out_info, "tans_encode_batch_dev: bad argument");
     if (nstreams == 0) return BASIC_OK;
-    hipLaunchKernelGGL(tans_encode_kernel, dim3(nstreams), dim3(64), 0, as_stream(hip_stream), dev_view(t), d_symbols, d_indexes, d_seg,
+    TansDev T = dev_view(t);
+    const size_t lds = tans_lds_bytes(t, false);
+    T.lds_words = static_cast<int>(lds / 4);
+    if (lds > 48 * 1024) BASIC_HIP_TRY(ensure_max_lds(reinterpret_cast<const void *>(tans_encode_kernel)));
+    hipLaunchKernelGGL(tans_encode_kernel, dim3(nstreams), dim3(64), lds, as_stream(hip_stream), T, d_symbols, d_indexes, d_seg,
                        d_out_words, slot_words, d_out_info);
     BASIC_HIP_TRY(hipGetLastError());
     return BASIC_OK;
@@ -552,7 +579,11 @@ extern "C" int basic_tans_decode_batch_dev(const basic_tans_tables *t, const uin
     BASIC_REQUIRE(!t->d_ar, "tans_decode_batch_dev: AR remap needs the host entry point (per-element AR arrays)");
     BASIC_REQUIRE(nstreams >= 0 && d_bytes && d_byte_off && d_seg && d_out_symbols && d_status, "tans_decode_batch_dev: bad argument");
     if (nstreams == 0) return BASIC_OK;
-    hipLaunchKernelGGL(tans_decode_kernel, dim3(nstreams), dim3(64), 0, as_stream(hip_stream), dev_view(t), d_bytes, d_byte_off, d_indexes,
+    TansDev T = dev_view(t);
+    const size_t lds = tans_lds_bytes(t, true);
+    T.lds_words = static_cast<int>(lds / 4);
+    if (lds > 48 * 1024) BASIC_HIP_TRY(ensure_max_lds(reinterpret_cast<const void *>(tans_decode_kernel)));
+    hipLaunchKernelGGL(tans_decode_kernel, dim3(nstreams), dim3(64), lds, as_stream(hip_stream), T, d_bytes, d_byte_off, d_indexes,
                        d_seg, d_out_symbols, d_status);
     BASIC_HIP_TRY(hipGetLastError());
     return BASIC_OK;
@@ -618,7 +649,10 @@ extern "C" int basic_tans_encode_host(const basic_tans_tables *t, const int32_t 
     TansDev T = dev_view(t);
     int rc = stage_ar(t, T, n, ar_indexes, ar_off0, ar_off1, b_ai, b_o0, b_o1);
     if (rc) return rc;
-    hipLaunchKernelGGL(tans_encode_kernel, dim3(1), dim3(64), 0, nullptr, T, b_sym.as<int32_t>(), b_idx.as<int32_t>(), b_seg.as<int64_t>(),
+    const size_t lds = n >= 2048 ? tans_lds_bytes(t, false) : 0;   // short streams: the copy would cost more than it saves
+    T.lds_words = static_cast<int>(lds / 4);
+    if (lds > 48 * 1024) BASIC_HIP_TRY(ensure_max_lds(reinterpret_cast<const void *>(tans_encode_kernel)));
+    hipLaunchKernelGGL(tans_encode_kernel, dim3(1), dim3(64), lds, nullptr, T, b_sym.as<int32_t>(), b_idx.as<int32_t>(), b_seg.as<int64_t>(),
                        b_out.as<uint32_t>(), slot_words, b_info.as<int64_t>());
     BASIC_HIP_TRY(hipGetLastError());
     int64_t info[2] = {0, 0};
@@ -658,7 +692,10 @@ extern "C" int basic_tans_decode_host(const basic_tans_tables *t, const uint8_t 
     TansDev T = dev_view(t);
     int rc = stage_ar(t, T, n, ar_indexes, ar_off0, ar_off1, b_ai, b_o0, b_o1);
     if (rc) return rc;
-    hipLaunchKernelGGL(tans_decode_kernel, dim3(1), dim3(64), 0, nullptr, T, b_bytes.as<uint8_t>(), b_boff.as<int64_t>(), b_idx.as<int32_t>(),
+    const size_t lds = n >= 2048 ? tans_lds_bytes(t, true) : 0;
+    T.lds_words = static_cast<int>(lds / 4);
+    if (lds > 48 * 1024) BASIC_HIP_TRY(ensure_max_lds(reinterpret_cast<const void *>(tans_decode_kernel)));
+    hipLaunchKernelGGL(tans_decode_kernel, dim3(1), dim3(64), lds, nullptr, T, b_bytes.as<uint8_t>(), b_boff.as<int64_t>(), b_idx.as<int32_t>(),
                        b_seg.as<int64_t>(), b_out.as<int32_t>(), b_status.as<int32_t>());
     BASIC_HIP_TRY(hipGetLastError());
     int32_t status = 0;
