@@ -294,12 +294,11 @@ struct BitSink {
     int64_t cap_words, nwords;
     uint64_t acc;        // pending bits, low `fill` valid
     uint32_t fill;
-    int64_t total_bits;
+    int64_t total_bits;  // set by finish()
     __device__ __forceinline__ void put(uint32_t value, uint32_t nbits, int lane)
     {
         acc |= static_cast<uint64_t>(value & ((1u << nbits) - 1u)) << fill;   // nbits <= 16
         fill += nbits;
-        total_bits += nbits;
         if (fill >= 32u) {
             if (lane == 0 && nwords < cap_words) words[nwords] = static_cast<uint32_t>(acc);
             ++nwords;
@@ -309,6 +308,7 @@ struct BitSink {
     }
     __device__ __forceinline__ void finish(int lane)
     {
+        total_bits = nwords * 32 + fill;
         if (fill) {
             if (lane == 0 && nwords < cap_words) words[nwords] = static_cast<uint32_t>(acc);
             ++nwords;
@@ -316,19 +316,20 @@ struct BitSink {
     }
 };
 
-__device__ __forceinline__ void tans_step(const TansDev &T, BitSink &sink, uint32_t &state, uint32_t row, uint32_t dbits, int32_t dstate, int lane)
+// tbase = (row << log) + the symbol's group start - its count: the lookup index is tbase + (state >> nb), inside the row's 2^log
+// entries for every state in [2^log, 2^(log+1)) by the tables' construction (symbols without mass point at entry 1).
+__device__ __forceinline__ void tans_step(const TansDev &T, BitSink &sink, uint32_t &state, uint32_t dbits, uint32_t tbase, int lane)
 {   // Tans_encodeSymbol, tans.cpp:245-252
     const uint32_t nb = (state + dbits) >> 16;
     sink.put(state, nb, lane);
-    const int32_t at = clampi(static_cast<int32_t>(state >> nb) + dstate, 0, (1 << T.log) - 1);
-    state = T.next[(static_cast<size_t>(row) << T.log) + at];
+    state = T.next[tbase + (state >> nb)];
     state = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(state)));
 }
 
 __device__ __forceinline__ void tans_step_bypass(const TansDev &T, BitSink &sink, uint32_t &state, uint32_t v, int lane)
 {
     const uint2 e = T.sym[static_cast<size_t>(T.rows) * T.max_nsym + v];
-    tans_step(T, sink, state, static_cast<uint32_t>(T.rows), e.x, static_cast<int32_t>(e.y), lane);
+    tans_step(T, sink, state, e.x, (static_cast<uint32_t>(T.rows) << T.log) + e.y, lane);
 }
 
 // One wavefront per stream.  out_info[stream] = { total bits incl. final state and end mark, coded symbols incl. bypass }.
@@ -352,7 +353,7 @@ __global__ __launch_bounds__(64) void tans_encode_kernel(TansDev T, const int32_
     const uint32_t bprec = static_cast<uint32_t>(T.bypass_precision), maxbv = (1u << bprec) - 1u;
     for (int64_t hi = n; hi > 0; hi -= 64) {
         const int64_t i = hi - 64 + lane;   // lane 63 holds the chunk's last symbol
-        uint32_t row_l = 0, dbits = 0, dstate = 0, raw = 0;
+        uint32_t dbits = 0, tbase = 0, raw = 0;
         bool is_bypass = false;
         if (i >= 0) {
             int32_t row = idx[i];
@@ -376,7 +377,7 @@ __global__ __launch_bounds__(64) void tans_encode_kernel(TansDev T, const int32_
             else if (value >= max_value) { raw = static_cast<uint32_t>(2 * (value - max_value)); value = max_value; }
             is_bypass = T.bypass && value == max_value;
             const uint2 e = T.sym[static_cast<size_t>(row) * T.max_nsym + value];
-            row_l = static_cast<uint32_t>(row); dbits = e.x; dstate = e.y;
+            dbits = e.x; tbase = (static_cast<uint32_t>(row) << T.log) + e.y;   // e.y is an int32 offset: unsigned wrap-around adds it
         }
         const uint64_t bypass_mask = __ballot(is_bypass);
         const int j_lo = hi >= 64 ? 0 : static_cast<int>(64 - hi);
@@ -391,7 +392,7 @@ __global__ __launch_bounds__(64) void tans_encode_kernel(TansDev T, const int32_
                 for (uint32_t k = 0; k < static_cast<uint32_t>(nb) / maxbv; ++k) tans_step_bypass(T, sink, state, maxbv, lane);
                 coded += nb + 1 + static_cast<int>(static_cast<uint32_t>(nb) / maxbv);
             }
-            tans_step(T, sink, state, bcast(row_l, j), bcast(dbits, j), static_cast<int32_t>(bcast(dstate, j)), lane);
+            tans_step(T, sink, state, bcast(dbits, j), bcast(tbase, j), lane);
             ++coded;
         }
     }
