@@ -37,8 +37,35 @@ class TimeProfiler:
         return {k: self.total[k] / max(1, self.count[k]) for k in self.total}
 
 
+class TorchCheckpointLoader:
+    """cbench/nn/base.py:175-196: load a ``torch.save``d state_dict into a module -- optional ``key`` (sub-dict of the
+    file), ``prefix`` (stripped from the keys that carry it), ``filter_keys`` (dropped; a missing one is a KeyError as in the
+    reference), ``strict``.  Returns what ``load_state_dict`` returns."""
+
+    def __init__(self, checkpoint_file, *args, strict=True, key=None, prefix=None, filter_keys=None, map_location="cpu", **kwargs):
+        self.checkpoint_file = checkpoint_file
+        self.strict = strict
+        self.key = key
+        self.prefix = prefix
+        self.filter_keys = filter_keys
+        self.map_location = map_location
+
+    def load(self, model: nn.Module):
+        state_dict = torch.load(self.checkpoint_file, map_location=self.map_location)
+        if self.key is not None:
+            state_dict = state_dict[self.key]
+        if self.prefix is not None:
+            state_dict = {(k[len(self.prefix):] if k.startswith(self.prefix) else k): v for k, v in state_dict.items()}
+        if self.filter_keys is not None:
+            for name in self.filter_keys:
+                state_dict.pop(name)
+        return model.load_state_dict(state_dict, strict=self.strict)
+
+
 class HotPathModule(nn.Module):
     """nn.Module + profiler + caches.  Equivalent of NNTrainableModule for inference."""
+
+    checkpoint_loader = None   # NNTrainableModule's constructor argument (nn/base.py:461-470); set it or pass one to load_checkpoint
 
     _CACHE_NAMES = ("loss_dict", "metric_dict", "moniter_dict", "hist_dict", "image_dict")
 
@@ -91,6 +118,20 @@ class HotPathModule(nn.Module):
         if clear:
             self.profiler.reset()
         return out
+
+    def load_checkpoint(self, checkpoint_loader=None):
+        """NNTrainableModule.load_checkpoint (nn/base.py:507-519): a path is loaded non-strictly, a TorchCheckpointLoader
+        with its own settings, None falls back to ``self.checkpoint_loader`` (no-op when that is None too).  Tables are
+        the caller's next ``update_state()`` as in the reference."""
+        if checkpoint_loader is None:
+            checkpoint_loader = self.checkpoint_loader
+        if checkpoint_loader is None:
+            return None
+        if isinstance(checkpoint_loader, str):
+            return self.load_state_dict(torch.load(checkpoint_loader, map_location="cpu"), strict=False)
+        if isinstance(checkpoint_loader, TorchCheckpointLoader):
+            return checkpoint_loader.load(self)
+        raise ValueError("Unsupported checkpoint_loader!")
 
     # ---- harness protocol
     def post_training_process(self, *args, **kwargs):

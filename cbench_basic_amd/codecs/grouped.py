@@ -105,3 +105,9 @@ class GroupedVariableRateCodec(HotPathModule, CodecInterface, VariableRateCodecI
         for codec in self.codecs:
             if hasattr(codec, "post_training_process"):
                 codec.post_training_process(*args, **kwargs)
+
+    def load_checkpoint(self, checkpoint_loader=None):   # codecs/base.py:239-243: members first, then the group's own
+        for codec in self.codecs:
+            if hasattr(codec, "load_checkpoint"):
+                codec.load_checkpoint()
+        return super().load_checkpoint(checkpoint_loader)

@@ -95,8 +95,16 @@ def _pmf_to_cdf(pmf, tail_mass, pmf_length, max_length, precision=16):
 
 
 class EntropyBottleneck(nn.Module):
-    """Parameter holder + table builder of the factorised prior (Balle et al. 2018), with
-    CompressAI 1.2.3's parameter names (matrices.N / biases.N / factors.N / quantiles)."""
+    """Parameter holder + table builder of the factorised prior (Balle et al. 2018).
+
+    Parameter names: ``_matrixN / _biasN / _factorN / quantiles`` -- the layout the reference's own checkpoint converter
+    writes under ``latent_node_entropy_coders.z.entropy_bottleneck`` (tools/compressai_checkpoint_to_cbench.py:16-25,
+    139-152: "nn.ParameterList to nn.Parameters") and the registration order of the pinned compressai 1.2.3
+    (requirements.txt:15).  ``state_dict()`` emits these names; ``load_state_dict`` also accepts the ParameterList spelling
+    of later compressai releases (``matrices.N / biases.N / factors.N`` and the zoo files' ``_matrices.N`` ...)."""
+
+    _LIST_NAMES = (("matrices.", "_matrix"), ("biases.", "_bias"), ("factors.", "_factor"),
+                   ("_matrices.", "_matrix"), ("_biases.", "_bias"), ("_factors.", "_factor"))
 
     def __init__(self, channels, tail_mass=1e-9, init_scale=10, filters=(3, 3, 3, 3)):
         super().__init__()
@@ -104,6 +112,8 @@ class EntropyBottleneck(nn.Module):
         self.filters = tuple(int(f) for f in filters)
         self.init_scale = float(init_scale)
         self.tail_mass = float(tail_mass)
+        self.likelihood_lower_bound = nn.Module()   # LowerBound(likelihood_bound) of EntropyModel (upstream)
+        self.likelihood_lower_bound.register_buffer("bound", torch.Tensor([1e-9]))
         # EntropyModel's registered buffers (upstream): empty until update(); resized on load like
         # compressai.models.utils.update_registered_buffers does
         self.register_buffer("_offset", torch.IntTensor())
@@ -111,24 +121,32 @@ class EntropyBottleneck(nn.Module):
         self.register_buffer("_cdf_length", torch.IntTensor())
         f = (1,) + self.filters + (1,)
         scale = self.init_scale ** (1 / (len(self.filters) + 1))
-        self.matrices, self.biases, self.factors = nn.ParameterList(), nn.ParameterList(), nn.ParameterList()
         for i in range(len(self.filters) + 1):
             init = np.log(np.expm1(1 / scale / f[i + 1]))
-            self.matrices.append(nn.Parameter(torch.full((channels, f[i + 1], f[i]), float(init))))
-            self.biases.append(nn.Parameter(torch.empty(channels, f[i + 1], 1).uniform_(-0.5, 0.5)))
+            self.register_parameter(f"_matrix{i:d}", nn.Parameter(torch.full((channels, f[i + 1], f[i]), float(init))))
+            self.register_parameter(f"_bias{i:d}", nn.Parameter(torch.empty(channels, f[i + 1], 1).uniform_(-0.5, 0.5)))
             if i < len(self.filters):
-                self.factors.append(nn.Parameter(torch.zeros(channels, f[i + 1], 1)))
+                self.register_parameter(f"_factor{i:d}", nn.Parameter(torch.zeros(channels, f[i + 1], 1)))
         self.quantiles = nn.Parameter(torch.tensor([-self.init_scale, 0.0, self.init_scale]).repeat(channels, 1, 1))
         target = np.log(2 / self.tail_mass - 1)
         self.register_buffer("target", torch.Tensor([-target, 0, target]))
-        self.likelihood_lower_bound = nn.Module()   # LowerBound(likelihood_bound) of EntropyModel (upstream)
-        self.likelihood_lower_bound.register_buffer("bound", torch.Tensor([1e-9]))
-        # parameters first, then the ParameterLists: the reference's key order
-        mats, bias, fact = self.matrices, self.biases, self.factors
-        del self.matrices, self.biases, self.factors
-        self.matrices, self.biases, self.factors = mats, bias, fact
+
+    @property
+    def matrices(self):
+        return [getattr(self, f"_matrix{i:d}") for i in range(len(self.filters) + 1)]
+
+    @property
+    def biases(self):
+        return [getattr(self, f"_bias{i:d}") for i in range(len(self.filters) + 1)]
+
+    @property
+    def factors(self):
+        return [getattr(self, f"_factor{i:d}") for i in range(len(self.filters))]
 
     def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        for old, new in self._LIST_NAMES:                            # ParameterList spellings -> _matrixN / _biasN / _factorN
+            for key in [k for k in state_dict if k.startswith(prefix + old) and k[len(prefix + old):].isdigit()]:
+                state_dict[prefix + new + key[len(prefix + old):]] = state_dict.pop(key)
         for name in ("_offset", "_quantized_cdf", "_cdf_length"):   # table buffers take the checkpoint's size
             v = state_dict.get(prefix + name)
             if v is not None and v.shape != getattr(self, name).shape:
@@ -162,8 +180,11 @@ class EntropyBottleneck(nn.Module):
         assert coef.shape[1] == 58
         return coef.contiguous()
 
-    def build_tables(self):
-        """EntropyBottleneck.update() (upstream): returns (cdf int32 [C, L], cdf_length, offset)."""
+    def update(self, force=False):
+        """EntropyBottleneck.update() (upstream): tables already present -- from an earlier update or a loaded checkpoint -- are
+        kept unless ``force`` (compressai_coder.py:131-151 calls it with force=False).  Returns True when rebuilt."""
+        if self._offset.numel() > 0 and not force:
+            return False
         with torch.no_grad():
             q = self.quantiles.detach().float().cpu()
             medians = q[:, 0, 1]
@@ -184,7 +205,16 @@ class EntropyBottleneck(nn.Module):
         self._offset = offset.to(dev)
         self._quantized_cdf = torch.from_numpy(cdf).to(dev)
         self._cdf_length = (pmf_length + 2).to(dev)
-        return cdf, (pmf_length + 2).numpy().astype(np.int32), offset.numpy().astype(np.int32)
+        return True
+
+    def host_tables(self):
+        """(cdf int32 [C, L], cdf_length, offset) of the current table buffers."""
+        return (self._quantized_cdf.cpu().numpy().astype(np.int32), self._cdf_length.cpu().numpy().astype(np.int32).reshape(-1),
+                self._offset.cpu().numpy().astype(np.int32).reshape(-1))
+
+    def build_tables(self):
+        self.update(force=True)
+        return self.host_tables()
 
 
 class CompressAIEntropyBottleneckPriorCoder(HotPathModule):
@@ -204,8 +234,9 @@ class CompressAIEntropyBottleneckPriorCoder(HotPathModule):
         if self._medians_dev is None or self._medians_dev.device != self.device:
             self._medians_dev = self.entropy_bottleneck.medians().to(self.device).contiguous()
 
-    def update_state(self, *args, **kwargs) -> None:  # :247-248 -> EntropyBottleneck.update()
-        cdf, lengths, offsets = self.entropy_bottleneck.build_tables()
+    def update_state(self, *args, force=False, **kwargs) -> None:  # :247-248 -> self.update(force) -> EntropyBottleneck.update(force)
+        self.entropy_bottleneck.update(force=force)
+        cdf, lengths, offsets = self.entropy_bottleneck.host_tables()
         self._tables = K.RansTables(cdfs=cdf, cdf_sizes=lengths, offsets=offsets, precision=16, bypass=True, bypass_precision=4)
         self._cdf_host = (cdf, lengths, offsets)
         self._medians_dev = None
@@ -304,18 +335,69 @@ def gaussian_conditional_tables(scale_table: torch.Tensor, tail_mass=1e-9):
     return cdf, (pmf_length + 2).numpy().astype(np.int32), (-pmf_center).numpy().astype(np.int32)
 
 
+class GaussianConditional(nn.Module):
+    """State holder of the y-coder's ``gaussian_conditional`` (compressai_coder.py:345: ``GaussianConditional(None)``): the
+    buffers that travel in the reference's checkpoints -- EntropyModel's ``_offset / _quantized_cdf / _cdf_length`` plus
+    ``scale_table`` and ``scale_bound`` and the two LowerBound children -- empty until ``update_state()`` and resized to the
+    checkpoint's on load exactly as compressai_coder.py:298-319 does with update_registered_buffers."""
+
+    def __init__(self, scale_bound=0.11, tail_mass=1e-9, likelihood_bound=1e-9):
+        super().__init__()
+        self.tail_mass = float(tail_mass)
+        self.likelihood_lower_bound = nn.Module()
+        self.likelihood_lower_bound.register_buffer("bound", torch.Tensor([float(likelihood_bound)]))
+        self.register_buffer("_offset", torch.IntTensor())
+        self.register_buffer("_quantized_cdf", torch.IntTensor())
+        self.register_buffer("_cdf_length", torch.IntTensor())
+        self.lower_bound_scale = nn.Module()
+        self.lower_bound_scale.register_buffer("bound", torch.Tensor([float(scale_bound)]))
+        self.register_buffer("scale_table", torch.Tensor())
+        self.register_buffer("scale_bound", torch.Tensor([float(scale_bound)]))
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        for name in ("_quantized_cdf", "_offset", "_cdf_length", "scale_table"):
+            v = state_dict.get(prefix + name)
+            if v is not None and v.shape != getattr(self, name).shape:
+                cur = getattr(self, name)
+                setattr(self, name, torch.zeros(v.shape, dtype=cur.dtype, device=cur.device))
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
+    def update_scale_table(self, scale_table, force=False):
+        """GaussianConditional.update_scale_table (upstream): tables already present (an earlier update or a loaded
+        checkpoint) are kept unless ``force``.  Returns True when the tables were rebuilt."""
+        if self._offset.numel() > 0 and not force:
+            return False
+        dev = self.scale_table.device
+        self.scale_table = scale_table.float().to(dev)
+        cdf, lengths, offsets = gaussian_conditional_tables(self.scale_table, self.tail_mass)
+        self._quantized_cdf = torch.from_numpy(cdf).to(dev)
+        self._cdf_length = torch.from_numpy(lengths).to(dev)
+        self._offset = torch.from_numpy(offsets).to(dev)
+        return True
+
+    def host_tables(self):
+        return (self._quantized_cdf.cpu().numpy().astype(np.int32), self._cdf_length.cpu().numpy().astype(np.int32).reshape(-1),
+                self._offset.cpu().numpy().astype(np.int32).reshape(-1))
+
+
 class CompressAIGaussianConditionalCoder(HotPathModule):
     """compressai_coder.py:341-397: zero-mean Gaussian with hyperprior scales."""
 
     def __init__(self, use_bit_rate_loss=True, training_output_straight_through=False, scale_bound=0.11, **kwargs):
         super().__init__()
+        self.gaussian_conditional = GaussianConditional(scale_bound=scale_bound)
         self.scale_bound = float(scale_bound)
         self._tables = None
         self._scale_table_dev = None
 
-    def update_state(self, *args, **kwargs) -> None:  # :395-397
-        self.scale_table = get_scale_table()
-        cdf, lengths, offsets = gaussian_conditional_tables(self.scale_table)
+    @property
+    def scale_table(self):
+        return self.gaussian_conditional.scale_table
+
+    def update_state(self, *args, force=False, **kwargs) -> None:  # :395-397 -> update_scale_table(get_scale_table())
+        gc = self.gaussian_conditional
+        gc.update_scale_table(get_scale_table(), force=force)
+        cdf, lengths, offsets = gc.host_tables()
         self._tables = K.RansTables(cdfs=cdf, cdf_sizes=lengths, offsets=offsets, precision=16, bypass=True, bypass_precision=4)
         self._cdf_host = (cdf, lengths, offsets)
         self._scale_table_dev = None

@@ -168,7 +168,7 @@ def seed_synthetic_weights(codec, seed=0, y_std=0.5):
                 p.copy_((torch.rand(p.shape, generator=g) * 2 - 1) * (3.0 / fan_in) ** 0.5)
             elif name.endswith(".bias") and (".model." in name or ".pgm_model." in name):
                 p.copy_((torch.rand(p.shape, generator=g) * 2 - 1) * 0.05)
-            elif ".entropy_bottleneck.biases." in name:
+            elif ".entropy_bottleneck._bias" in name:
                 # the constructor draws these from the GLOBAL generator (uniform(-.5, .5), as upstream): redraw them from
                 # the seeded one, or two codecs built by the same call would code z with different tables
                 p.copy_(torch.rand(p.shape, generator=g) - 0.5)

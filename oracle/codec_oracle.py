@@ -95,9 +95,9 @@ def eb_tables(sd, prefix, n_filters=4):
 
     def logits(v):
         for i in range(n_filters + 1):
-            v = torch.matmul(F.softplus(sd[f"{prefix}matrices.{i}"].float()), v) + sd[f"{prefix}biases.{i}"].float()
+            v = torch.matmul(F.softplus(sd[f"{prefix}_matrix{i}"].float()), v) + sd[f"{prefix}_bias{i}"].float()
             if i < n_filters:
-                v = v + torch.tanh(sd[f"{prefix}factors.{i}"].float()) * torch.tanh(v)
+                v = v + torch.tanh(sd[f"{prefix}_factor{i}"].float()) * torch.tanh(v)
         return v
 
     lower, upper = logits(samples - 0.5), logits(samples + 0.5)
@@ -185,6 +185,7 @@ class HyperpriorOracle:
 
     def compress(self, x):
         a = self.analyse(x)
+        self.last = a
         B, C = a["z"].shape[:2]
         z_idx = torch.arange(C, dtype=torch.int32).reshape(1, C, 1, 1).expand_as(a["z_sym"])
         z_strings = [self.z_enc.encode_with_indexes(a["z_sym"][b].numpy(), z_idx[b].numpy()) for b in range(B)]
@@ -207,6 +208,12 @@ class HyperpriorOracle:
         y_hat = torch.stack([torch.from_numpy(self.y_dec.decode_with_indexes(s, y_idx[b].numpy())) for b, s in enumerate(y_strings)]).float()
         return self.g_s(y_hat)
 
+    def forward_entropies(self, x):
+        """Eval forward()'s rate terms (compressai_coder.py:203-228,352-375): nats per image for y and z."""
+        a = self.analyse(x)
+        return dict(y=float(gc_entropy(a["y"], a["scales"])),
+                    z=float(eb_entropy(self.sd, "latent_node_entropy_coders.z.entropy_bottleneck.", a["z"])))
+
 
 def gc_entropy(y, scales, bound=0.11, lik_bound=1e-9):
     """GaussianConditional forward's -sum log likelihood / batch (upstream _likelihood, compressai_coder.py:352-375)."""
@@ -226,9 +233,9 @@ def eb_entropy(sd, prefix, z, lik_bound=1e-9, n_filters=4):
 
     def logits(t):
         for i in range(n_filters + 1):
-            t = torch.matmul(F.softplus(sd[f"{prefix}matrices.{i}"]), t) + sd[f"{prefix}biases.{i}"]
+            t = torch.matmul(F.softplus(sd[f"{prefix}_matrix{i}"]), t) + sd[f"{prefix}_bias{i}"]
             if i < n_filters:
-                t = t + torch.tanh(sd[f"{prefix}factors.{i}"]) * torch.tanh(t)
+                t = t + torch.tanh(sd[f"{prefix}_factor{i}"]) * torch.tanh(t)
         return t
 
     lower, upper = logits(v - 0.5), logits(v + 0.5)

@@ -218,13 +218,14 @@ class EntropyBottleneck(EntropyModel):
         self.init_scale, self.tail_mass = float(init_scale), float(tail_mass)
         filters = (1,) + self.filters + (1,)
         scale = self.init_scale ** (1 / (len(self.filters) + 1))
-        self.matrices, self.biases, self.factors = nn.ParameterList(), nn.ParameterList(), nn.ParameterList()
+        # nn.Parameters named _matrixN / _biasN / _factorN: the layout the reference's converter writes for its pinned
+        # compressai (tools/compressai_checkpoint_to_cbench.py:16-25 "nn.ParameterList to nn.Parameters")
         for i in range(len(self.filters) + 1):
             init = np.log(np.expm1(1 / scale / filters[i + 1]))
-            self.matrices.append(nn.Parameter(torch.full((channels, filters[i + 1], filters[i]), float(init))))
-            self.biases.append(nn.Parameter(torch.empty(channels, filters[i + 1], 1).uniform_(-0.5, 0.5)))
+            self.register_parameter(f"_matrix{i:d}", nn.Parameter(torch.full((channels, filters[i + 1], filters[i]), float(init))))
+            self.register_parameter(f"_bias{i:d}", nn.Parameter(torch.empty(channels, filters[i + 1], 1).uniform_(-0.5, 0.5)))
             if i < len(self.filters):
-                self.factors.append(nn.Parameter(torch.zeros(channels, filters[i + 1], 1)))
+                self.register_parameter(f"_factor{i:d}", nn.Parameter(torch.zeros(channels, filters[i + 1], 1)))
         self.quantiles = nn.Parameter(torch.Tensor([-self.init_scale, 0, self.init_scale]).repeat(channels, 1, 1))
         target = np.log(2 / self.tail_mass - 1)
         self.register_buffer("target", torch.Tensor([-target, 0, target]))
@@ -241,9 +242,9 @@ class EntropyBottleneck(EntropyModel):
     def _logits_cumulative(self, inputs, stop_gradient=True):
         logits = inputs
         for i in range(len(self.filters) + 1):
-            logits = torch.matmul(F.softplus(self.matrices[i].detach()), logits) + self.biases[i].detach()
+            logits = torch.matmul(F.softplus(getattr(self, f"_matrix{i:d}").detach()), logits) + getattr(self, f"_bias{i:d}").detach()
             if i < len(self.filters):
-                logits = logits + torch.tanh(self.factors[i].detach()) * torch.tanh(logits)
+                logits = logits + torch.tanh(getattr(self, f"_factor{i:d}").detach()) * torch.tanh(logits)
         return logits
 
     def _likelihood(self, inputs, stop_gradient=False):

@@ -21,6 +21,11 @@ def topo_cfg(z, k):
     return dict(N=N, M=M, G=G, expand=bool(expand), B=B, H=H, W=W, method=str(z[f"{k}.method"]))
 
 
+def hyper_cfg(z, k):
+    N, M, B, H, W = (int(v) for v in z[f"{k}.cfg"])
+    return dict(N=N, M=M, B=B, H=H, W=W)
+
+
 def basic_cfg(z):
     cfg = [int(v) for v in z["b0.cfg"]]
     ctl = [str(c) for c in z["b0.controllers"]]
@@ -36,7 +41,11 @@ def build_codec(z, k, y_extra=None, **graph_extra):
     from cbench_basic_amd.modules.prior_model.prior_coder.compressai_coder import CompressAIEntropyBottleneckPriorCoder
     from cbench_basic_amd.modules.prior_model.prior_coder.pgm_coder import (GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder,
                                                                             TopoGroupDynamicMaskConv2dContextModel)
-    if k.startswith("t"):
+    if k.startswith("h"):   # the plain hyperprior graph: exactly what presets.hyperprior_codec builds
+        from cbench_basic_amd.presets import hyperprior_codec
+        c = hyper_cfg(z, k)
+        ec = hyperprior_codec(N=c["N"], M=c["M"]).entropy_coder
+    elif k.startswith("t"):
         from cbench_basic_amd.nn.models.google import (HyperpriorAnalysisModel, HyperpriorHyperAnalysisModel,
                                                        HyperpriorHyperSynthesisModel, HyperpriorSynthesisModel)
         c = topo_cfg(z, k)
@@ -91,12 +100,14 @@ def build_codec(z, k, y_extra=None, **graph_extra):
 
 
 def case_input(z, k):
-    c = topo_cfg(z, k) if k.startswith("t") else basic_cfg(z)
+    c = hyper_cfg(z, k) if k.startswith("h") else topo_cfg(z, k) if k.startswith("t") else basic_cfg(z)
     return recipe_input(int(z[f"{k}.xseed"]), (c["B"], 3, c["H"], c["W"]))
 
 
 def build_oracle(z, k, state_dict):
-    from oracle.codec_oracle import BasicCodecOracle, TopoGroupCodecOracle
+    from oracle.codec_oracle import BasicCodecOracle, HyperpriorOracle, TopoGroupCodecOracle
+    if k.startswith("h"):
+        return HyperpriorOracle(state_dict, prefix="entropy_coder.")
     if k.startswith("t"):
         c = topo_cfg(z, k)
         return TopoGroupCodecOracle(state_dict, method=c["method"], channels=c["M"], channel_groups=c["G"],
@@ -107,7 +118,7 @@ def build_oracle(z, k, state_dict):
 
 def records(z, k):
     """Fixture record prefixes of case k: the case itself, or one per complexity level for the BaSIC graph."""
-    if k.startswith("t"):
+    if k[0] in "th":
         return [(k, None)]
     return [(f"b0.l{i}", i) for i in range(len(z["b0.levels"]))]
 

@@ -548,6 +548,9 @@ def codec_graph():
       t0  topo-group graph, checkerboard + expand-bottleneck merger   (configs/lossy_latent_graph_topogroup.py:203-244)
       t1  topo-group graph, channel-wise G=2
       t2  topo-group graph, scanline, batch of 2 (one stream for the batch: the reference's layout)
+      h0-h2  plain hyperprior graph (configs/lossy_graph_scalable_exp_hp.py:182-215): batch 1, batch 3, and a batch of 2 whose
+          size is not a multiple of 64 (prior crop); also the z / y (symbols, indexes) of every native encode call and the
+          GaussianConditional table buffers
       b0  BaSIC slimmable graph (presets/lossy_latent_graph_scalable_ar_models.py:73-197), widths [4,6,8,12,16], eight
           complexity levels = eight fixed controller index tuples (complexity_level_greedy_search_custom_params), every
           uniform width plus three mixed ones
@@ -633,6 +636,71 @@ def codec_graph():
         out[f"{k}.cfg"] = np.array([N, M, G, int(expand), int(ctxm), B, H, W])
         out[f"{k}.method"] = np.array(method)
         finish(k, codec, touched, seed, 800 + ci, calib)
+
+    # ---- plain hyperprior graph (configs/lossy_graph_scalable_exp_hp.py:182-215): y = CompressAIGaussianConditionalCoder,
+    #      z = CompressAIEntropyBottleneckPriorCoder, Hyperprior*Model transforms -- the graph bench.py and basic_hp_* run
+    from cbench.modules.prior_model.prior_coder.compressai_coder import CompressAIGaussianConditionalCoder
+    from oracle import compressai_restated as cr
+
+    def spy_native(log):
+        """Log every (symbols, indexes) the coders hand to compressai.ans (EntropyModel.compress, one call per batch item:
+        first the z items, then the y items)."""
+        orig = cr.RansEncoder.encode_with_indexes
+
+        def spy(self, symbols, indexes, *a, **k):
+            log.append((np.array(symbols, np.int32).reshape(-1), np.array(indexes, np.int32).reshape(-1)))
+            return orig(self, symbols, indexes, *a, **k)
+        cr.RansEncoder.encode_with_indexes = spy
+        return lambda: setattr(cr.RansEncoder, "encode_with_indexes", orig)
+
+    for ci, (B, H, W) in enumerate([(1, 64, 64), (3, 64, 96), (2, 72, 100)]):   # the last: not a multiple of 64 (prior crop path)
+        k = f"h{ci}"
+        ec = LatentGraphicalANSEntropyCoder(
+            latent_node_inference_topo_order=["x", "y", "z"], latent_node_generative_topo_order=["z", "y", "x"],
+            latent_node_entropy_coder_dict=dict(x=LossyDummyEntropyCoder(lambda_rd=145.2225),
+                                                y=CompressAIGaussianConditionalCoder(),
+                                                z=CompressAIEntropyBottleneckPriorCoder(entropy_bottleneck_channels=N, use_inner_aux_opt=True)),
+            latent_inference_dict=dict(x_y=HyperpriorAnalysisModel(N=N, M=M), y_z=HyperpriorHyperAnalysisModel(N=N, M=M)),
+            latent_generative_dict=dict(z_y=HyperpriorHyperSynthesisModel(N=N, M=M), y_x=HyperpriorSynthesisModel(N=N, M=M)))
+        codec = GeneralCodec(entropy_coder=ec).eval()
+        seed = 720 + ci
+        pre = "entropy_coder.latent_inference_modules."
+        gen = "entropy_coder.latent_generative_modules."
+        # y std ~ 2; predicted scales (ReLU output of h_s) spread over the lower half of the scale table; x-hat O(1)
+        calib = [(pre + "x_y.model.6.weight", 8.0, 0.0), (pre + "y_z.model.4.weight", 6.0, 0.0),
+                 (gen + "z_y.model.4.bias", 1.0, 1.5), (gen + "y_x.model.0.weight", 0.05, 0.0)]
+        touched = named_seed_weights(codec, seed, calib)
+        codec.update_state()
+        x = recipe_input(820 + ci, (B, 3, H, W))
+        log = []
+        undo = spy_native(log)
+        with torch.no_grad():
+            data = codec.compress(x)
+        undo()
+        assert len(log) == 2 * B
+        zs, ys = log[:B], log[B:]
+        with torch.no_grad():
+            xhat = codec.decompress(data)
+            node = ec._node_generate_process(**ec._get_default_node_dict(force_add_default_dynamic_nodes=True))
+            lat = ec._inference_process({"x": x, **node})
+            codec.reset_all_cache()
+            xfwd = codec(x)
+            met = {n.split("metric_dict/entropy_coder/")[-1]: float(v) for n, v in codec.get_cache("metric_dict").items()}
+        gc = ec.latent_node_entropy_coders["y"].gaussian_conditional
+        out.update({f"{k}.bytes": b2a(data), f"{k}.symbols": np.stack([s for s, _ in ys]), f"{k}.indexes": np.stack([i for _, i in ys]),
+                    f"{k}.z_symbols": np.stack([s for s, _ in zs]), f"{k}.z_indexes": np.stack([i for _, i in zs]),
+                    f"{k}.xhat": xhat.numpy(), f"{k}.y": lat["y"].numpy(), f"{k}.z": lat["z"].numpy(),
+                    # decompress() returns the un-cropped synthesis output, forward() the input-sized one: compare the overlap
+                    f"{k}.xfwd_minus_xhat_max": np.float64((xfwd - xhat[..., :xfwd.shape[-2], :xfwd.shape[-1]]).abs().max()),
+                    f"{k}.xfwd_shape": np.array(xfwd.shape),
+                    f"{k}.metric_names": np.array(list(met)), f"{k}.metric_values": np.array(list(met.values()), np.float64),
+                    f"{k}.gc_cdf_sha256": np.array(hashlib.sha256(gc._quantized_cdf.numpy().astype(np.int32).tobytes()).hexdigest()),
+                    f"{k}.gc_cdf_length": gc._cdf_length.numpy().astype(np.int32), f"{k}.gc_offset": gc._offset.numpy().astype(np.int32),
+                    f"{k}.cfg": np.array([N, M, B, H, W])})
+        print(f"  {k}: {len(data)} bytes, {ys[0][0].size} y symbols per image, mse {met.get('mse', float('nan')):.4f}, "
+              f"y std {float(lat['y'].std()):.2f}, index range {int(out[f'{k}.indexes'].min())}..{int(out[f'{k}.indexes'].max())}, "
+              f"prior_entropy {met.get('prior_entropy', float('nan')):.2f}")
+        finish(k, codec, touched, seed, 820 + ci, calib)
 
     # ---- BaSIC slimmable graph
     codec, ec, levels, ctl, touched, calib, Wd, M = _basic_graph()

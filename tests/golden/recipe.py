@@ -20,12 +20,21 @@ _KEEP = (".beta", ".gamma", "_reparam", "scale_beta", "scale_gamma", "bias_beta"
          "gamma_scales", "gamma_biases")
 
 
+def seed_name(name):
+    """The name a parameter's generator is seeded by: the EntropyBottleneck's ``_biasN`` is seeded as ``biases.N`` (the
+    spelling the first fixtures were drawn with), so the values do not depend on which of the two layouts a class uses."""
+    head, _, leaf = name.rpartition(".")
+    if "entropy_bottleneck" in head and leaf.startswith("_bias") and leaf[5:].isdigit():
+        return f"{head}.biases.{leaf[5:]}"
+    return name
+
+
 def named_seed_weights(module, base_seed, calib=()):
     touched = []
     with torch.no_grad():
         params = dict(module.named_parameters())
         for name, p in params.items():
-            g = torch.Generator().manual_seed((zlib.crc32(name.encode()) + int(base_seed)) % (1 << 31))
+            g = torch.Generator().manual_seed((zlib.crc32(seed_name(name).encode()) + int(base_seed)) % (1 << 31))
             if "entropy_bottleneck" in name:
                 if ".biases." in name or "._biases" in name or "_bias" in name.rsplit(".", 1)[-1]:
                     p.copy_((torch.rand(p.shape, generator=g) - 0.5).to(p.device))

@@ -423,3 +423,154 @@ def test_harness_workers_need_a_codec_builder():
         BasicLosslessCompressionBenchmark(object(), [], num_testing_workers=2)
     b = BasicLosslessCompressionBenchmark(object(), [], num_testing_workers=2, codec_builder=lambda: object())
     assert b.num_testing_workers == 2 and b._pool is None
+
+
+# ---------------------------------------------------------------- checkpoint contract (state_dict layouts, loaders)
+def _tiny_presets():
+    from cbench_basic_amd.presets import basic_codec, hyperprior_codec, topogroup_ar_codec
+    return dict(hyperprior=hyperprior_codec(N=8, M=16), topogroup=topogroup_ar_codec("checkerboard", N=8, M=16),
+                basic=basic_codec(widths=[4, 6, 8, 12, 16], M=16))
+
+
+# what tools/compressai_checkpoint_to_cbench.py does to a compressai zoo file (restated as DATA: :16-25 rename rule,
+# :139-152 the bmshj2018_hyperprior prefix map and its discarded keys)
+_ZOO_RENAME = {"entropy_bottleneck._biases.": "entropy_bottleneck._bias", "entropy_bottleneck._matrices.": "entropy_bottleneck._matrix",
+               "entropy_bottleneck._factors.": "entropy_bottleneck._factor"}
+_ZOO_DISCARD = ("entropy_bottleneck._offset", "entropy_bottleneck._quantized_cdf", "entropy_bottleneck._cdf_length")
+_ZOO_PREFIX = {"entropy_bottleneck": "latent_node_entropy_coders.z.entropy_bottleneck", "g_a": "latent_inference_modules.x_y.model",
+               "h_a": "latent_inference_modules.y_z.model", "g_s": "latent_generative_modules.y_x.model",
+               "h_s": "latent_generative_modules.z_y.model"}
+
+
+def _convert_like_the_reference_tool(zoo):
+    out = {}
+    for key, value in zoo.items():
+        for old, new in _ZOO_RENAME.items():
+            if key.startswith(old):
+                key = new + key[-1]
+        if key in _ZOO_DISCARD:
+            continue
+        for prefix, target in _ZOO_PREFIX.items():
+            if key.startswith(prefix):
+                out["entropy_coder." + target + key[len(prefix):]] = value
+                break
+    return out
+
+
+def test_entropy_bottleneck_emits_the_converter_layout_and_accepts_parameter_lists():
+    """state_dict() of every preset names the factorised prior's parameters _matrixN / _biasN / _factorN (what the reference's
+    converter writes, tools/compressai_checkpoint_to_cbench.py:16-25); the ParameterList spellings (matrices.N, and the zoo
+    files' _matrices.N) load strictly into the same tensors."""
+    for name, codec in _tiny_presets().items():
+        sd = codec.state_dict()
+        eb = "entropy_coder.latent_node_entropy_coders.z.entropy_bottleneck."
+        leaves = [k[len(eb):] for k in sd if k.startswith(eb)]
+        assert leaves[:3] == ["_matrix0", "_bias0", "_factor0"] and "_matrix4" in leaves and "_bias4" in leaves and "_factor4" not in leaves, (name, leaves)
+        assert not any(s.startswith(("matrices", "biases", "factors")) for s in leaves), name
+        for spell in (("matrices.", "biases.", "factors."), ("_matrices.", "_biases.", "_factors.")):
+            alt = {}
+            for k, v in sd.items():
+                leaf = k[len(eb):] if k.startswith(eb) else ""
+                for old, new in zip(("_matrix", "_bias", "_factor"), spell):
+                    if leaf.startswith(old) and leaf[len(old):].isdigit():
+                        k = eb + new + leaf[len(old):]
+                alt[k] = torch.full_like(v, 0.25) if k != eb + "quantiles" and k.startswith(eb) and v.is_floating_point() else v
+            assert any(spell[0] in k for k in alt)
+            res = codec.load_state_dict(alt, strict=True)
+            assert not res.missing_keys and not res.unexpected_keys
+            assert float(codec.state_dict()[eb + "_matrix2"].mean()) == 0.25 and float(codec.state_dict()[eb + "_bias4"].mean()) == 0.25
+            codec.load_state_dict(sd, strict=True)
+
+
+def test_converted_zoo_checkpoint_loads_into_the_hyperprior_preset(tmp_path):
+    """A compressai-zoo style state_dict (g_a.N.weight, entropy_bottleneck._matrices.N, gaussian_conditional.*) pushed through
+    the reference converter's key map lands on this codec with NO unexpected key; what is missing is exactly what the converter
+    discards or the zoo model keeps elsewhere (table buffers, the y-coder's gaussian_conditional.*, the complexity-level
+    bookkeeping); with those taken from the codec itself the load is strict.  Also through TorchCheckpointLoader
+    (nn/base.py:175-196) and load_checkpoint (nn/base.py:507-519)."""
+    from cbench_basic_amd.base import TorchCheckpointLoader
+    codec = _tiny_presets()["hyperprior"]
+    sd = codec.state_dict()
+    inv = {"entropy_coder." + v: k for k, v in _ZOO_PREFIX.items()}
+    zoo = {}
+    for k, v in sd.items():
+        for ours, theirs in inv.items():
+            if k.startswith(ours + "."):
+                leaf = k[len(ours):]
+                for new, old in (("._matrix", "._matrices."), ("._bias", "._biases."), ("._factor", "._factors.")):
+                    if theirs == "entropy_bottleneck" and leaf.startswith(new) and leaf[len(new):].isdigit():
+                        leaf = old + leaf[len(new):]
+                zoo[theirs + leaf] = torch.randn(v.shape) if v.is_floating_point() else v.clone()
+    for name in ("_offset", "_quantized_cdf", "_cdf_length", "scale_table"):
+        zoo["gaussian_conditional." + name] = torch.zeros(3)
+    assert "entropy_bottleneck._matrices.0" in zoo and "g_a.0.weight" in zoo and "h_s.4.bias" in zoo
+    conv = _convert_like_the_reference_tool(zoo)
+    res = codec.load_state_dict(conv, strict=False)
+    assert res.unexpected_keys == []
+    allowed = ("entropy_bottleneck._offset", "entropy_bottleneck._quantized_cdf", "entropy_bottleneck._cdf_length", ".gaussian_conditional.",
+               "_complexity_", ".target", "likelihood_lower_bound.bound")
+    assert all(any(a in k for a in allowed) for k in res.missing_keys), res.missing_keys
+    assert torch.equal(codec.state_dict()["entropy_coder.latent_inference_modules.x_y.model.0.weight"], zoo["g_a.0.weight"])
+    assert torch.equal(codec.state_dict()["entropy_coder.latent_node_entropy_coders.z.entropy_bottleneck._bias3"], zoo["entropy_bottleneck._biases.3"])
+    full = dict(conv, **{k: sd[k] for k in res.missing_keys})
+    codec.load_state_dict(full, strict=True)
+    # loaders: a file whose keys carry one more prefix, one key filtered, under a sub-dict
+    path = str(tmp_path / "ckpt.pt")
+    drop = "entropy_coder.latent_node_entropy_coders.z.entropy_bottleneck.target"   # filter_keys name keys AFTER the prefix is stripped
+    torch.save({"state_dict": {"model." + k: v for k, v in full.items()}}, path)
+    with pytest.raises(RuntimeError):
+        TorchCheckpointLoader(path, key="state_dict", prefix="model.", filter_keys=[drop]).load(codec)     # strict: the filtered key is missing
+    res = TorchCheckpointLoader(path, key="state_dict", prefix="model.", filter_keys=[drop], strict=False).load(codec)
+    assert res.missing_keys == [drop] and not res.unexpected_keys
+    with pytest.raises(KeyError):
+        TorchCheckpointLoader(path, key="state_dict", filter_keys=["not there"]).load(codec)
+    torch.save(full, path)
+    assert codec.load_checkpoint() is None                       # no loader configured: nothing happens
+    assert not codec.load_checkpoint(path).unexpected_keys       # a path: non-strict load
+    codec.checkpoint_loader = TorchCheckpointLoader(path)
+    assert not codec.load_checkpoint().missing_keys
+    with pytest.raises(ValueError):
+        codec.load_checkpoint(42)
+
+
+def test_gaussian_conditional_buffers_travel_in_checkpoints():
+    """compressai_coder.py:298-319,341-346: the y-coder of the plain hyperprior graph owns gaussian_conditional.{_offset,
+    _quantized_cdf, _cdf_length, scale_table, scale_bound} (+ the two LowerBound children); a checkpoint's tables are taken at
+    their size and KEPT by the next update (update_scale_table returns early when tables exist) unless forced; a fresh coder
+    builds the reference fixture's table (codec_graph.npz h0: lengths, offsets, sha256 of the CDF)."""
+    import hashlib
+    from cbench_basic_amd.modules.prior_model.prior_coder.compressai_coder import (CompressAIGaussianConditionalCoder, get_scale_table)
+    c = CompressAIGaussianConditionalCoder()
+    keys = list(c.state_dict())
+    assert keys == ["gaussian_conditional._offset", "gaussian_conditional._quantized_cdf", "gaussian_conditional._cdf_length",
+                    "gaussian_conditional.scale_table", "gaussian_conditional.scale_bound",
+                    "gaussian_conditional.likelihood_lower_bound.bound", "gaussian_conditional.lower_bound_scale.bound"], keys
+    assert c.state_dict()["gaussian_conditional._offset"].numel() == 0 and float(c.state_dict()["gaussian_conditional.scale_bound"]) == pytest.approx(0.11)
+    gc = c.gaussian_conditional
+    assert gc.update_scale_table(get_scale_table()) is True
+    z = np.load(os.path.join(ROOT, "tests", "golden", "codec_graph.npz"))
+    cdf, length, offset = gc.host_tables()
+    assert np.array_equal(length, z["h0.gc_cdf_length"]) and np.array_equal(offset, z["h0.gc_offset"])
+    assert hashlib.sha256(cdf.tobytes()).hexdigest() == str(z["h0.gc_cdf_sha256"])
+    assert torch.equal(gc.scale_table, get_scale_table())
+    # a checkpoint with other (smaller) tables: adopted, kept by update, replaced by a forced update
+    ck = dict(c.state_dict())
+    ck["gaussian_conditional._quantized_cdf"] = torch.arange(12, dtype=torch.int32).reshape(3, 4)
+    ck["gaussian_conditional._cdf_length"] = torch.tensor([4, 4, 3], dtype=torch.int32)
+    ck["gaussian_conditional._offset"] = torch.tensor([-1, -1, 0], dtype=torch.int32)
+    ck["gaussian_conditional.scale_table"] = torch.tensor([0.5, 1.0, 2.0])
+    c2 = CompressAIGaussianConditionalCoder()
+    c2.load_state_dict(ck, strict=True)
+    g2 = c2.gaussian_conditional
+    assert g2.update_scale_table(get_scale_table()) is False
+    assert torch.equal(g2._quantized_cdf, ck["gaussian_conditional._quantized_cdf"]) and torch.equal(c2.scale_table, ck["gaussian_conditional.scale_table"])
+    assert g2.update_scale_table(get_scale_table(), force=True) is True and g2._quantized_cdf.shape == gc._quantized_cdf.shape
+    # the factorised prior follows the same rule (EntropyBottleneck.update(force=False))
+    from cbench_basic_amd.modules.prior_model.prior_coder.compressai_coder import EntropyBottleneck
+    eb = EntropyBottleneck(4)
+    assert eb.update() is True and eb.update() is False
+    first = eb._quantized_cdf.clone()
+    with torch.no_grad():
+        eb._bias0.add_(0.3)
+    assert eb.update() is False and torch.equal(eb._quantized_cdf, first)
+    assert eb.update(force=True) is True and not torch.equal(eb._quantized_cdf, first)

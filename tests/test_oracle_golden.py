@@ -243,7 +243,7 @@ def test_codec_state_dict_contract_matches_reference():
         ours = {n: ",".join(str(d) for d in v.shape) for n, v in codec.state_dict().items()}
         ref = dict(zip((str(s) for s in z[f"{k}.sd_keys"]), (str(s) for s in z[f"{k}.sd_shapes"])))
         assert set(ours) == set(ref), (k, sorted(set(ours) ^ set(ref)))
-        table_buffers = ("entropy_bottleneck._offset", "entropy_bottleneck._quantized_cdf", "entropy_bottleneck._cdf_length")
+        table_buffers = ("._offset", "._quantized_cdf", "._cdf_length", "gaussian_conditional.scale_table")
         diff = [(n, ours[n], ref[n]) for n in ours if ours[n] != ref[n] and not n.endswith(table_buffers)]
         assert not diff, (k, diff)       # (the three table buffers are empty until update_state(), as upstream)
         assert sorted(n for n, _ in touched) == sorted(str(s) for s in z[f"{k}.pnames"]), k
@@ -270,8 +270,13 @@ def test_codec_oracle_matches_reference_codec_graph():
                 lv = cc.basic_cfg(z)["levels"][level]
                 o.set_levels(*(n - 1 - lv[c] for c in ("pgmxy", "pgmyz", "pgmzy", "pgmyx")))
             data = o.compress(x)
-            assert np.array_equal(o.last["y_sym"].reshape(-1), z[f"{rec}.symbols"]), rec
-            assert np.array_equal(o.last["y_idx"].reshape(-1), z[f"{rec}.indexes"]), rec
+            assert np.array_equal(np.asarray(o.last["y_sym"]).reshape(-1), z[f"{rec}.symbols"].reshape(-1)), rec
+            assert np.array_equal(np.asarray(o.last["y_idx"]).reshape(-1), z[f"{rec}.indexes"].reshape(-1)), rec
+            if f"{rec}.z_symbols" in z:     # hyperprior cases: the z coder's integers and the GaussianConditional tables too
+                assert np.array_equal(o.last["z_sym"].numpy().reshape(-1), z[f"{rec}.z_symbols"].reshape(-1)), rec
+                cdf, length, offset = o.gc
+                assert hashlib.sha256(cdf.astype(np.int32).tobytes()).hexdigest() == str(z[f"{rec}.gc_cdf_sha256"]), rec
+                assert np.array_equal(length, z[f"{rec}.gc_cdf_length"]) and np.array_equal(offset, z[f"{rec}.gc_offset"]), rec
             assert data == z[f"{rec}.bytes"].tobytes(), rec
             assert torch.allclose(o.last["y"], torch.from_numpy(z[f"{rec}.y"]), atol=1e-5, rtol=1e-5), rec
             xhat = o.decompress(z[f"{rec}.bytes"].tobytes())
