@@ -46,6 +46,10 @@ bool set_dynamic_tiles(bool on);
 
 constexpr int kWave = 64;  // CDNA wavefront
 
+// Canonical summation block of the masked convolution (mconv.hip header comment): channels of one (tap, input group) slab
+// whose products form ONE fp32 MFMA / FMA chain; the persistent scan-line kernel (scanline.hip) sums in the same blocks.
+#define BASIC_MCONV_BLOCK_CHANNELS 64
+
 // Device view of a table set's fast-decoder search image (rans.hip), for kernels outside rans.hip that decode in place.
 struct RansFastView {
     const uint32_t *image = nullptr, *meta = nullptr;   // image: per row 64 x {key, start, freq, pad} (rows <= 64 entries)

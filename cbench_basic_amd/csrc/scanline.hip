@@ -14,6 +14,14 @@
 // device-wide barrier before the next layer.  Four barriers per coding step instead of four-plus kernel boundaries with
 // their dependent weight re-reads.
 //
+// Summation order.  The integers coded here must equal, bit for bit, what the per-step path (csrc/mconv.hip) derives from
+// the same layers at any batch size -- a stream may be encoded by one path and decoded by the other.  Every dot product is
+// therefore evaluated in mconv.hip's CANONICAL order: the K axis of a layer (context layer: [causal tap][channel]; dense
+// layer: its input channels in `in_groups` equal groups) is cut, group by group, into blocks of BASIC_MCONV_BLOCK_CHANNELS
+// channels; a block's partial is one fp32 FMA chain over its channels in ascending order starting from zero (= the
+// v_mfma_f32_32x32x2_f32 chain of the masked convolution, scripts/micro/mfma_arith.hip); the partials are added in block
+// order, then the bias.  Taps outside the image enter as zeros, as the masked-out slabs do there.
+//
 // Cross-workgroup visibility follows MI355X_MICROARCH.md ("Workgroup dispatch, XCD placement & inter-workgroup visibility",
 // valid-forms table, first row): every handed-over byte is stored sc1 and loaded sc1 (agent-scope relaxed atomics lower to
 // exactly that), every storing wave drains (s_waitcnt vmcnt(0)) before the workgroup barrier, ONE lane then adds to the
@@ -48,10 +56,11 @@ struct ScanArgs {
     int B, C, H, W, P;
     int nlayers, ntaps, vec4;   // vec4: every K, row count and C is a multiple of 4 -> 16-byte exchanges and LDS reads
     int rows[kMaxLayers], kdim[kMaxLayers], rpw[kMaxLayers], woff[kMaxLayers], act_after[kMaxLayers];
+    int kgroup[kMaxLayers], bpg[kMaxLayers], kpad[kMaxLayers];   // channels / canonical blocks per K group; padded LDS row (see padded_k)
     const float *w[kMaxLayers], *bias[kMaxLayers];
     float *act[kMaxLayers];   // exchange buffers [B][rows_l]
     int tap_off[kMaxTaps], tap_dy[kMaxTaps], tap_dx[kMaxTaps];
-    int bc, xs_off, ps_off, tab_off, part_off, flag_off;   // LDS float offsets (the whole LDS is dynamic)
+    int bc, xs_off, ps_off, tab_off, part_off, part_floats, flag_off;   // LDS float offsets (the whole LDS is dynamic)
     unsigned *bar;
     int *err;
     int debug;   // BASIC_SCAN_DEBUG timing ablations (wrong results): 1 no barrier wait, 2 no input staging, 4 no dot products
@@ -199,41 +208,38 @@ __device__ __forceinline__ void stage_inputs(const ScanArgs &a, int l, int p, in
     }
 }
 
-// ---- this workgroup's rows of a layer for the staged images.  A LANE owns one output (image, row): the four waves take
-//      the four quarters of K, a lane walks its quarter in order (no cross-lane reduction: a dependent shuffle tree per
-//      output cost 13 us per coding step at batch 1, this form 2), and the four quarter sums are added in wave order.
-//      Lanes with the same image read the same input address (LDS broadcast); weight rows are padded by 4 (1) floats so
-//      that the lanes' rows start on different banks.  The order of summation depends only on the layer shapes: the same in
-//      the encoder and in the decoder launch, which is all that matters for the stream.
-__device__ __forceinline__ float slice_dot(const float *wr, const float *xr, int K, int chunk, int nchunks, int vec4)
+constexpr int kKB = BASIC_MCONV_BLOCK_CHANNELS;
+constexpr int kBlockPad = 4;   // LDS floats between the blocks of a weight row: lanes working on different blocks of a row start on different banks
+
+// LDS position of element k of a weight row whose K axis has groups of kg channels (bpg blocks each)
+__host__ __device__ __forceinline__ int padded_k(int k, int kg, int bpg)
 {
-    // four independent running sums (columns j, j+1, j+2, j+3 of every group of four) keep four LDS read pairs and four FMA
-    // chains in flight; they are folded as (a0 + a1) + (a2 + a3)
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    const int g = k / kg, kk = k - g * kg;
+    return g * (kg + kBlockPad * bpg) + kk + kBlockPad * (kk / kKB);
+}
+
+// ---- one canonical block of one output: an FMA chain over `len` channels in ascending order, starting from zero.  A THREAD
+//      owns a (block, image, row) unit; threads of a wave take consecutive rows of the same block (weight rows are padded
+//      so that they start on different banks; lanes of one image read the same input address: LDS broadcast).
+__device__ __forceinline__ float block_dot(const float *wr, const float *xr, int len, int vec4)
+{
+    float p = 0.f;
     if (vec4) {
-        const int K4 = K >> 2, q = (K4 + nchunks - 1) / nchunks;
-        const int kend = (chunk + 1) * q < K4 ? (chunk + 1) * q : K4;
         const f4 *x4 = reinterpret_cast<const f4 *>(xr), *w4 = reinterpret_cast<const f4 *>(wr);
-        int k4 = chunk * q;
-#define BASIC_FMA4(A, WV, XV) A = fmaf(WV[0], XV[0], A); A = fmaf(WV[1], XV[1], A); A = fmaf(WV[2], XV[2], A); A = fmaf(WV[3], XV[3], A)
-        for (; k4 + 4 <= kend; k4 += 4) {
+        const int n4 = len >> 2;
+        int k4 = 0;
+        for (; k4 + 4 <= n4; k4 += 4) {   // 16 channels of loads in flight, one chain
             const f4 x0 = x4[k4], x1 = x4[k4 + 1], x2 = x4[k4 + 2], x3 = x4[k4 + 3];
             const f4 w0 = w4[k4], w1 = w4[k4 + 1], w2 = w4[k4 + 2], w3 = w4[k4 + 3];
-            BASIC_FMA4(a0, w0, x0); BASIC_FMA4(a1, w1, x1); BASIC_FMA4(a2, w2, x2); BASIC_FMA4(a3, w3, x3);
+#define BASIC_FMA4(WV, XV) p = fmaf(WV[0], XV[0], p); p = fmaf(WV[1], XV[1], p); p = fmaf(WV[2], XV[2], p); p = fmaf(WV[3], XV[3], p)
+            BASIC_FMA4(w0, x0); BASIC_FMA4(w1, x1); BASIC_FMA4(w2, x2); BASIC_FMA4(w3, x3);
         }
-        for (; k4 < kend; ++k4) { const f4 xv = x4[k4], wv = w4[k4]; BASIC_FMA4(a0, wv, xv); }
+        for (; k4 < n4; ++k4) { const f4 xv = x4[k4], wv = w4[k4]; BASIC_FMA4(wv, xv); }
 #undef BASIC_FMA4
     } else {
-        const int q = (K + nchunks - 1) / nchunks;
-        const int kend = (chunk + 1) * q < K ? (chunk + 1) * q : K;
-        int kk = chunk * q;
-        for (; kk + 4 <= kend; kk += 4) {
-            a0 = fmaf(wr[kk], xr[kk], a0); a1 = fmaf(wr[kk + 1], xr[kk + 1], a1);
-            a2 = fmaf(wr[kk + 2], xr[kk + 2], a2); a3 = fmaf(wr[kk + 3], xr[kk + 3], a3);
-        }
-        for (; kk < kend; ++kk) a0 = fmaf(wr[kk], xr[kk], a0);
+        for (int k = 0; k < len; ++k) p = fmaf(wr[k], xr[k], p);
     }
-    return (a0 + a1) + (a2 + a3);
+    return p;
 }
 
 // ---- in-place rANS decoder of ONE stream held by one wavefront (decode_stream semantics, csrc/ans/rans64.cpp:501-598;
@@ -385,8 +391,8 @@ __global__ __launch_bounds__(kThreads) void scanline_persistent_kernel(const Sca
         rows_w[l] = r;
         const float *src = a.w[l] + static_cast<int64_t>(wg) * a.rpw[l] * a.kdim[l];
         float *dst = lds + a.woff[l];
-        const int Kl = a.kdim[l], Kp = Kl + (a.vec4 ? 4 : 1);
-        for (int e = tid; e < r * Kl; e += kThreads) { const int rr = e / Kl; dst[rr * Kp + (e - rr * Kl)] = src[e]; }
+        const int Kl = a.kdim[l], Kp = a.kpad[l];
+        for (int e = tid; e < r * Kl; e += kThreads) { const int rr = e / Kl; dst[rr * Kp + padded_k(e - rr * Kl, a.kgroup[l], a.bpg[l])] = src[e]; }
     }
     float *tab = lds + a.tab_off;
     for (int e = tid; e < a.table_len; e += kThreads) tab[e] = a.table[e];
@@ -402,22 +408,25 @@ __global__ __launch_bounds__(kThreads) void scanline_persistent_kernel(const Sca
                 const int nb = (a.B - b0) < a.bc ? (a.B - b0) : a.bc;
                 if (rw > 0 && !(a.debug & 2)) stage_inputs(a, l, p, py, px, b0, nb, xs);
                 __syncthreads();
-                // S lanes per output (a power of two: 64 / S outputs per round), each of the 4 * S (wave, sub-lane) pairs walks
-                // one contiguous slice of K; the finishing thread adds the 4 * S slice sums in slice order
-                const int items = (a.debug & 4) ? 0 : nb * rw, Kp = K + (a.vec4 ? 4 : 1);
-                int S = 1;
-                while (S < 16 && items * (S << 1) <= 64) S <<= 1;
-                const int per_round = 64 / S;
+                // units = (canonical block, image, row), one FMA chain each; `part` holds one round of partials as
+                // [block][item]; the finishing threads add an item's partials in block order, then bias and activation
+                const int items = (a.debug & 4) ? 0 : nb * rw, Kp = a.kpad[l];
+                const int kg = a.kgroup[l], bpg = a.bpg[l], nblk = (K / kg) * bpg;
+                const int per_round = items < a.part_floats / nblk ? items : a.part_floats / nblk;
                 for (int i0 = 0; i0 < items; i0 += per_round) {
-                    const int item = i0 + lane / S, sub = lane & (S - 1);
-                    const bool on = item < items && lane / S < per_round;
-                    const int bi = on ? item / rw : 0, r = on ? item - bi * rw : 0;
-                    part[wave * 64 + lane] = slice_dot(wl + r * Kp, xs + bi * K, K, wave * S + sub, 4 * S, a.vec4);
+                    const int n_it = (items - i0) < per_round ? (items - i0) : per_round;
+                    for (int u = tid; u < n_it * nblk; u += kThreads) {
+                        const int blk = u / n_it, it = u - blk * n_it, item = i0 + it;
+                        const int bi = item / rw, r = item - bi * rw;
+                        const int g = blk / bpg, j = blk - g * bpg;
+                        const int k0 = g * kg + j * kKB, len = (kg - j * kKB) < kKB ? (kg - j * kKB) : kKB;
+                        part[u] = block_dot(wl + r * Kp + g * (kg + kBlockPad * bpg) + j * (kKB + kBlockPad), xs + bi * K + k0, len, a.vec4);
+                    }
                     __syncthreads();
-                    if (wave == 0 && on && sub == 0) {
+                    for (int it = tid; it < n_it; it += kThreads) {
+                        const int item = i0 + it, bi = item / rw, r = item - bi * rw;
                         float v = 0.f;
-                        for (int w4 = 0; w4 < 4; ++w4)
-                            for (int s2 = 0; s2 < S; ++s2) v += part[w4 * 64 + (lane / S) * S + s2];
+                        for (int blk = 0; blk < nblk; ++blk) v += part[blk * n_it + it];
                         v += a.bias[l] ? a.bias[l][r_first + r] : 0.f;
                         if (a.act_after[l]) v = v > 0.f ? v : 0.01f * v;   // LeakyReLU(0.01)
                         if (l < last) st_sc1(a.act[l] + static_cast<int64_t>(b0 + bi) * a.rows[l] + r_first + r, v);
@@ -473,6 +482,7 @@ __global__ void transpose_prior_kernel(const float *__restrict__ in, float *__re
 struct basic_scanline_plan {
     int C = 0, P = 0, ksize = 0, nlayers = 0, ntaps = 0, nwg = 1, vec4 = 0;
     int rows[kMaxLayers] = {}, kdim[kMaxLayers] = {}, rpw[kMaxLayers] = {}, woff[kMaxLayers] = {}, act_after[kMaxLayers] = {};
+    int kgroup[kMaxLayers] = {}, bpg[kMaxLayers] = {}, kpad[kMaxLayers] = {};   // canonical blocks (see the header comment)
     int tap_dy[kMaxTaps] = {}, tap_dx[kMaxTaps] = {};
     float *d_w[kMaxLayers] = {}, *d_b[kMaxLayers] = {};
     int weight_floats = 0;   // LDS floats of one workgroup's weight slices
@@ -543,7 +553,7 @@ extern "C" void basic_scanline_plan_destroy(basic_scanline_plan *p)
 extern "C" int basic_scanline_plan_create(const float *ctx_weight, const float *ctx_bias, int channels, int ctx_out, int ksize,
                                           int prior_channels, int n_dense, const float *const *dense_weight,
                                           const float *const *dense_bias, const int *dense_out, const int *act_after,
-                                          basic_scanline_plan **out)
+                                          const int *dense_in_groups, basic_scanline_plan **out)
 {
     int rc = require_device();
     if (rc) return rc;
@@ -566,8 +576,25 @@ extern "C" int basic_scanline_plan_create(const float *ctx_weight, const float *
         p->kdim[l] = p->rows[l - 1] + (l == 1 ? prior_channels : 0);
         p->act_after[l] = act_after[l];
     }
+    // canonical blocks: the context layer's K groups are its taps; a dense layer's are its in_groups equal channel groups
+    // (the channel groups of the masked convolution it stands for: cat(ctx, prior) of the first merger layer is two)
+    p->kgroup[0] = channels;
+    for (int l = 1; l <= n_dense; ++l) {
+        const int gi = dense_in_groups ? dense_in_groups[l - 1] : 1;
+        if (gi < 1 || p->kdim[l] % gi) {
+            delete p;
+            set_error("scanline_plan_create: a dense layer's inputs do not divide into its channel groups");
+            return BASIC_ERR_INVALID;
+        }
+        p->kgroup[l] = p->kdim[l] / gi;
+    }
     p->vec4 = channels % 4 == 0 && prior_channels % 4 == 0;
-    for (int l = 0; l < p->nlayers; ++l) p->vec4 = p->vec4 && p->rows[l] % 4 == 0 && p->kdim[l] % 4 == 0;
+    for (int l = 0; l < p->nlayers; ++l) p->vec4 = p->vec4 && p->rows[l] % 4 == 0 && p->kdim[l] % 4 == 0 && p->kgroup[l] % 4 == 0;
+    for (int l = 0; l < p->nlayers; ++l) {
+        p->bpg[l] = (p->kgroup[l] + kKB - 1) / kKB;
+        // row = its groups' channels + kBlockPad floats after every block, + one more pad so that consecutive rows shift banks
+        p->kpad[l] = (p->kdim[l] / p->kgroup[l]) * (p->kgroup[l] + kBlockPad * p->bpg[l]) + (p->vec4 ? 4 : 1);
+    }
     // workgroups: the fewest (<= 192: the decoder adds its own) whose weight slices fit ~112 KB of LDS; every layer in whole rows per workgroup, the
     // last one in whole (mean, scale) pairs
     int nwg = 1;
@@ -576,7 +603,7 @@ extern "C" int basic_scanline_plan_create(const float *ctx_weight, const float *
         for (int l = 0; l < p->nlayers; ++l) {
             int rpw = (p->rows[l] + nwg - 1) / nwg;
             if (l == p->nlayers - 1) rpw = (rpw + 1) & ~1;
-            floats += rpw * (p->kdim[l] + 4);
+            floats += rpw * p->kpad[l];
         }
         if (floats * sizeof(float) <= 112 * 1024 || nwg >= 192) { p->weight_floats = floats; break; }
     }
@@ -592,7 +619,7 @@ extern "C" int basic_scanline_plan_create(const float *ctx_weight, const float *
         if (l == p->nlayers - 1) rpw = (rpw + 1) & ~1;
         p->rpw[l] = rpw;
         p->woff[l] = off;
-        off += (rpw * (p->kdim[l] + (p->vec4 ? 4 : 1)) + 3) & ~3;
+        off += (rpw * p->kpad[l] + 3) & ~3;
     }
     p->weight_floats = off;
     // upload: context weights as [row][tap][c] (only the causal taps), dense layers as they are ([rows][k]); padded by
@@ -667,6 +694,7 @@ int fill_args(basic_scanline_plan *p, ScanArgs &a, int batch, int h, int w, cons
     int kmax = 0;
     for (int l = 0; l < p->nlayers; ++l) {
         a.rows[l] = p->rows[l]; a.kdim[l] = p->kdim[l]; a.rpw[l] = p->rpw[l]; a.woff[l] = p->woff[l]; a.act_after[l] = p->act_after[l];
+        a.kgroup[l] = p->kgroup[l]; a.bpg[l] = p->bpg[l]; a.kpad[l] = p->kpad[l];
         a.w[l] = p->d_w[l]; a.bias[l] = p->d_b[l];
         a.act[l] = p->d_scratch + ao;
         ao += align4(static_cast<size_t>(batch) * p->rows[l]);
@@ -692,13 +720,17 @@ int fill_args(basic_scanline_plan *p, ScanArgs &a, int batch, int h, int w, cons
     a.ps_off = a.tab_off + static_cast<int>(align4(table_len));
     const int rpw_last = p->rpw[p->nlayers - 1];
     int bc = 8 < batch ? 8 : batch;
-    auto need = [&](int n) { return a.ps_off + static_cast<int>(align4(n * rpw_last)) + static_cast<int>(align4(n * kmax)) + 256 + 4; };
+    // one round of block partials: [blocks][items]; 1024 floats hold a batch-1 layer in one round (<= 36 blocks x ~10 rows)
+    a.part_floats = 1024;
+    for (int l = 0; l < p->nlayers; ++l)
+        BASIC_REQUIRE((p->kdim[l] / p->kgroup[l]) * p->bpg[l] <= a.part_floats, "scanline: too many summation blocks in a layer");
+    auto need = [&](int n) { return a.ps_off + static_cast<int>(align4(n * rpw_last)) + static_cast<int>(align4(n * kmax)) + a.part_floats + 4; };
     while (bc > 1 && need(bc) > total_floats) --bc;
     BASIC_REQUIRE(need(bc) <= total_floats, "scanline: layer inputs do not fit the LDS");
     a.bc = bc;
     a.xs_off = a.ps_off + static_cast<int>(align4(bc * rpw_last));
     a.part_off = a.xs_off + static_cast<int>(align4(bc * kmax));
-    a.flag_off = a.part_off + 256;
+    a.flag_off = a.part_off + a.part_floats;
     *lds_bytes = static_cast<size_t>(a.flag_off + 4) * sizeof(float);
     a.bar = p->d_bar;
     a.err = reinterpret_cast<int *>(p->d_bar + 1);

@@ -333,7 +333,7 @@ class GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(HotPathModule):
                     (K.MaskedConvPlan(e[2].weight, e[2].bias, 1, 1, True, K.ACT_LEAKY_RELU), "pgm", "pgm"),
                     (K.MaskedConvPlan(e[4].weight[order], e[4].bias[order], 1, 1, True, K.ACT_NONE), "pgm", "pgm"),
                 ]
-                L["dense"] = [(w0, e[0].bias, True), (e[2].weight, e[2].bias, True), (e[4].weight[order], e[4].bias[order], False)]
+                L["dense"] = [(w0, e[0].bias, True, 1), (e[2].weight, e[2].bias, True, 1), (e[4].weight[order], e[4].bias[order], False, 1)]
             elif self.use_param_merger:
                 m = self.param_merger
                 L["m"] = [
@@ -350,7 +350,8 @@ class GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(HotPathModule):
                         w = conv.weight.detach().clone()
                         w[w.shape[0] // 2:, : w.shape[1] // 2] = 0
                         return w
-                    L["dense"] = [(masked(m[0]), m[0].bias, True), (masked(m[2]), m[2].bias, True), (m[4].weight[:C2], m[4].bias[:C2], False)]
+                    # (weight, bias, LeakyReLU after, input channel groups of the masked layer = its canonical summation blocks)
+                    L["dense"] = [(masked(m[0]), m[0].bias, True, 2), (masked(m[2]), m[2].bias, True, 2), (m[4].weight[:C2], m[4].bias[:C2], False, 2)]
         else:
             cp = cm.context_prediction
             L["ctx"] = K.MaskedConvPlan(cp.weight, cp.bias, G, G, False)
@@ -364,7 +365,7 @@ class GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(HotPathModule):
                     gi = 2 * G if i == 0 else G
                     L["m"].append((K.MaskedConvPlan(c.weight, c.bias, gi, G, True, act), "cat" if i == 0 else "pgm", "pgm"))
                 if G == 1:
-                    L["dense"] = [(c.weight, c.bias, i + 1 < len(convs)) for i, c in enumerate(convs)]
+                    L["dense"] = [(c.weight, c.bias, i + 1 < len(convs), 2 if i == 0 else 1) for i, c in enumerate(convs)]
         L["ctx_raw"] = (cp.weight, cp.bias)
         return L
 
@@ -543,7 +544,7 @@ class GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(HotPathModule):
             cw, cb = self._layers["ctx_raw"]
             try:
                 sp = (K.ScanlinePlan(cw.detach(), cb.detach() if cb is not None else None,
-                                     [(w.detach(), b.detach() if b is not None else None, a) for w, b, a in self._layers["dense"]], pc), pc)
+                                     [(w.detach(), b.detach() if b is not None else None, a, gi) for w, b, a, gi in self._layers["dense"]], pc), pc)
             except ValueError:   # the layers' weights exceed the LDS of the chip (a property of the configuration)
                 sp = (None, pc)
             self._layers["scanline"] = sp

@@ -463,7 +463,11 @@ class ScanlinePlan:
     """basic_scanline_*: the persistent scan-line AR coding loop (one launch for all H*W coding steps)."""
 
     def __init__(self, ctx_weight, ctx_bias, dense, prior_channels, ctx_act=False):
-        """dense: list of (weight [out, in(, 1, 1)], bias or None, leaky_after: bool)."""
+        """dense: list of (weight [out, in(, 1, 1)], bias or None, leaky_after: bool[, in_groups: int = 1]); in_groups = the
+        input channel groups of the masked convolution the layer stands for (fixes the canonical summation blocks)."""
+        dense = [tuple(d) + (1,) * (4 - len(d)) for d in dense]
+        groups = np.array([int(d[3]) for d in dense], dtype=np.int32)
+        dense = [d[:3] for d in dense]
         cw = _f32(ctx_weight)
         cb = _f32(ctx_bias) if ctx_bias is not None else None
         self.channels, self.ksize = cw.shape[1], cw.shape[2]
@@ -477,7 +481,7 @@ class ScanlinePlan:
         h = ctypes.c_void_p()
         _lib.check(_lib.lib().basic_scanline_plan_create(cw.ctypes.data, cb.ctypes.data if cb is not None else None, self.channels,
                                                          cw.shape[0], self.ksize, int(prior_channels), n, wp, bp, outs.ctypes.data,
-                                                         acts.ctypes.data, ctypes.byref(h)))
+                                                         acts.ctypes.data, groups.ctypes.data, ctypes.byref(h)))
         self._h = h
         wg, lb = ctypes.c_int(), ctypes.c_int()
         _lib.check(_lib.lib().basic_scanline_plan_info(h, ctypes.byref(wg), ctypes.byref(lb)))

@@ -331,11 +331,14 @@ typedef struct basic_scanline_plan basic_scanline_plan;
 /* ctx_weight [ctx_out][channels][k][k] (PyTorch layout; only the causal taps are used), ctx_bias [ctx_out] or NULL.
  * Dense layer i (i < n_dense): weight [dense_out[i]][in_i], in_0 = ctx_out + prior_channels (input = cat(ctx, prior)),
  * in_i = dense_out[i-1]; bias or NULL.  act_after[0] belongs to the context layer, act_after[1 + i] to dense layer i
- * (1 = LeakyReLU(0.01)).  The last layer must have 2 * channels rows: (mean, scale) pairs, channel 2c = mean. */
+ * (1 = LeakyReLU(0.01)).  The last layer must have 2 * channels rows: (mean, scale) pairs, channel 2c = mean.
+ * dense_in_groups[i] (NULL = all 1): the input channel groups of the masked convolution dense layer i stands for
+ * (masked_conv.py:170-172; cat(ctx, prior) of the first merger layer = 2): the sums are taken in that operator's canonical
+ * block order (csrc/mconv.hip), so the integers coded here equal the per-step path's at any batch size. */
 int basic_scanline_plan_create(const float *ctx_weight, const float *ctx_bias, int channels, int ctx_out, int ksize,
                                int prior_channels, int n_dense, const float *const *dense_weight,
                                const float *const *dense_bias, const int *dense_out, const int *act_after,
-                               basic_scanline_plan **out);
+                               const int *dense_in_groups, basic_scanline_plan **out);
 int basic_scanline_plan_info(const basic_scanline_plan *p, int *workgroups, int *lds_weight_bytes);
 /* d_y [B][C][H][W], d_prior [B][prior_channels][H][W] (NULL when prior_channels == 0), d_table float32 [table_len]:
  * writes d_symbols / d_indexes int32 [B][H*W*C] in coding order (element p * C + c) and d_ybuf [B][C][H][W]

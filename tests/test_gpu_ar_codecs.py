@@ -256,3 +256,68 @@ def test_basic_combined_entropy_coder_levels():
         assert float((oracle.decompress(data) - xhat).abs().max()) < 1e-3
         assert float((psnr(xhat, x) - psnr(oracle.decompress(ref), x)).abs().max()) < 0.01
     assert seen == {0, 1, 2, 3, 4}
+
+
+# ---------------------------------------------------------------- streams do not depend on the batch or on the launch shape
+def _image_streams(data, B):
+    """Per-image y streams of a per-image-mode codec stream: [u32 len(z body)][z body][y body = u32 lens ... streams]."""
+    import struct
+    (nz,) = struct.unpack("I", data[:4])
+    zbody, ybody = data[4:4 + nz], data[4 + nz:]
+    (nb,) = struct.unpack("<I", ybody[:4])
+    assert nb == B
+    lens = struct.unpack("<%dI" % B, ybody[4:4 + 4 * B])
+    cur, out = 4 + 4 * B, []
+    for n in lens:
+        out.append(ybody[cur:cur + n])
+        cur += n
+    assert cur == len(ybody)
+    return zbody, out
+
+
+@pytest.mark.parametrize("kind", ["checkerboard", "basic-l0", "basic-l7", "channelwise4"])
+def test_streams_do_not_depend_on_batch_or_launch_shape(kind):
+    """One code path for any batch in the reference (pgm_coder.py:912-981): an image's stream must not depend on what it was
+    batched with.  The same 64 images are coded at batch 1, 3, 8 and 64 -- which takes the masked convolution through its
+    block-parallel, register-gather and LDS-DMA kernels and the scan-line coder through the persistent launch and the per-step
+    path -- and every image's y stream must EQUAL its batch-1 stream; the batch-8 streams are then decoded one image at a
+    time (another launch shape again) to exactly the latent the batched decoder returns."""
+    import struct
+    from cbench_basic_amd.presets import basic_codec, seed_synthetic_weights, topogroup_ar_codec
+    if kind.startswith("basic"):
+        codec = seed_synthetic_weights(basic_codec(), seed=0).eval().cuda()
+        codec.update_state()
+        codec.set_complex_level(int(kind[-1]))
+    elif kind == "channelwise4":
+        codec = seed_synthetic_weights(topogroup_ar_codec("channelwise", channel_groups=4), seed=0).eval().cuda()
+        codec.update_state()
+    else:
+        codec = seed_synthetic_weights(topogroup_ar_codec("checkerboard"), seed=0).eval().cuda()
+        codec.update_state()
+    ec = codec.entropy_coder
+    yc = ec.latent_node_entropy_coders["y"]
+    N = 64
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(N, 3, 64, 64, generator=g).cuda()
+    ref = []                                     # batch 1: one image at a time
+    for i in range(N if kind != "basic-l7" else 16):
+        data = codec.compress(x[i:i + 1])
+        ref.append(data)
+    n_ref = len(ref)
+
+    def y_stream_b1(d):      # a batch-1 stream: [u32 len(z)][z body][y stream (reference layout, no per-image table)]
+        (nz,) = struct.unpack("I", d[:4])
+        return d[4:4 + nz], d[4 + nz:]
+
+    for B in (3, 8, 64):
+        for i0 in range(0, n_ref - n_ref % B if n_ref >= B else 0, B):
+            data = codec.compress(x[i0:i0 + B])
+            zbody, streams = _image_streams(data, B)
+            for j, sj in enumerate(streams):
+                z1, y1 = y_stream_b1(ref[i0 + j])
+                assert sj == y1, (kind, B, i0 + j, len(sj), len(y1))
+            if B == 8 and i0 == 0:
+                xhat = codec.decompress(data)
+                for j in range(B):
+                    one = codec.decompress(ref[j])
+                    assert torch.equal(one[0], xhat[j]), (kind, j)

@@ -205,19 +205,40 @@ def test_masked_conv_positions(cfg):
     assert err <= TOL * max(1.0, float(ref.abs().max())), float(err)
 
 
+def _run_mconv_variants(plans, x, topo_in, topo_out, sel, cout, off, variants, **call):
+    """The same launch through several (plan, BASIC_MCONV_KERNEL) variants; returns the outputs on the host."""
+    import os
+    B, _, H, W = x.shape
+    outs = []
+    for pl, kernel in variants:
+        os.environ["BASIC_MCONV_KERNEL"] = kernel
+        try:
+            out = torch.full((B, cout + off, H, W), -7.0).cuda()
+            plans[pl](x.cuda(), topo_in.int().cuda(), topo_out.int().cuda(), sel.cuda(), out, out_offset=off, **call)
+            torch.cuda.synchronize()
+        finally:
+            del os.environ["BASIC_MCONV_KERNEL"]
+        outs.append(out.cpu())
+    return outs
+
+
 @pytest.mark.parametrize("seed", range(40))
 def test_masked_conv_fuzz(seed):
-    """Random channel counts / group structures / map sizes / position lists for the topo-group masked conv.  Every
-    case runs through ALL launch shapes (K split across workgroups / inside a workgroup for tiny launches, one wave per
-    1..5 row tiles for large ones; BASIC_MCONV_SPLITK_BELOW / _CROSS_BELOW move the switch-overs); the several-tiles-per-wave variants must agree bit for bit
-    with the one-tile-per-wave kernel (plan built under BASIC_MCONV_MAX_MT=1)."""
+    """Random channel counts / group structures / map sizes / position lists for the topo-group masked conv.  Every case runs
+    through ALL kernels (BASIC_MCONV_KERNEL: the register-gather kernel with the plan's row tiles per wave and with one tile
+    per wave, the block-parallel kernel + reduce of tiny launches, and -- where the layer qualifies -- the LDS-DMA kernel of
+    GEMM-shaped launches).  They all sum in the canonical order (csrc/mconv.hip), so their outputs must be IDENTICAL, bit for
+    bit: which kernel serves a launch may depend on the batch, the integers the coder derives from the sums may not."""
     import os
     from cbench_basic_amd.nn import kernels as K
     rng = np.random.default_rng(900 + seed)
     gi, go = int(rng.choice([1, 2, 3, 4, 6])), int(rng.choice([1, 2, 3, 4, 6]))
     cin, cout = gi * int(rng.integers(1, 40)), go * int(rng.integers(1, 40))
-    if seed % 2:  # whole 32-row tiles per group: 1..6 tiles -> the 1/2/3/4/5-tiles-per-wave variants
+    if seed % 2:  # whole 32-row tiles per group: 1..6 tiles -> the 1/2/3/4-tiles-per-wave variants
         cout = go * 32 * int(rng.integers(1, 7))
+    if seed % 4 == 3:  # a layer the LDS-DMA kernel takes: 128-row chunks, 32-channel stages (blocks of 64 and a 32 / 96 remainder)
+        gi, go = int(rng.choice([1, 2])), int(rng.choice([1, 2]))
+        cin, cout = gi * 32 * int(rng.integers(1, 6)), go * 128 * int(rng.integers(1, 3))
     k = int(rng.choice([1, 3, 5]))
     same = bool(rng.integers(0, 2))
     B, H, W = int(rng.integers(1, 4)), int(rng.integers(2, 20)), int(rng.integers(2, 20))
@@ -237,28 +258,63 @@ def test_masked_conv_fuzz(seed):
     npos = int(rng.integers(1, B * H * W + 1))
     sel = torch.randperm(B * H * W, generator=g)[:npos].sort().values.int()
     off = int(rng.choice([0, 3]))
-    outs = []
-    big = str(1 << 40)
-    # large-launch kernel (default pack / one tile per wave), split-K inside a workgroup, split-K across workgroups
-    for pl, split_below, cross_below in ((plan, "0", "0"), (plan_mt1, "0", "0"), (plan, big, "0"), (plan, big, big)):
-        os.environ["BASIC_MCONV_SPLITK_BELOW"], os.environ["BASIC_MCONV_CROSS_BELOW"] = split_below, cross_below
-        try:
-            out = torch.full((B, cout + off, H, W), -7.0).cuda()
-            pl(x.cuda(), topo_in.int().cuda(), topo_out.int().cuda(), sel.cuda(), out, out_offset=off)
-            torch.cuda.synchronize()
-        finally:
-            del os.environ["BASIC_MCONV_SPLITK_BELOW"], os.environ["BASIC_MCONV_CROSS_BELOW"]
-        outs.append(out.cpu())
-    assert torch.equal(outs[0], outs[1]), "tiles-per-wave variants disagree"
+    outs = _run_mconv_variants(dict(p=plan, p1=plan_mt1), x, topo_in, topo_out, sel, cout, off,
+                               [("p", "gather"), ("p1", "gather"), ("p", "block"), ("p", "dma")])
+    for i in (1, 2, 3):
+        assert torch.equal(outs[0], outs[i]), f"kernel variant {i} differs from the gather kernel"
     mask = torch.zeros(B * H * W, dtype=torch.bool)
     mask[sel.long()] = True
     mask = mask.reshape(B, 1, H, W)
-    for out in (outs[0], outs[2], outs[3]):
-        got = out[:, off:]
-        assert torch.all(out[:, :off] == -7.0)
-        assert torch.all(got[(~mask).expand_as(got)] == -7.0), "positions outside the list were touched"
-        err = ((got - ref).abs() * mask).max()
+    got = outs[0][:, off:]
+    assert torch.all(outs[0][:, :off] == -7.0)
+    assert torch.all(got[(~mask).expand_as(got)] == -7.0), "positions outside the list were touched"
+    err = ((got - ref).abs() * mask).max()
+    assert err <= TOL * max(1.0, float(ref.abs().max())), float(err)
+
+
+@pytest.mark.parametrize("case", ["merger", "context", "step"])
+def test_masked_conv_codec_sized_layers_all_kernels_identical(case):
+    """The layers of the 192-channel codecs at a GEMM-shaped size (8 images 16 x 16, checkerboard positions): the 768 -> 1536
+    merger layer (2 x 2 channel groups, the prior half masked for the context rows), the 5 x 5 context convolution, and the
+    coding-loop step rule with four channel groups -- LDS-DMA kernel == gather kernel == block kernel, bit for bit, and equal
+    to the fp32 reference within 1e-4."""
+    from cbench_basic_amd.nn import kernels as K
+    g = torch.Generator().manual_seed(7)
+    B, H, W = 8, 16, 16
+    yy, xx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+    cb = ((yy + xx) % 2).int()
+    call = {}
+    if case == "merger":
+        cin, cout, k, gi, go, same = 768, 1536, 1, 2, 2, True
+        topo_in = torch.stack([cb, torch.full_like(cb, -1)])
+        topo_out = topo_in.clone()
+    elif case == "context":
+        cin, cout, k, gi, go, same = 192, 384, 5, 1, 1, False
+        topo_in = cb[None].clone()
+        topo_out = cb[None].clone()
+    else:
+        cin, cout, k, gi, go, same = 256, 512, 3, 4, 4, False
+        topo_in = torch.stack([cb + 2 * i for i in range(4)])
+        topo_out = topo_in.clone()
+        call = dict(step=3, first_step=topo_in.min(0).values.int().cuda())
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) * (1.0 / (cin * k * k) ** 0.5)
+    b = torch.randn(cout, generator=g) * 0.1
+    plan = K.MaskedConvPlan(w, b, gi, go, same, K.ACT_LEAKY_RELU)
+    sel = torch.nonzero((cb.reshape(-1) == 1)[None].expand(B, -1).reshape(-1)).reshape(-1).int()
+    outs = _run_mconv_variants(dict(p=plan), x, topo_in, topo_out, sel, cout, 0, [("p", "gather"), ("p", "dma"), ("p", "block")], **call)
+    assert torch.equal(outs[0], outs[1]), "LDS-DMA kernel differs from the gather kernel"
+    assert torch.equal(outs[0], outs[2]), "block kernel differs from the gather kernel"
+    if case != "step":
+        ref = torch.nn.functional.leaky_relu(_masked_conv_ref(x, w, b, topo_in, topo_out, same), 0.01)
+        mask = torch.zeros(B * H * W, dtype=torch.bool)
+        mask[sel.long()] = True
+        mask = mask.reshape(B, 1, H, W)
+        err = ((outs[1] - ref).abs() * mask).max()
         assert err <= TOL * max(1.0, float(ref.abs().max())), float(err)
+    else:   # only (group, position) pairs whose id equals the step were written
+        wrote = (outs[1] != -7.0).reshape(B, 4, cout // 4, H, W).any(2)
+        assert torch.equal(wrote, ((topo_out == 3)[None] & (cb == 1)[None, None]).expand(B, -1, -1, -1))
 
 
 def test_entropy_param_kernels():
