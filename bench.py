@@ -55,6 +55,12 @@ def parse():
                          "(W batches in flight; the reference's pool also hands whole dataset items to its workers); "
                          "images = every step's batch is cut into W contiguous shards")
     ap.add_argument("--rans-waves", type=int, default=-1, help="image streams per rANS workgroup (-1: 8 for whole batches in flight, 4 for image shards, library default with one worker)")
+    ap.add_argument("--token-lanes", type=int, default=None,
+                    help="transform phases of the workers admitted at a time (1: full batches; 2: small batches, whose launches leave compute units idle); default by batch size")
+    ap.add_argument("--strong-workers", type=int, default=6,
+                    help="stream workers of the strong_per_gpu_proxy leg (total/8 images per step = one rank's share of the N = 8 strong-scaling leg)")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="bound of the CPU-baseline sample of the AR workload lines")
+    ap.add_argument("--no-ar-workloads", action="store_true", help="do not add the ar_workloads lines (child processes) to the N = 1 line")
     ap.add_argument("--cpu-images", type=int, default=2000, help="bounded CPU-baseline sample (images)")
     ap.add_argument("--input", default="hbm", choices=["hbm", "host"],
                     help="where the batch lives when the timed region starts: hbm = resident (the tier's contract for `value`), "
@@ -290,10 +296,10 @@ def run_ar_workload(args):
     events, flops, per_launch = [], [0], []
     orig = K.MaskedConvPlan.__call__
 
-    def timed(self, xin, topo_in, topo_out, pos, out, out_offset=0, step=None, first_step=None):
+    def timed(self, xin, topo_in, topo_out, pos, out, out_offset=0, step=None, first_step=None, **layout):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        r = orig(self, xin, topo_in, topo_out, pos, out, out_offset=out_offset, step=step, first_step=first_step)
+        r = orig(self, xin, topo_in, topo_out, pos, out, out_offset=out_offset, step=step, first_step=first_step, **layout)
         e1.record()
         events.append((e0, e1))
         ti, to = topo_in.cpu().numpy(), topo_out.cpu().numpy()
@@ -336,7 +342,7 @@ def run_ar_workload(args):
                                         + (f"{workers} concurrent stream workers (step k on worker k mod W: whole batches in flight)" if workers > 1 else "one stream"),
                            images_per_gpu=batch, workers=workers, bpp=len(data) * 8 / (batch * args.size ** 2), psnr_db=float((-10 * torch.log10(mse.double())).mean())),
                roofline=dict(bound="mfma", achieved=ach, peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_FP32_MFMA_TFLOPS, traffic=None,
-                             kernel="masked_conv_pos_kernel (+ masked_conv_reduce_kernel): the masked-convolution launches of one encode + decode pass "
+                             kernel="masked_conv_dma_kernel / masked_conv_gather_kernel / masked_conv_block_kernel + reduce (csrc/mconv.hip): the masked-convolution launches of one encode + decode pass "
                                     "of the y-coder (context convolution + merger layers at the coded positions), HIP events per launch",
                              flops_per_launch=flops[0] / max(1, len(events)), launches_per_pass=len(events), avg_launch_ms=mc_ms / max(1, len(events)),
                              pass_ms=mc_ms, note="algorithmic FLOPs = 2 x the (output, input, tap) products the reference's masks keep at the positions a step codes",
@@ -358,12 +364,36 @@ def run_ar_workload(args):
             xi = image(i, args.size).unsqueeze(0)
             oracle.decompress(oracle.compress(xi))
             done += 1
-            if time.time() - t0 > 15.0:
+            if time.time() - t0 > args.cpu_seconds:
                 break
         cdt = time.time() - t0
         out["cpu_baseline"] = dict(value=done * args.size ** 2 / cdt / 1e6, unit="Mpix/s", cores=cores, kind="port",
                                    sample=f"images 0..{done - 1} of the same synthetic set, batch 1, PyTorch-CPU fp32 oracle of the same graph, {cdt:.1f} s wall")
     print(json.dumps(out))
+
+
+def ar_workload_children(args):
+    """The AR parity configurations (BASELINE configs[2] / [3]) as extra keys of the N = 1 line: each runs `bench.py --workload W`
+    in a CHILD process started before this process touches the GPU (the workloads set HIP environment variables before HIP
+    initialises and instrument the masked-convolution binding), one after the other on the idle GPU; the child's JSON line is
+    kept without its per-launch table."""
+    import subprocess
+    out = {}
+    for w in ("checkerboard", "basic"):
+        cmd = [sys.executable, os.path.abspath(__file__), "--workload", w, "--steps", str(max(4, args.steps)), "--warmup", "2",
+               "--cpu-seconds", "8"] + (["--no-cpu-baseline"] if args.no_cpu_baseline else [])
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+            lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            if r.returncode != 0 or not lines:
+                out[w] = dict(error=f"exit code {r.returncode}", stderr_tail=r.stderr[-400:])
+                continue
+            d = json.loads(lines[-1])
+            d.get("roofline", {}).pop("launches", None)
+            out[w] = {k: d[k] for k in ("value", "unit", "ms_per_step", "steps", "config", "roofline", "cpu_baseline") if k in d}
+        except Exception as e:   # a failed extra line must not take the headline down, but it must be visible
+            out[w] = dict(error=repr(e))
+    return out
 
 
 def main():
@@ -372,6 +402,9 @@ def main():
         if args.gpus != 1:
             raise SystemExit("the AR workloads are single-GPU extra lines")
         return run_ar_workload(args)
+    ar_lines = None
+    if args.gpus == 1 and os.environ.get("WORLD_SIZE") is None and not args.no_ar_workloads and not args.no_extra_legs:
+        ar_lines = ar_workload_children(args)   # before anything here initialises the GPU
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is None and args.gpus > 1:
         raise SystemExit(self_launch(args))
@@ -411,12 +444,13 @@ def main():
     # packing more image streams into one rANS workgroup frees compute units for the other workers' transforms at the
     # price of a longer chain (+2 % at 4, +10 % at 8, x2 at 16): with whole batches in flight the chain has slack
     waves = args.rans_waves if args.rans_waves >= 0 else (8 if by_steps else 4 if workers > 1 else 0)
+    token_lanes = args.token_lanes if args.token_lanes is not None else (1 if args.batch >= 128 else 2)
 
-    def make_codec():
+    def make_codec(lanes=None):
         c = seed_synthetic_weights(hyperprior_codec(), seed=0).eval().to(dev)   # every replica: the same seeded weights
         c.update_state()
         c.entropy_coder.fused_rans_waves = waves
-        c.entropy_coder.fused_transform_token = workers > 1
+        c.entropy_coder.fused_transform_token = (token_lanes if lanes is None else lanes) if workers > 1 else 0
         return c
 
     def barrier():
@@ -424,7 +458,7 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    def run_leg(pool, batch, steps, warmup):
+    def run_leg(pool, batch, steps, warmup, workers=workers):
         """Exactly K steps (K x the whole batch through compress + decompress) spread over the workers; returns (seconds,
         bytes of one step, [(bytes, xhat)] of one whole batch in image order, mean seconds of one compress+decompress call)."""
         if by_steps:   # step k on worker k mod W: whole batches, W of them in flight
@@ -499,6 +533,23 @@ def main():
                                    images_total_per_step=args.total, images_per_gpu=len(ids),
                                    ms_per_step=sred["time_s"] / args.steps * 1e3,
                                    note="image i of the step's set on rank i mod world; compare with the N=1 line's value (256 images on one GPU)")
+        # (3) at N = 1: one rank's share of that strong leg on THIS GPU -- total / 8 images per step -- with the worker count and
+        #     token lanes a small batch needs (its ~12 ms of rANS chain latency per call against ~3 ms of transforms wants >= 5
+        #     batches in flight; its launches leave compute units idle, so two sessions' transform phases run side by side).
+        #     No data-path collective exists, so 8 x this figure is what the N = 8 strong leg can reach.
+        if world == 1 and by_steps and args.total // 8 >= 1:
+            sb, sw = args.total // 8, max(2, args.strong_workers)
+            pool.close()
+            pool = StreamWorkerPool(lambda: make_codec(2), sw, dev)
+            ssteps = max(8 * args.steps, 4 * sw)
+            pdt, _, _, pcall = run_leg(pool, x[:sb].contiguous(), ssteps, sw, workers=sw)
+            pv = sb * ssteps * args.size ** 2 / pdt / 1e6
+            extra["strong_per_gpu_proxy"] = dict(
+                value=pv, unit="Mpix/s", images_per_step=sb, steps=ssteps, workers=sw, batches_in_flight=sw, token_lanes=2,
+                ms_per_step=pdt / ssteps * 1e3, call_latency_ms=pcall * 1e3, frac_of_value=pv / (red["images"] * args.size ** 2 / red["time_s"] / 1e6),
+                predicted_8gpu_strong=8 * pv,
+                note=f"BASELINE configs[4] as written is {args.total} images per step over 8 GPUs = {sb} per GPU: this leg runs that share on one GPU "
+                     "(image-sharded, no data-path collective, so the N = 8 strong figure is 8 x it up to launch jitter)")
     pool.close()
 
     if rank == 0:
@@ -540,6 +591,8 @@ def main():
                           dominant=None if args.no_dominant else measure_dominant_kernel(codec, x)),
         )
         out.update(extra)
+        if ar_lines is not None:
+            out["ar_workloads"] = ar_lines
         if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only; at N > 1 the other ranks would just wait for it
             out["cpu_baseline"] = cpu_baseline(cpu_state, args.cpu_images, args.size)
         print(json.dumps(out))

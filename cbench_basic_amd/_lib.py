@@ -76,11 +76,13 @@ _SIGNATURES = {
     "basic_mconv_plan_create": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "basic_mconv_forward_pos_dev": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _L, _P, _I, _I, _P]),
     "basic_mconv_forward_step_dev": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _L, _P, _I, _I, _I, _P, _P]),
+    "basic_mconv_forward_ex_dev": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _L, _P, _I, _I, _I, _I, _P, _P, _P, _P]),
     "basic_mconv_plan_destroy": (None, [_P]),
     "basic_scanline_plan_create": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "basic_scanline_plan_info": (_I, [_P, _P, _P]),
     "basic_scanline_encode_dev": (_I, [_P, _P, _P, _I, _I, _I, _P, _I, _P, _P, _P, _P]),
     "basic_scanline_decode_dev": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _I, _P, _P, _P, _P]),
+    "basic_scanline_can_decode": (_I, [_P, _P, _I, _P]),
     "basic_scanline_status": (_I, [_P, _P, _P]),
     "basic_scanline_plan_destroy": (None, [_P]),
     "basic_mse_per_image_dev": (_I, [_P, _P, _I, _L, _P, _P]),

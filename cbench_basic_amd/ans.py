@@ -100,6 +100,7 @@ class _Rans64Base:
             self._freq_precision, int(self._bypass_coding), self._bypass_precision, ctypes.byref(h)))
         self._free()
         self._tables = h
+        self._host_sizes, self._host_offsets = (nsym + 2).copy(), offsets[: nsym.size].copy()   # _cdfs_sizes = nsym + 2 (rans64.cpp:128-159)
 
     def init_cdf_params(self, cdfs, cdfs_sizes, offsets):
         cdfs, sizes, offsets = _i32(cdfs), _i32(cdfs_sizes).reshape(-1), _i32(offsets).reshape(-1)
@@ -111,6 +112,37 @@ class _Rans64Base:
             self._freq_precision, int(self._bypass_coding), self._bypass_precision, ctypes.byref(h)))
         self._free()
         self._tables = h
+        self._host_sizes, self._host_offsets = sizes.copy(), offsets[: sizes.size].copy()
+
+    def create_ar_ptrs(self, indexes, ar_offsets):
+        """ANSBase::create_ar_ptrs (csrc/ans/ans_interface.cpp:34-73; bound on both coders, rans64.hpp:136,147): for every
+        autoregressive offset vector (one non-positive entry per data dimension after the batch dimension) the flat position
+        of each element's AR neighbour, or -1 where the neighbour would fall outside a dimension.  Host-side index
+        arithmetic only."""
+        ix = np.asarray(indexes)
+        n, nd = ix.size, ix.ndim
+        strides = [st // ix.itemsize for st in ix.strides]
+        out = []
+        for vec in ar_offsets:
+            vec = [int(v) for v in vec]
+            if any(v > 0 for v in vec):
+                raise ValueError("ar_offset should be non-positive!")
+            reach = (ix.shape[0] - 1) * strides[0]
+            limits = []          # (steps back, stride of the dimension, stride of the dimension before it)
+            for j in range(nd - 1):
+                cur = vec[j] if j < len(vec) else 0
+                if cur < 0:
+                    limits.append((-cur, strides[j], strides[j + 1]))
+                reach += (ix.shape[j + 1] - 1 + cur) * strides[j + 1]
+            back = n - 1 - reach
+            k = np.arange(n, dtype=np.int64)
+            ok = np.ones(n, dtype=bool)
+            for steps, outer, inner in limits:
+                # the reference's test AS WRITTEN (:59-62) compares k % (inner stride) with the OUTER stride, which is never
+                # smaller: with any negative offset every entry comes out -1 (pinned by tests/golden/rans_cache_kat.npz)
+                ok &= (k % inner) >= outer
+            out.append(np.where(ok, k - back, -1).tolist())
+        return out
 
     def init_ar_params(self, ar_table, ar_offsets):
         """ANSBase::init_ar_params, csrc/ans/ans_interface.cpp:75-137."""
@@ -210,7 +242,39 @@ class Rans64Encoder(_Rans64Base):
         return self.encode_with_indexes(symbols, indexes)
 
     def peek_cache(self):
-        raise NotImplementedError("peek_cache is a debugging aid of the reference (rans64.hpp:78-86)")
+        """rans64.hpp:78-86: the cached rANS symbols as int32 [m, 3] rows (start, range, bypass flag) in the order flush()
+        codes them: per cached call its elements last to first, an escaped element's bypass digits -- count nibble(s), then
+        the value's nibbles -- in REVERSE before the element's own (sentinel) symbol (rans64.cpp:292-344).  Host-side
+        bookkeeping on the table set's integer CDFs (a debugging aid: nothing is coded here)."""
+        if self._tables is None:
+            raise ValueError("ANS not initialized!")
+        cdfs, sizes, offs = self.get_cdfs(), self._host_sizes, self._host_offsets
+        bp, mb = self._bypass_precision, (1 << self._bypass_precision) - 1
+        rows = []
+        for symbols, indexes in self._cache:
+            for i in range(symbols.size - 1, -1, -1):
+                r = int(indexes[i])
+                maxv, v, raw = int(sizes[r]) - 2, int(symbols[i]) - int(offs[r]), 0
+                if self._bypass_coding:
+                    if v < 0:
+                        raw, v = -2 * v - 1, maxv
+                    elif v >= maxv:
+                        raw, v = 2 * (v - maxv), maxv
+                if not 0 <= v < int(sizes[r]) - 1:
+                    raise ValueError("symbol outside its table and bypass coding is off")
+                if self._bypass_coding and v == maxv:
+                    digits, nb = [], 0
+                    while (raw >> (nb * bp)) != 0:
+                        nb += 1
+                    val = nb
+                    while val >= mb:
+                        digits.append((mb, 0, 1))
+                        val -= mb
+                    digits.append((val, val + 1, 1))
+                    digits.extend((((raw >> (j * bp)) & mb), ((raw >> (j * bp)) & mb) + 1, 1) for j in range(nb))
+                    rows.extend(reversed(digits))
+                rows.append((int(cdfs[r, v]) & 0xFFFF, (int(cdfs[r, v + 1]) - int(cdfs[r, v])) & 0xFFFF, 0))
+        return np.array(rows, dtype=np.int32).reshape(-1, 3)
 
 
 class Rans64Decoder(_Rans64Base):

@@ -90,11 +90,18 @@ class StreamWorkerPool:
                 f.clear() if stagger else f.set()
         for i, s in enumerate(shards):
             job = fn
-            if stagger and i > 0:
+            if stagger:
                 def job(codec, arg, i=i, fn=fn):
-                    self._gate_flag[i - 1].wait()
-                    self.streams[i].wait_event(self._gate_evt[i - 1])
-                    return fn(codec, arg)
+                    try:
+                        if i > 0:
+                            self._gate_flag[i - 1].wait()
+                            self.streams[i].wait_event(self._gate_evt[i - 1])
+                        return fn(codec, arg)
+                    finally:
+                        # a job that raised, or never reached encode()'s hook, must still open the gate of the next worker
+                        if not self._gate_flag[i].is_set():
+                            self._gate_evt[i].record(self.streams[i])
+                            self._gate_flag[i].set()
             self._jobs[i].put((job, s, i))
         out, err = [None] * len(shards), None
         for _ in shards:

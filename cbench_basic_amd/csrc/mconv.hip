@@ -72,6 +72,11 @@ struct MaskedLaunch {
     int64_t n_pos;
     int batch, cin, cout, coutp, h, w_, gi, go, gs_in, gs_out, tiles_per_group;
     int out_total, out_off, ntaps, pad, ksize, allow_same, act;
+    // optional position permutations of the planes of x / y (nullptr = row-major p = py * W + px): element (b, c, p) sits at
+    // (b * C + c) * HW + perm[p].  The coder keeps its PRIVATE hidden activations (between the 1x1 merger layers) with the
+    // positions of a coding step contiguous, so that a step's gathers and stores cover whole cache lines (a checkerboard
+    // step in row-major planes touches every other float: half of every line fetched and half of every sector written).
+    const int32_t *in_perm, *out_perm;
     int step;              // coding step (topo group being coded), or kNoStep: see the skip rule in the kernel
     const int32_t *first;  // [H][W] first step that visits a position (min over channel groups), or nullptr
     int mt;                // pack factor of w (gather kernel): row r of a group sits at (r / (32 mt)) * 32 mt + (r % 32) * mt + (r / 32) % mt
@@ -81,6 +86,7 @@ struct MaskedLaunch {
     int units, blocks_per_slab;
     // dma kernel
     int n_pchunks, n_rchunks, x_bytes;
+    int debug;   // BASIC_MCONV_DEBUG timing ablations of the dma kernel (wrong results): 1 no staging, 4 no stores
 };
 
 constexpr int kNoStep = INT32_MIN;
@@ -121,6 +127,13 @@ __device__ __forceinline__ bool tap_open(const MaskedLaunch &g, int gin, bool in
     if (!inside) return false;
     const int32_t tn = g.topo_in[gin * g.h * g.w_ + noff];
     return g.allow_same ? (tn <= centre) : (tn < centre);
+}
+
+__device__ __forceinline__ int in_slot(const MaskedLaunch &g, int noff) { return g.in_perm ? g.in_perm[noff] : noff; }
+__device__ __forceinline__ int out_slot(const MaskedLaunch &g, const Pos &p)
+{
+    const int q = p.py * g.w_ + p.px;
+    return g.out_perm ? g.out_perm[q] : q;
 }
 
 // bias, then the activation FUSED after the layer -- written with selects on launch-uniform values so that the 64 epilogue
@@ -187,6 +200,7 @@ __global__ __launch_bounds__(64) void masked_conv_gather_kernel(const MaskedLaun
         for (int gin = 0; gin < g.gi; ++gin) {
             const bool open = tap_open(g, gin, inside, noff, centre);
             if (__ballot(open) == 0ull) continue;  // wave-uniform skip of an all-masked slab
+            const int xoff = open ? in_slot(g, noff) : 0;
             const int c_beg = gin * g.gs_in, c_end = c_beg + g.gs_in;
             const float *wt = g.w + (static_cast<int64_t>(t) * g.cin) * g.coutp + a_off;
             for (int c0 = c_beg; c0 < c_end; c0 += kKB) {       // canonical block: its own chain, then one add per element
@@ -203,7 +217,7 @@ __global__ __launch_bounds__(64) void masked_conv_gather_kernel(const MaskedLaun
                         const int ci = c + u * 2 + khalf;
                         const bool ci_ok = ci < c1;
                         load_a<MT>(wt + static_cast<int64_t>(ci) * g.coutp, row_ok && ci_ok, af[u]);
-                        bf[u] = (open && ci_ok) ? xb[static_cast<int64_t>(ci) * hw + noff] : 0.f;
+                        bf[u] = (open && ci_ok) ? xb[static_cast<int64_t>(ci) * hw + xoff] : 0.f;
                     }
 #pragma unroll
                     for (int u = 0; u < kUnroll; ++u)
@@ -220,7 +234,7 @@ __global__ __launch_bounds__(64) void masked_conv_gather_kernel(const MaskedLaun
     }
 
     if (p.ok) {
-        float *yb = g.y + (static_cast<int64_t>(p.b) * g.out_total + g.out_off) * hw + p.py * g.w_ + p.px;
+        float *yb = g.y + (static_cast<int64_t>(p.b) * g.out_total + g.out_off) * hw + out_slot(g, p);
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -270,6 +284,7 @@ __global__ __launch_bounds__(256) void masked_conv_block_kernel(const MaskedLaun
         if (lane == 0) *flag = 0;
         return;
     }
+    const int xoff = open ? in_slot(g, noff) : 0;
     const int c_beg = gin * g.gs_in, c_end = c_beg + g.gs_in;
     const int c0 = c_beg + blk_i * kKB, c1 = c0 + kKB < c_end ? c0 + kKB : c_end;
     const float *wt = g.w + (static_cast<int64_t>(t) * g.cin) * g.coutp + a_off;
@@ -283,7 +298,7 @@ __global__ __launch_bounds__(256) void masked_conv_block_kernel(const MaskedLaun
             const int ci = c + u * 2 + khalf;
             const bool ci_ok = ci < c1;
             af[u] = (row_ok && ci_ok) ? wt[static_cast<int64_t>(ci) * g.coutp] : 0.f;
-            bf[u] = (open && ci_ok) ? xb[static_cast<int64_t>(ci) * hw + noff] : 0.f;
+            bf[u] = (open && ci_ok) ? xb[static_cast<int64_t>(ci) * hw + xoff] : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < kBlockUnroll; ++u) blk = __builtin_amdgcn_mfma_f32_32x32x2f32(af[u], bf[u], blk, 0, 0, 0);
@@ -328,7 +343,7 @@ __global__ __launch_bounds__(256) void masked_conv_reduce_kernel(const MaskedLau
             }
     }
     if (!p.ok) return;
-    float *yb = g.y + (static_cast<int64_t>(p.b) * g.out_total + g.out_off) * hw + p.py * g.w_ + p.px;
+    float *yb = g.y + (static_cast<int64_t>(p.b) * g.out_total + g.out_off) * hw + out_slot(g, p);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int rg = ti * 32 + 8 * wave + 4 * khalf + q;
@@ -342,8 +357,8 @@ __global__ __launch_bounds__(256) void masked_conv_reduce_kernel(const MaskedLau
 // ---------------------------------------------------------------------------------------------------------------------
 // GEMM-shaped launches.  Workgroup = 8 waves = one 128-row chunk of an output channel group x 256 listed positions; wave w
 // owns all 128 rows (4 accumulator tiles) of positions 32w .. 32w+31.  K is walked kDmaCK = 32 channels of one (tap, input
-// group) slab per stage through two LDS stage buffers { A [32 k][32 cols][4 tiles] | B [32 k][256 positions] } filled by
-// LDS-DMA one stage ahead of the MFMAs:
+// group) slab per stage through three LDS stage buffers { A [32 k][32 cols][4 tiles] | B [32 k][256 positions] } filled by
+// LDS-DMA a stage and a half ahead of the MFMAs:
 //   A  16-byte pieces of the pre-packed slab [row chunk][tap][ci][32][4] (contiguous per stage: two instructions per lane);
 //   B  buffer_load_dword ... lds, one position per lane: the lane's byte offset of (image, neighbour position) in a VGPR --
 //      0x80000000 = out of range = the hardware writes ZERO for a masked / padded / unlisted element -- and the channel
@@ -358,22 +373,25 @@ constexpr int kDmaWaves = 8, kDmaThreads = 64 * kDmaWaves, kDmaCK = 32, kDmaPos 
 constexpr int kDmaAFloats = kDmaCK * 32 * 4, kDmaBFloats = kDmaCK * kDmaPos, kDmaStage = kDmaAFloats + kDmaBFloats;
 constexpr int kDmaMaxSlabs = 64;
 constexpr unsigned kOutOfRange = 0x80000000u;
-constexpr size_t kDmaLdsBytes = (2 * kDmaStage + 64 + kDmaRows) * sizeof(float);
+constexpr int kDmaBufs = 3;
+constexpr size_t kDmaLdsBytes = (kDmaBufs * kDmaStage + 64 + kDmaRows) * sizeof(float);
 
 __global__ __launch_bounds__(kDmaThreads, 1) void masked_conv_dma_kernel(const MaskedLaunch g)
 {
     extern __shared__ float lds[];
-    unsigned *s_open = reinterpret_cast<unsigned *>(lds + 2 * kDmaStage);   // [2] slab bitmask, [2] step-rule flag
-    float *s_bias = lds + 2 * kDmaStage + 64;
+    unsigned *s_open = reinterpret_cast<unsigned *>(lds + kDmaBufs * kDmaStage);   // [2] slab bitmask, [2] step-rule flag
+    float *s_bias = lds + kDmaBufs * kDmaStage + 64;
     const int tid = threadIdx.x, lane = tid & 63, col = lane & 31, khalf = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // workgroup -> (position chunk, row chunk): ids b, b + 8, b + 16 .. share an XCD; consecutive slots of an XCD walk the
     // row chunks of one position chunk
+    // ... and output group by output group: the workgroups of one group do the same amount of work, and when the groups differ
+    // (the merger's id-less groups see only the prior half of the inputs) the cheap ones come last, where they cost the least tail
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int pc = (slot / g.n_rchunks) * 8 + xcd, rc = slot % g.n_rchunks;
+    const int chunks_per_group = g.gs_out / kDmaRows, pcs_per_xcd = (g.n_pchunks + 7) >> 3;
+    const int grp_o = slot / (pcs_per_xcd * chunks_per_group), rem = slot - grp_o * pcs_per_xcd * chunks_per_group;
+    const int pc = (rem / chunks_per_group) * 8 + xcd, rc = grp_o * chunks_per_group + rem % chunks_per_group;
     if (pc >= g.n_pchunks) return;
-    const int chunks_per_group = g.gs_out / kDmaRows;
-    const int grp_o = rc / chunks_per_group;
     const int row0 = grp_o * g.gs_out + (rc - grp_o * chunks_per_group) * kDmaRows;   // first output channel of the chunk
     const int hw = g.h * g.w_;
 
@@ -405,8 +423,45 @@ __global__ __launch_bounds__(kDmaThreads, 1) void masked_conv_dma_kernel(const M
         for (int d = 32; d > 0; d >>= 1) { lo |= __shfl_xor(lo, d, 64); hi |= __shfl_xor(hi, d, 64); }
         if (lane == 0) { atomicOr(&s_open[0], lo); atomicOr(&s_open[1], hi); }
     }
+    // WIDE staging of B (1x1 layers): when the workgroup's 256 listed positions come in aligned runs of four that are
+    // contiguous in memory (the step-contiguous plane order of the coder's hidden activations, see in_perm) and share their
+    // masks, lane l stages positions 4 l .. 4 l + 3 of a k row with ONE 16-byte piece: 4 gathers per wave and stage instead
+    // of 16 (the texture-address unit takes ~33 cycles per 64-lane gather whatever its width, and 144 of them per stage did
+    // not hide under a 64-MFMA stage).  Checked per workgroup; anything else takes the 4-byte gathers.
+    unsigned wide_voff = kOutOfRange;
+    uint64_t wide_open = 0ull;
+    {
+        bool okw = g.ksize == 1 && (hw & 3) == 0;
+        if (okw) {
+            const int64_t j0 = static_cast<int64_t>(pc) * kDmaPos + 4 * lane;
+            const Pos p0 = decode_pos(g, j0);
+            if (p0.ok) {
+                const int s0 = in_slot(g, p0.py * g.w_ + p0.px);
+                const int32_t c0 = g.topo_out[grp_o * hw + p0.py * g.w_ + p0.px];
+                okw = (s0 & 3) == 0;
+                for (int gin = 0; gin < g.gi; ++gin)
+                    if (tap_open(g, gin, true, p0.py * g.w_ + p0.px, c0)) wide_open |= 1ull << gin;
+                for (int i = 1; i < 4 && okw; ++i) {
+                    const Pos pi = decode_pos(g, j0 + i);
+                    okw = pi.ok && pi.b == p0.b && in_slot(g, pi.py * g.w_ + pi.px) == s0 + i;
+                    if (okw) {
+                        const int32_t ci = g.topo_out[grp_o * hw + pi.py * g.w_ + pi.px];
+                        uint64_t oi = 0ull;
+                        for (int gin = 0; gin < g.gi; ++gin)
+                            if (tap_open(g, gin, true, pi.py * g.w_ + pi.px, ci)) oi |= 1ull << gin;
+                        okw = oi == wide_open;
+                    }
+                }
+                wide_voff = (static_cast<unsigned>(p0.b) * static_cast<unsigned>(g.cin) * static_cast<unsigned>(hw) + static_cast<unsigned>(s0)) * 4u;
+            } else {
+                for (int i = 1; i < 4; ++i) okw = okw && !decode_pos(g, j0 + i).ok;   // a run is listed entirely or not at all
+            }
+        }
+        if (!okw) atomicOr(&s_open[3], 1u);
+    }
     __syncthreads();
     if (g.step != kNoStep && s_open[2] == 0u) return;   // workgroup-uniform
+    const bool wide = __builtin_amdgcn_readfirstlane(s_open[3]) == 0u;
     uint64_t todo = static_cast<uint64_t>(__builtin_amdgcn_readfirstlane(s_open[0])) |
                     (static_cast<uint64_t>(__builtin_amdgcn_readfirstlane(s_open[1])) << 32);
     const int stages_per_slab = g.gs_in / kDmaCK;
@@ -429,23 +484,35 @@ __global__ __launch_bounds__(kDmaThreads, 1) void masked_conv_dma_kernel(const M
     int is_t = is_slab / g.gi, is_gin = is_slab - is_t * g.gi;
     auto slab_voffset = [&](int s, int t) __attribute__((always_inline)) {
         const int yy = dp.py + t / g.ksize - g.pad, xx = dp.px + t % g.ksize - g.pad;
-        const unsigned off = img_off + static_cast<unsigned>(yy * g.w_ + xx) * 4u;
-        return ((my_open >> s) & 1ull) ? off : kOutOfRange;
+        if (wide) return ((wide_open >> s) & 1ull) ? wide_voff : kOutOfRange;   // 1x1 layer: slab = input group, the lane's own run
+        const bool on = (my_open >> s) & 1ull;
+        return on ? img_off + static_cast<unsigned>(in_slot(g, yy * g.w_ + xx)) * 4u : kOutOfRange;
     };
     unsigned voff = nstages > 0 ? slab_voffset(is_slab, is_t) : kOutOfRange;
 
-#define BASIC_MCONV_ISSUE(BUF)                                                                                                  \
+    // The DMA of one stage = 2 pieces of A (16 bytes per lane) + 16 gathers of B, then the issue state moves on.  It is issued in
+    // PIECES spread over the MFMA steps that follow the stage barrier: a wave that issues its 18 vector-memory instructions
+    // back to back blocks in the issue stage until the texture-address unit has taken them (~33 cycles per 64-lane gather, all
+    // eight waves at once: thousands of cycles without an MFMA, measured as +20 % kernel time).
+    int ci0_i = 0;
+    float *dst_i = nullptr;
+    const float *srca_i = nullptr;
+#define BASIC_MCONV_ISSUE_BEGIN(BUF)                                                                                            \
     do {                                                                                                                        \
-        const int ci0_ = is_gin * g.gs_in + is_j * kDmaCK;                                                                      \
-        float *dsta_ = lds + (BUF) * kDmaStage;                                                                                 \
-        const float *srca_ = wchunk + (static_cast<int64_t>(is_t) * g.cin + ci0_) * 128 + tid * 4;                              \
-        __builtin_amdgcn_global_load_lds((glb_cvoid *)srca_, (lds_void *)(dsta_ + wave * 256), 16, 0, 0);                       \
-        __builtin_amdgcn_global_load_lds((glb_cvoid *)(srca_ + 2048), (lds_void *)(dsta_ + 2048 + wave * 256), 16, 0, 0);       \
-        float *dstb_ = dsta_ + kDmaAFloats + (wave & 3) * 64;                                                                   \
-        const int k0_ = wave >> 2;                                                                                              \
-        _Pragma("unroll") for (int i_ = 0; i_ < kDmaCK / 2; ++i_)                                                               \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_void *)(dstb_ + (2 * i_ + k0_) * kDmaPos), 4, voff,            \
-                                                     (ci0_ + 2 * i_ + k0_) * hw * 4, 0, 0);                                     \
+        ci0_i = is_gin * g.gs_in + is_j * kDmaCK;                                                                               \
+        dst_i = lds + (BUF) * kDmaStage;                                                                                        \
+        srca_i = wchunk + (static_cast<int64_t>(is_t) * g.cin + ci0_i) * 128 + tid * 4;                                         \
+    } while (0)
+#define BASIC_MCONV_ISSUE_A(J)                                                                                                  \
+    __builtin_amdgcn_global_load_lds((glb_cvoid *)(srca_i + (J) * 2048), (lds_void *)(dst_i + (J) * 2048 + wave * 256), 16, 0, 0)
+#define BASIC_MCONV_ISSUE_B(I)                                                                                                  \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_void *)(dst_i + kDmaAFloats + (wave & 3) * 64 + (2 * (I) + (wave >> 2)) * kDmaPos), \
+                                             4, voff, (ci0_i + 2 * (I) + (wave >> 2)) * hw * 4, 0, 0)
+#define BASIC_MCONV_ISSUE_BW(I)   /* wide: k row 4 wave + I, 16 bytes = four positions per lane */                          \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_void *)(dst_i + kDmaAFloats + (4 * wave + (I)) * kDmaPos), 16, voff,   \
+                                             (ci0_i + 4 * wave + (I)) * hw * 4, 0, 0)
+#define BASIC_MCONV_ISSUE_END()                                                                                                 \
+    do {                                                                                                                        \
         if (++is_j == stages_per_slab) {                                                                                        \
             is_j = 0;                                                                                                           \
             is_todo &= is_todo - 1;                                                                                             \
@@ -457,29 +524,71 @@ __global__ __launch_bounds__(kDmaThreads, 1) void masked_conv_dma_kernel(const M
             }                                                                                                                   \
         }                                                                                                                       \
     } while (0)
+#define BASIC_MCONV_ISSUE(BUF)                                                                                                  \
+    do {                                                                                                                        \
+        BASIC_MCONV_ISSUE_BEGIN(BUF);                                                                                           \
+        BASIC_MCONV_ISSUE_A(0);                                                                                                 \
+        BASIC_MCONV_ISSUE_A(1);                                                                                                 \
+        if (wide) {                                                                                                             \
+            _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) BASIC_MCONV_ISSUE_BW(i_);                                          \
+        } else {                                                                                                                \
+            _Pragma("unroll") for (int i_ = 0; i_ < kDmaCK / 2; ++i_) BASIC_MCONV_ISSUE_B(i_);                                  \
+        }                                                                                                                       \
+        BASIC_MCONV_ISSUE_END();                                                                                                \
+    } while (0)
 
-    if (nstages > 0) BASIC_MCONV_ISSUE(0);
+    // Pipeline: THREE stage buffers and ONE workgroup barrier per stage, placed in the MIDDLE of the stage.  At the barrier of
+    // stage n every wave has waited for its own DMAs of stage n+1 (issued a whole stage earlier) -- so after it stage n+1 is
+    // complete in LDS -- and every wave has left stage n-1, whose buffer the DMA of stage n+2 (issued right after the barrier)
+    // overwrites.  The MFMA stream of a wave therefore runs across stage boundaries without a pause: the first fragments of
+    // stage n+1 are read during the last step of stage n.  (With the barrier at the stage boundary and two buffers, every
+    // wave of the workgroup stopped there together, issued its DMAs and waited for its first LDS reads: ~25 % of the time of
+    // a 64-MFMA stage, measured with the staging switched off.)
+    if (nstages > 0 && !(g.debug & 1)) {
+        BASIC_MCONV_ISSUE(0);
+        if (nstages > 1) BASIC_MCONV_ISSUE(1);
+    }
+    __syncthreads();   // stages 0 and 1 have landed
     const int a_lane = (khalf * 32 + col) * 4, b_lane = khalf * kDmaPos + wave * 32 + col;
+    float fb[2];
+    f32x4 fa[2];
+    fb[0] = lds[kDmaAFloats + b_lane];
+    fa[0] = *reinterpret_cast<const f32x4 *>(lds + a_lane);
+    int buf = 0;   // stage buffer of the current stage (stg % 3)
     // one stage: 16 steps of { next step's LDS reads, 4 MFMAs }.  FIRST = first stage of a canonical block: the chain starts
     // from an inline-constant 0 (no register initialisation).
     auto run_stage = [&](int stg, auto first_tag) __attribute__((always_inline)) {
         constexpr bool kFirst = decltype(first_tag)::value;
-        // my DMAs of this stage have landed (vmcnt(0), part of the barrier's fence) + every wave is past the previous
-        // stage, whose buffer the next DMA overwrites
-        __syncthreads();
-        if (stg + 1 < nstages) BASIC_MCONV_ISSUE((stg + 1) & 1);
-        const float *al = lds + (stg & 1) * kDmaStage + a_lane;
-        const float *bl = lds + (stg & 1) * kDmaStage + kDmaAFloats + b_lane;
-        float fb[2];
-        f32x4 fa[2];
-        fb[0] = bl[0];
-        fa[0] = *reinterpret_cast<const f32x4 *>(al);
+        constexpr int kSteps = kDmaCK / 2;
+        const int nbuf = buf == 2 ? 0 : buf + 1;
+        const float *al = lds + buf * kDmaStage + a_lane, *bl = al + (kDmaAFloats + b_lane - a_lane);
+        const float *aln = lds + nbuf * kDmaStage + a_lane, *bln = aln + (kDmaAFloats + b_lane - a_lane);
+        const bool issuing = stg + 2 < nstages && !(g.debug & 1);
 #pragma unroll
-        for (int st = 0; st < kDmaCK / 2; ++st) {
+        for (int st = 0; st < kSteps; ++st) {
             const int cur = st & 1, nxt = cur ^ 1;
-            const int sn = st + 1 < kDmaCK / 2 ? st + 1 : st;
-            fb[nxt] = bl[sn * 2 * kDmaPos];
-            fa[nxt] = *reinterpret_cast<const f32x4 *>(al + sn * 2 * 128);
+            if (st == kSteps / 2) {
+                __syncthreads();   // vmcnt(0): my DMAs of stage stg+1 have landed; barrier: everyone's have, and stage stg-1 is free
+                if (issuing) BASIC_MCONV_ISSUE_BEGIN(buf == 0 ? 2 : buf - 1);
+            }
+            if (st >= kSteps / 2 && issuing) {   // stage stg+2's DMA, two or three pieces per step
+                const int q = st - kSteps / 2;
+                if (q < 2) BASIC_MCONV_ISSUE_A(q);
+                if (wide) {
+                    if (q < 4) BASIC_MCONV_ISSUE_BW(q);
+                } else {
+                    BASIC_MCONV_ISSUE_B(2 * q);
+                    BASIC_MCONV_ISSUE_B(2 * q + 1);
+                }
+                if (st == kSteps - 1) BASIC_MCONV_ISSUE_END();
+            }
+            if (st + 1 < kSteps) {
+                fb[nxt] = bl[(st + 1) * 2 * kDmaPos];
+                fa[nxt] = *reinterpret_cast<const f32x4 *>(al + (st + 1) * 2 * 128);
+            } else {   // first fragments of the next stage (complete since this stage's barrier; a harmless read after the last stage)
+                fb[nxt] = bln[0];
+                fa[nxt] = *reinterpret_cast<const f32x4 *>(aln);
+            }
             __builtin_amdgcn_sched_barrier(0);
             if (kFirst && st == 0) {
 #pragma unroll
@@ -490,8 +599,9 @@ __global__ __launch_bounds__(kDmaThreads, 1) void masked_conv_dma_kernel(const M
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        buf = nbuf;
     };
-    static_assert(kKB == 2 * kDmaCK, "a canonical block is two stages");
+    static_assert(kKB == 2 * kDmaCK && (kDmaCK / 2) % 2 == 0, "a canonical block is two stages of an even number of steps");
     for (int stg = 0; stg < nstages; stg += 2) {     // gs_in % kKB == 0 (host-checked): every block is exactly two stages
         run_stage(stg, std::true_type{});
         run_stage(stg + 1, std::false_type{});
@@ -502,9 +612,14 @@ __global__ __launch_bounds__(kDmaThreads, 1) void masked_conv_dma_kernel(const M
             for (int r = 0; r < 16; ++r) acc[m][r] += blk[m][r];
     }
 #undef BASIC_MCONV_ISSUE
+#undef BASIC_MCONV_ISSUE_BEGIN
+#undef BASIC_MCONV_ISSUE_A
+#undef BASIC_MCONV_ISSUE_B
+#undef BASIC_MCONV_ISSUE_BW
+#undef BASIC_MCONV_ISSUE_END
 
-    if (mp.ok) {
-        float *yb = g.y + (static_cast<int64_t>(mp.b) * g.out_total + g.out_off + row0) * hw + mp.py * g.w_ + mp.px;
+    if (mp.ok && !(g.debug & 4)) {
+        float *yb = g.y + (static_cast<int64_t>(mp.b) * g.out_total + g.out_off + row0) * hw + out_slot(g, mp);
 #pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -614,7 +729,8 @@ extern "C" int basic_mconv_plan_create(const float *weight, const float *bias, i
 
 static int mconv_forward(const basic_mconv_plan *p, const float *d_x, const int32_t *d_topo_in, const int32_t *d_topo_out,
                          int batch, int h, int w, const int32_t *d_pos, int64_t n_pos, float *d_y, int out_channels_total,
-                         int out_channel_offset, int step, const int32_t *d_first, void *hip_stream);
+                         int out_channel_offset, int step, const int32_t *d_first, const int32_t *d_in_perm,
+                         const int32_t *d_out_perm, void *hip_stream);
 
 extern "C" int basic_mconv_forward_pos_dev(const basic_mconv_plan *p, const float *d_x, const int32_t *d_topo_in,
                                            const int32_t *d_topo_out, int batch, int h, int w, const int32_t *d_pos,
@@ -622,7 +738,7 @@ extern "C" int basic_mconv_forward_pos_dev(const basic_mconv_plan *p, const floa
                                            void *hip_stream)
 {
     return mconv_forward(p, d_x, d_topo_in, d_topo_out, batch, h, w, d_pos, n_pos, d_y, out_channels_total, out_channel_offset,
-                         kNoStep, nullptr, hip_stream);
+                         kNoStep, nullptr, nullptr, nullptr, hip_stream);
 }
 
 extern "C" int basic_mconv_forward_step_dev(const basic_mconv_plan *p, const float *d_x, const int32_t *d_topo_in,
@@ -632,12 +748,25 @@ extern "C" int basic_mconv_forward_step_dev(const basic_mconv_plan *p, const flo
 {
     BASIC_REQUIRE(d_first_step && step != kNoStep, "mconv_forward_step: first-step map and a step are required");
     return mconv_forward(p, d_x, d_topo_in, d_topo_out, batch, h, w, d_pos, n_pos, d_y, out_channels_total, out_channel_offset,
-                         step, d_first_step, hip_stream);
+                         step, d_first_step, nullptr, nullptr, hip_stream);
+}
+
+extern "C" int basic_mconv_forward_ex_dev(const basic_mconv_plan *p, const float *d_x, const int32_t *d_topo_in,
+                                          const int32_t *d_topo_out, int batch, int h, int w, const int32_t *d_pos,
+                                          int64_t n_pos, float *d_y, int out_channels_total, int out_channel_offset,
+                                          int use_step, int step, const int32_t *d_first_step, const int32_t *d_in_perm,
+                                          const int32_t *d_out_perm, void *hip_stream)
+{
+    BASIC_REQUIRE(!use_step || (d_first_step && step != kNoStep), "mconv_forward_ex: first-step map and a step are required");
+    BASIC_REQUIRE(p && (!d_in_perm || p->ksize == 1), "mconv_forward_ex: an input permutation needs a 1x1 layer (no neighbours)");
+    return mconv_forward(p, d_x, d_topo_in, d_topo_out, batch, h, w, d_pos, n_pos, d_y, out_channels_total, out_channel_offset,
+                         use_step ? step : kNoStep, use_step ? d_first_step : nullptr, d_in_perm, d_out_perm, hip_stream);
 }
 
 static int mconv_forward(const basic_mconv_plan *p, const float *d_x, const int32_t *d_topo_in, const int32_t *d_topo_out,
                          int batch, int h, int w, const int32_t *d_pos, int64_t n_pos, float *d_y, int out_channels_total,
-                         int out_channel_offset, int step, const int32_t *d_first, void *hip_stream)
+                         int out_channel_offset, int step, const int32_t *d_first, const int32_t *d_in_perm,
+                         const int32_t *d_out_perm, void *hip_stream)
 {
     BASIC_REQUIRE(p && d_x && d_topo_in && d_topo_out && d_pos && d_y && batch >= 1 && h >= 1 && w >= 1 && n_pos >= 0,
                   "mconv_forward_pos: bad argument");
@@ -652,7 +781,7 @@ static int mconv_forward(const basic_mconv_plan *p, const float *d_x, const int3
     g.tiles_per_group = (g.gs_out + 31) / 32;
     g.out_total = out_channels_total; g.out_off = out_channel_offset;
     g.ntaps = p->ksize * p->ksize; g.pad = p->ksize / 2; g.ksize = p->ksize; g.allow_same = p->allow_same; g.act = p->act;
-    g.mt = p->mt; g.step = step; g.first = d_first;
+    g.mt = p->mt; g.step = step; g.first = d_first; g.in_perm = d_in_perm; g.out_perm = d_out_perm;
     const unsigned ptiles = static_cast<unsigned>((n_pos + 31) / 32), rtiles = static_cast<unsigned>(g.tiles_per_group * g.go);
     hipStream_t st = as_stream(hip_stream);
     // Which kernel: every one of them sums in the canonical order, so this is a matter of speed only and may depend on the
@@ -678,6 +807,7 @@ static int mconv_forward(const basic_mconv_plan *p, const float *d_x, const int3
         g.n_pchunks = static_cast<int>((n_pos + kDmaPos - 1) / kDmaPos);
         g.n_rchunks = p->cout / kDmaRows;
         g.x_bytes = static_cast<int>(x_bytes);
+        { const char *e = std::getenv("BASIC_MCONV_DEBUG"); g.debug = e ? std::atoi(e) : 0; }
         const unsigned grid = static_cast<unsigned>((g.n_pchunks + 7) / 8 * 8) * g.n_rchunks;
         hipLaunchKernelGGL(masked_conv_dma_kernel, dim3(grid), dim3(kDmaThreads), kDmaLdsBytes, st, g);
     } else if (use_block) {

@@ -802,6 +802,24 @@ extern "C" int basic_scanline_decode_dev(basic_scanline_plan *p, const basic_ran
     return chained_launch(p, st, p->nwg + ndec, cus, [&] { hipLaunchKernelGGL(scanline_persistent_kernel<true>, dim3(p->nwg + ndec), dim3(kThreads), lds_bytes, st, a); });
 }
 
+// Whether basic_scanline_decode_dev can serve `batch` streams of this table set on the current device (the set has a fast
+// search image that fits the LDS, and compute + decoder workgroups fit the chip).  Both paths code the same integers, so a
+// caller that gets 0 simply decodes with the per-step path.
+extern "C" int basic_scanline_can_decode(const basic_scanline_plan *p, const basic_rans_tables *tables, int batch, int *ok)
+{
+    BASIC_REQUIRE(p && tables && ok && batch >= 1, "scanline_can_decode: bad argument");
+    *ok = 0;
+    RansFastView tv;
+    if (rans_fast_view(tables, &tv) != BASIC_OK) return BASIC_OK;
+    int cus = 0;
+    int rc = device_cus(&cus);
+    if (rc) return rc;
+    const int ndec = (batch + kThreads / 64 - 1) / (kThreads / 64);
+    const size_t dec_lds = (static_cast<size_t>((tv.image_words + 3) & ~3) + 4) * sizeof(uint32_t);
+    *ok = p->nwg + ndec <= cus && dec_lds <= 160 * 1024;
+    return BASIC_OK;
+}
+
 // 0 = the last launch on this plan completed its barriers; 1 = a barrier timed out (results invalid).  Synchronises `hip_stream`.
 extern "C" int basic_scanline_status(basic_scanline_plan *p, void *hip_stream, int *poisoned)
 {

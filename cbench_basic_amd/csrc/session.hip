@@ -8,10 +8,14 @@
 #include "common.h"
 
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <vector>
 
 using namespace basic;
+
+constexpr int kMaxTokenLanes = 4;
+
 
 namespace {
 
@@ -123,6 +127,7 @@ struct basic_hp_session {
     hipStream_t side = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;
     bool use_token = false;
+    int token_lanes = 0;   // transform phases of all sessions admitted at a time (0 = no ordering)
     hipEvent_t enc_phase = nullptr, dec_phase = nullptr;   // close this session's transform phases (see TransformToken)
     // Upload of a host-resident batch (general_codec.py:46-47): on its own stream, ordered only after the PREVIOUS call's
     // analysis transform (the last reader of d_x), so it runs beside whatever the caller's stream still has queued (the
@@ -191,7 +196,15 @@ int chain_out_hw(const std::vector<const basic_conv_plan *> &plans, int h, int w
 // except the short critical section that keeps wait / launches / record of one phase together.
 struct TransformToken {
     std::mutex mu;
-    hipEvent_t last = nullptr;   // closes the most recently enqueued phase (owned by the session that recorded it)
+    // per device: the events that close the most recently enqueued phases, one per LANE (owned by the sessions that recorded
+    // them).  A new phase waits for the phase that used its lane last, so `lanes` phases run side by side: 1 = strictly one
+    // after another (full batches fill the chip on their own), 2 = two at a time (small batches: one session's launches
+    // leave compute units idle and tile counts quantise badly, two sessions' launches interleave)
+    struct Dev {
+        hipEvent_t lane[kMaxTokenLanes] = {};
+        int cursor = 0;
+    };
+    std::map<int, Dev> dev;
 };
 TransformToken g_token;
 
@@ -200,6 +213,8 @@ struct TokenPhase {   // RAII: a phase of one session on one stream
     hipStream_t st;
     hipEvent_t *evt;
     bool on;
+    TransformToken::Dev *dev = nullptr;
+    int slot = 0;
     int rc = BASIC_OK;
     TokenPhase(basic_hp_session *s_, hipStream_t st_, hipEvent_t *evt_);
     int close();
@@ -241,13 +256,19 @@ int rejoin(basic_hp_session *s, hipStream_t st, hipStream_t es)
     return BASIC_OK;
 }
 
-TokenPhase::TokenPhase(basic_hp_session *s_, hipStream_t st_, hipEvent_t *evt_) : s(s_), st(st_), evt(evt_), on(s_->use_token)
+TokenPhase::TokenPhase(basic_hp_session *s_, hipStream_t st_, hipEvent_t *evt_) : s(s_), st(st_), evt(evt_), on(s_->token_lanes > 0)
 {
     if (!on) return;
     g_token.mu.lock();
-    hipError_t e = hipSuccess;
-    if (!*evt) e = hipEventCreateWithFlags(evt, hipEventDisableTiming);
-    if (e == hipSuccess && g_token.last && g_token.last != *evt) e = hipStreamWaitEvent(st, g_token.last, 0);
+    int d = 0;
+    hipError_t e = hipGetDevice(&d);
+    if (e == hipSuccess && !*evt) e = hipEventCreateWithFlags(evt, hipEventDisableTiming);
+    if (e == hipSuccess) {
+        dev = &g_token.dev[d];
+        slot = dev->cursor % s->token_lanes;
+        hipEvent_t prev = dev->lane[slot];
+        if (prev && prev != *evt) e = hipStreamWaitEvent(st, prev, 0);
+    }
     if (e != hipSuccess) rc = hip_fail(e, "transform token: wait", __FILE__, __LINE__);
 }
 
@@ -256,7 +277,10 @@ int TokenPhase::close()
     if (!on) return rc;
     on = false;
     hipError_t e = hipEventRecord(*evt, st);
-    if (e == hipSuccess) g_token.last = *evt;
+    if (e == hipSuccess && dev) {
+        dev->lane[slot] = *evt;
+        dev->cursor = (slot + 1) % s->token_lanes;
+    }
     g_token.mu.unlock();
     if (e != hipSuccess && rc == BASIC_OK) rc = hip_fail(e, "transform token: record", __FILE__, __LINE__);
     return rc;
@@ -266,7 +290,8 @@ int TokenPhase::close()
 
 extern "C" int basic_hp_session_set_transform_token(basic_hp_session *s, int enable)
 {
-    BASIC_REQUIRE(s, "hp_session_set_transform_token: null session");
+    BASIC_REQUIRE(s && enable >= 0 && enable <= kMaxTokenLanes, "hp_session_set_transform_token: 0 (off) or 1 .. 4 phases at a time");
+    s->token_lanes = enable;
     s->use_token = enable != 0;
     return BASIC_OK;
 }
@@ -322,10 +347,12 @@ basic_hp_session::~basic_hp_session()
 {
     {
         std::lock_guard<std::mutex> lock(g_token.mu);
-        if (g_token.last && (g_token.last == enc_phase || g_token.last == dec_phase)) {
-            (void)hipEventSynchronize(g_token.last);   // whoever waits on it has been released
-            g_token.last = nullptr;
-        }
+        for (auto &kv : g_token.dev)
+            for (hipEvent_t &e : kv.second.lane)
+                if (e && (e == enc_phase || e == dec_phase)) {
+                    (void)hipEventSynchronize(e);   // whoever waits on it has been released
+                    e = nullptr;
+                }
     }
     for (hipEvent_t e : {in_done, enc_phase, dec_phase, fork, join, x_free, x_ready})
         if (e) (void)hipEventDestroy(e);

@@ -358,7 +358,7 @@ class LatentGraphicalANSEntropyCoder(HotPathModule, VariableRateCodecInterface, 
     # ---- fused C entry points for the plain hyperprior graph (include/basic_hip.h section 8)
     use_fused_session = True    # set False to force the module-by-module path (the two give identical bytes: tests)
     fused_rans_waves = 0        # wavefronts (image streams) per workgroup of the session's rANS launches; 0 = library default
-    fused_transform_token = False   # serialise the transform phases of all such sessions in GPU time (stream workers)
+    fused_transform_token = False   # order the transform phases of all such sessions in GPU time (stream workers): True / 1 = one at a time, 2 = two at a time
 
     def _fused_session(self, kwargs, prior):
         """The HyperpriorSession serving this graph, or None when the graph is anything but

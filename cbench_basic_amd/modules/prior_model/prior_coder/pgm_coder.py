@@ -20,7 +20,9 @@ reference's.  For batch size > 1 the reference codes ALL images into one serial 
 independent stream per image -- framed as <I n> <n x I length> streams -- which is what lets 256 images
 be coded concurrently; ``"reference"`` reproduces the single stream.
 """
+import contextlib
 import struct
+import threading
 from typing import Optional
 
 import numpy as np
@@ -133,6 +135,20 @@ class TopoGroupDynamicMaskConv2dContextModel(nn.Module):
             self.param_merger_out = nn.Sequential(*layers)
 
 
+_CAPTURE_LOCK = threading.Lock()
+
+
+@contextlib.contextmanager
+def _capture(device, graph):
+    """HIP-graph capture that is safe beside other host threads (stream workers with their own codec replicas): one capture at
+    a time in the process, in thread-local capture mode -- in the default global mode a hipMalloc / hipFree issued by ANY other
+    thread while this one captures fails or invalidates the capture -- and only THIS thread's stream is drained first."""
+    with _CAPTURE_LOCK:
+        torch.cuda.current_stream(device).synchronize()
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+            yield
+
+
 class _GroupPlan:
     """Static coding schedule of one (H, W) latent shape: per topo group the per-image element list
     (ascending flat index = boolean-mask order, pgm_coder.py:898-900) and the spatial positions."""
@@ -155,6 +171,15 @@ class _GroupPlan:
             base += int(elems.size)
         self.per_image = base
         self._pos_cache = {}
+        # plane layout of the merger's PRIVATE hidden activations: positions ordered by the first step that codes them, so
+        # the positions of a step are contiguous (whole cache lines per gather / store; row-major planes give a checkerboard
+        # step every other float).  None when that is the row-major order anyway.
+        order = np.argsort(topo.min(axis=0).reshape(-1), kind="stable")
+        perm = np.empty(H * W, dtype=np.int32)
+        perm[order] = np.arange(H * W, dtype=np.int32)
+        ident = np.array_equal(perm, np.arange(H * W))
+        self.hidden_perm_dev = None if ident else torch.from_numpy(perm).to(device).contiguous()            # position -> slot
+        self.hidden_order_dev = None if ident else torch.from_numpy(order.astype(np.int64)).to(device)      # slot -> position
 
     def positions(self, g, batch, device):
         key = (g, batch)
@@ -462,7 +487,7 @@ class GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(HotPathModule):
         return self._plans[key]
 
     # ------------------------------------------------------------------ context model at one group's positions
-    def _alloc(self, B, H, W, prior):
+    def _alloc(self, B, H, W, prior, plan):
         dev, C2 = self.device, self.out_channels
         ws = dict()
         ws["ybuf"] = torch.zeros((B, self.in_channels, H, W), device=dev)
@@ -471,9 +496,17 @@ class GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(HotPathModule):
             ws["ctx"] = torch.zeros((B, C2, H, W), device=dev)
             ws["params"] = torch.empty((B, C2, H, W), device=dev)
         else:
+            # cat(ctx, prior) is read by the first merger layer alone: like the hidden activations it lives in the
+            # step-contiguous plane order (see _GroupPlan.hidden_order_dev) -- the context layer writes it that way, the prior
+            # half is permuted here, once per call
             cat = torch.empty((B, 2 * C2, H, W), device=dev)
             cat[:, :C2].zero_()
-            cat[:, C2:].copy_(prior if prior is not None else torch.zeros((B, C2, H, W), device=dev))
+            if prior is None:
+                cat[:, C2:].zero_()
+            elif plan.hidden_order_dev is None:
+                cat[:, C2:].copy_(prior)
+            else:
+                cat[:, C2:].copy_(torch.index_select(prior.reshape(B, C2, H * W), 2, plan.hidden_order_dev).reshape(B, C2, H, W))
             ws["cat"] = cat
             ws["hidden"] = [torch.empty((B, pl.cout, H, W), device=dev) for pl, _, _ in merger]
             ws["params"] = ws["hidden"][-1]
@@ -495,10 +528,11 @@ class GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(HotPathModule):
             # cheap plumbing and only the group's positions are read afterwards
             ws["params"] = ws["ctx"] + prior if prior is not None else ws["ctx"]
             return ws["params"]
-        self._layers["ctx"](ws["ybuf"], topo["pgm"], topo["pgm"], pos, ws["cat"], out_offset=0, **sk)
+        hp, last = plan.hidden_perm_dev, len(merger) - 1   # cat and the hidden planes in step-contiguous order; the parameters row-major
+        self._layers["ctx"](ws["ybuf"], topo["pgm"], topo["pgm"], pos, ws["cat"], out_offset=0, out_perm=hp, **sk)
         x = ws["cat"]
-        for (pl, tin, tout), out in zip(merger, ws["hidden"]):
-            pl(x, topo[tin], topo[tout], pos, out, **sk)
+        for i, ((pl, tin, tout), out) in enumerate(zip(merger, ws["hidden"])):
+            pl(x, topo[tin], topo[tout], pos, out, in_perm=hp, out_perm=hp if i < last else None, **sk)
             x = out
         return ws["params"]
 
@@ -521,16 +555,19 @@ class GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(HotPathModule):
     # per-group launch sequence is captured once per (batch, H, W) into a HIP graph and replayed.
     GRAPH_MIN_GROUPS = 8
 
-    # The scan-line schedule (one coding step per spatial position) with one channel group runs as ONE persistent launch
-    # (csrc/scanline.hip) instead of ~6 dependent launches per step.  Encoder and decoder must make the same choice (the
-    # two paths sum in different orders): it depends on the coder's configuration only, never on the batch.
+    # The scan-line schedule (one coding step per spatial position) with one channel group can run as ONE persistent launch
+    # (csrc/scanline.hip) instead of ~6 dependent launches per step.  Both paths sum in the canonical block order of
+    # csrc/mconv.hip and code IDENTICAL integers (tests/test_gpu_scanline.py demands equality), so which one serves a call is a
+    # matter of speed alone: the encoder and the decoder of a stream need not agree, and nothing about it is recorded in the
+    # stream.  The two attributes below are tuning knobs, not part of the format.
     use_persistent_scanline = True
     persistent_scanline_max_batch = 4    # measured (scripts/scanline_probe.py, C = 192): batch 1 x2.1 in the loop, batch 8 break-even, beyond it the per-step path's batched MFMA launches win
 
-    def _scanline_plan(self, plan, prior, batch=1):
-        """The ScanlinePlan serving this call, or None.  A function of the coder's configuration and of the batch size --
-        which both the encoder and the decoder know -- because the two paths sum in different orders and a stream must be
-        decoded by the path that encoded it."""
+    def _scanline_plan(self, plan, prior, batch=1, decode=False):
+        """The ScanlinePlan serving this call, or None (then the per-step path codes the same integers): the configuration
+        must be the scan-line schedule with dense merger layers that fit the chip's LDS, the batch small enough to pay, and
+        the launch must fit the device (the decoder launch adds one wavefront per image stream and needs the table set's
+        fast search image)."""
         if not self.use_persistent_scanline or self.channel_groups != 1 or self.default_topo_group_method != "scanline" \
                 or plan.key != ("default",) or "dense" not in self._layers or batch > self.persistent_scanline_max_batch \
                 or (batch > 1 and not self._per_image(batch)):
@@ -548,7 +585,10 @@ class GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(HotPathModule):
             except ValueError:   # the layers' weights exceed the LDS of the chip (a property of the configuration)
                 sp = (None, pc)
             self._layers["scanline"] = sp
-        return sp[0]
+        sl = sp[0]
+        if sl is not None and not (sl.can_decode(self._tables, batch) if decode else sl.can_encode(batch)):
+            return None
+        return sl
 
     def _run_encode(self, y, prior, pgm=None):
         self._ready()
@@ -569,9 +609,8 @@ class GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(HotPathModule):
             if sp is not None:
                 sp.copy_(prior)
             self._run_encode_impl(sy, sp, plan)    # eager warm-up: builds position lists, sets kernel attributes
-            torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with _capture(self.device, graph):
                 out = self._run_encode_impl(sy, sp, plan)
             entry = self._graphs[key] = (graph, sy, sp, out)
         graph, sy, sp, out = entry
@@ -583,7 +622,7 @@ class GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(HotPathModule):
 
     def _run_encode_impl(self, y, prior, plan):
         B, C, H, W = y.shape
-        ws = self._alloc(B, H, W, prior)
+        ws = self._alloc(B, H, W, prior, plan)
         n = plan.per_image
         sym = torch.empty((B, n), device=self.device, dtype=torch.int32)
         idx = torch.empty((B, n), device=self.device, dtype=torch.int32)
@@ -656,7 +695,7 @@ class GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(HotPathModule):
         if getattr(self, "estimate_rate", False):
             B, C, H, W = input.shape
             plan = self._plan(H, W, pgm)   # logits are taken at their argmax here too (the coding-mode groups)
-            ws = self._alloc(B, H, W, prior)
+            ws = self._alloc(B, H, W, prior, plan)
             ws["ybuf"] = q
             allpos = torch.arange(B * H * W, device=self.device, dtype=torch.int32)
             params = self._context_at(ws, plan, allpos, prior)
@@ -728,7 +767,7 @@ class GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(HotPathModule):
         stage = self._tables._stage_in(int(woff[-1]))
         stage.numpy()[:] = np.frombuffer(body, dtype=np.int32, count=int(woff[-1]), offset=payload)
         words_np = stage.numpy()
-        sl = self._scanline_plan(plan, prior, B)
+        sl = self._scanline_plan(plan, prior, B, decode=True)
         if sl is not None:   # persistent scan-line launch (see _run_encode); one stream per image
             d_words = stage.to(dev, non_blocking=True)
             self._tables._pin_in_event = torch.cuda.Event()
@@ -757,9 +796,8 @@ class GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(HotPathModule):
             if sp is not None:
                 sp.copy_(prior)
             self._run_decode_impl(sw, so, sp, B, H, W, True, plan)   # eager warm-up
-            torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with _capture(self.device, graph):
                 out = self._run_decode_impl(sw, so, sp, B, H, W, True, plan)
             entry = self._graphs[key] = (graph, sw, so, sp, out)
         graph, sw, so, sp, out = entry
@@ -780,7 +818,7 @@ class GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(HotPathModule):
         ns = B if per_image else 1
         state = torch.zeros((ns,), device=dev, dtype=torch.int64)
         pos = torch.full((ns,), -1, device=dev, dtype=torch.int64)
-        ws = self._alloc(B, H, W, prior)
+        ws = self._alloc(B, H, W, prior, plan)
         sym = torch.empty((B, n), device=dev, dtype=torch.int32)
         idx = torch.empty((B, n), device=dev, dtype=torch.int32)
         L = _lib.lib()

@@ -109,22 +109,23 @@ class MaskedConvPlan:
             except Exception:
                 pass
 
-    def __call__(self, x, topo_in, topo_out, pos, out, out_offset=0, step=None, first_step=None):
-        """step / first_step: the coding-loop variant (basic_mconv_forward_step_dev) that only evaluates the
-        (output group, position) pairs of the current step."""
+    def __call__(self, x, topo_in, topo_out, pos, out, out_offset=0, step=None, first_step=None, in_perm=None, out_perm=None):
+        """step / first_step: the coding-loop variant that only evaluates the (output group, position) pairs of the current
+        step.  in_perm / out_perm (int32 [H*W]): position permutation inside the planes of x / out (private buffers of a
+        chain of 1x1 layers; see basic_mconv_forward_ex_dev)."""
         x = _dev(x, torch.float32)
         B, C, H, W = x.shape
         topo_in, topo_out, pos = _dev(topo_in, torch.int32), _dev(topo_out, torch.int32), _dev(pos, torch.int32)
         out = _dev(out, torch.float32)
         if step is not None:
             first_step = _dev(first_step, torch.int32)
-            _lib.check(_lib.lib().basic_mconv_forward_step_dev(self._h, x.data_ptr(), topo_in.data_ptr(), topo_out.data_ptr(), B, H, W,
-                                                               pos.data_ptr(), pos.numel(), out.data_ptr(), out.shape[1],
-                                                               int(out_offset), int(step), first_step.data_ptr(), _stream()))
-            return out
-        _lib.check(_lib.lib().basic_mconv_forward_pos_dev(self._h, x.data_ptr(), topo_in.data_ptr(), topo_out.data_ptr(), B, H, W,
-                                                          pos.data_ptr(), pos.numel(), out.data_ptr(), out.shape[1], int(out_offset),
-                                                          _stream()))
+        in_perm = _dev(in_perm, torch.int32) if in_perm is not None else None
+        out_perm = _dev(out_perm, torch.int32) if out_perm is not None else None
+        _lib.check(_lib.lib().basic_mconv_forward_ex_dev(
+            self._h, x.data_ptr(), topo_in.data_ptr(), topo_out.data_ptr(), B, H, W, pos.data_ptr(), pos.numel(), out.data_ptr(),
+            out.shape[1], int(out_offset), int(step is not None), int(step) if step is not None else 0,
+            first_step.data_ptr() if step is not None else None, in_perm.data_ptr() if in_perm is not None else None,
+            out_perm.data_ptr() if out_perm is not None else None, _stream()))
         return out
 
 
@@ -430,7 +431,8 @@ class HyperpriorSession:
         _lib.check(_lib.lib().basic_hp_session_set_rans_waves(self._h, int(waves_per_block)))
 
     def set_transform_token(self, enable):
-        _lib.check(_lib.lib().basic_hp_session_set_transform_token(self._h, int(bool(enable))))
+        """False / 0: no ordering; True / 1: the transform phases of all sessions one at a time; 2: two at a time."""
+        _lib.check(_lib.lib().basic_hp_session_set_transform_token(self._h, int(enable)))
 
     def encode(self, x) -> bytes:
         """x: float32 [B, C, H, W], on the GPU or on the host (uploaded inside the call; pinned memory goes at DMA rate)."""
@@ -506,6 +508,15 @@ class ScanlinePlan:
                                                         table.data_ptr(), table.numel(), sym.data_ptr(), idx.data_ptr(), ybuf.data_ptr(),
                                                         _stream()))
         return sym, idx, ybuf
+
+    def can_encode(self, batch):
+        """The encoder launch needs its workgroups resident: one per compute unit."""
+        return self.workgroups <= torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
+
+    def can_decode(self, tables, batch):
+        ok = ctypes.c_int()
+        _lib.check(_lib.lib().basic_scanline_can_decode(self._h, tables._h, int(batch), ctypes.byref(ok)))
+        return bool(ok.value)
 
     def decode(self, tables, d_words, d_word_off, prior, batch, h, w, table):
         """-> (symbols, indexes int32 [B, H*W*C] in coding order, y_hat [B, C, H, W])."""

@@ -262,6 +262,15 @@ int basic_mconv_forward_step_dev(const basic_mconv_plan *p, const float *d_x, co
                                  const int32_t *d_topo_out, int batch, int h, int w, const int32_t *d_pos,
                                  int64_t n_pos, float *d_y, int out_channels_total, int out_channel_offset,
                                  int step, const int32_t *d_first_step, void *hip_stream);
+/* Everything at once: use_step != 0 = the coding-loop variant above; d_in_perm / d_out_perm (int32 [H*W] or NULL) permute
+ * the positions inside the planes of x / y -- element (b, c, p) at (b * C + c) * H*W + perm[p] -- for buffers that are
+ * PRIVATE to a chain of 1x1 layers (the merger's hidden activations): with a coding step's positions contiguous its gathers
+ * and stores cover whole cache lines.  d_in_perm needs a 1x1 layer.  Values are unaffected. */
+int basic_mconv_forward_ex_dev(const basic_mconv_plan *p, const float *d_x, const int32_t *d_topo_in,
+                               const int32_t *d_topo_out, int batch, int h, int w, const int32_t *d_pos, int64_t n_pos,
+                               float *d_y, int out_channels_total, int out_channel_offset, int use_step, int step,
+                               const int32_t *d_first_step, const int32_t *d_in_perm, const int32_t *d_out_perm,
+                               void *hip_stream);
 void basic_mconv_plan_destroy(basic_mconv_plan *p);
 
 /* ======================================================================================
@@ -315,7 +324,9 @@ int basic_hp_session_set_rans_waves(basic_hp_session *s, int waves_per_block);
 /* Opt this session into the process-wide "transform token": the MFMA-heavy phases (compress: everything up to the y
  * rANS encoder; decompress: g_s) of all such sessions then run one after another in GPU time, in host enqueue order,
  * through stream-wait events -- so that with several sessions on several HIP streams one session's rANS chains always
- * run beside another's transforms instead of all sessions falling into lock-step.  No effect on results. */
+ * run beside another's transforms instead of all sessions falling into lock-step.  enable = 1: one phase at a time (full
+ * batches fill the chip on their own); 2: two at a time (small batches, whose launches leave compute units idle); 0: off.
+ * The order is kept per device.  No effect on results. */
 int basic_hp_session_set_transform_token(basic_hp_session *s, int enable);
 void basic_hp_session_destroy(basic_hp_session *s);
 
@@ -354,6 +365,10 @@ int basic_scanline_encode_dev(basic_scanline_plan *p, const float *d_y, const fl
 int basic_scanline_decode_dev(basic_scanline_plan *p, const basic_rans_tables *tables, const uint32_t *d_words,
                               const int64_t *d_word_off, const float *d_prior, int batch, int h, int w, const float *d_table,
                               int table_len, int32_t *d_symbols, int32_t *d_indexes, float *d_ybuf, void *hip_stream);
+/* *ok = 1 when basic_scanline_decode_dev can serve `batch` streams of `tables` on the current device (fast search image that
+ * fits the LDS; compute + decoder workgroups <= compute units); otherwise the caller decodes with the per-step path, which
+ * codes the same integers. */
+int basic_scanline_can_decode(const basic_scanline_plan *p, const basic_rans_tables *tables, int batch, int *ok);
 int basic_scanline_status(basic_scanline_plan *p, void *hip_stream, int *poisoned);
 void basic_scanline_plan_destroy(basic_scanline_plan *p);
 

@@ -1075,8 +1075,52 @@ def tans_kats():
     save("tans_kat.npz", **out)
 
 
+def rans_cache_kats():
+    """Rans64Encoder's symbol cache (encode_with_indexes(..., cache=True) / peek_cache / flush, rans64.cpp:237-386,
+    rans64.hpp:78-86) and ANSBase::create_ar_ptrs (ans_interface.cpp:34-73) of the reference's compiled cbench.ans."""
+    rng = np.random.default_rng(77)
+    out, names = {}, []
+    for ci, (nd, ns, bypass, calls) in enumerate([(3, 9, True, [40, 25]), (2, 6, False, [30]), (4, 20, True, [10, 1, 33])]):
+        freqs = rng.integers(1, 400, (nd, ns)).astype(np.int32)
+        nsym = rng.integers(2, ns + 1, nd).astype(np.int32)
+        off = rng.integers(-4, 3, nd).astype(np.int32)
+        enc = ref_ans.Rans64Encoder(16, bypass, 4)
+        enc.init_params(freqs, nsym, off)
+        k = f"c{ci}"
+        out.update({f"{k}.freqs": freqs, f"{k}.nsym": nsym, f"{k}.offsets": off, f"{k}.bypass": np.array(int(bypass)), f"{k}.ncalls": np.array(len(calls))})
+        for j, n in enumerate(calls):
+            idx = rng.integers(0, nd, n).astype(np.int32)
+            if bypass:
+                sym = (off[idx] + rng.integers(-3, ns + 4, n)).astype(np.int32)
+                sym[::7] += rng.integers(-3000, 3000, sym[::7].size).astype(np.int32)
+            else:
+                sym = (off[idx] + rng.integers(0, 1 << 30, n) % nsym[idx]).astype(np.int32)
+            assert enc.encode_with_indexes(sym, idx, cache=True) == b""
+            out[f"{k}.sym{j}"], out[f"{k}.idx{j}"] = sym, idx
+            out[f"{k}.peek{j}"] = np.array(enc.peek_cache()).astype(np.int32)
+        out[f"{k}.flush"] = b2a(enc.flush())
+        out[f"{k}.peek_after"] = np.array(enc.peek_cache()).astype(np.int32).reshape(-1, 3)
+        names.append(k)
+        print(f"  {k}: {sum(calls)} symbols cached in {len(calls)} calls -> {out[f'{k}.peek{len(calls) - 1}'].shape[0]} rANS symbols, {out[f'{k}.flush'].size} bytes")
+    enc = ref_ans.Rans64Encoder(16, True, 4)
+    pcases = [((1, 3, 4), [[-1, 0]]), ((2, 3, 4), [[0, -1], [-1, -1]]), ((1, 2, 3, 4), [[-1, 0, 0], [0, -2, -1], [0, 0, 0]]), ((1, 5), [[-2]])]
+    for pi, (shape, offs) in enumerate(pcases):
+        r = enc.create_ar_ptrs(np.zeros(shape, np.int32), offs)
+        out[f"p{pi}.shape"] = np.array(shape)
+        out[f"p{pi}.offsets"] = np.array([o + [0] * (3 - len(o)) for o in offs])
+        out[f"p{pi}.nd"] = np.array([len(o) for o in offs])
+        out[f"p{pi}.ptrs"] = np.array(r, dtype=np.int64)
+    try:
+        enc.create_ar_ptrs(np.zeros((1, 3, 3), np.int32), [[1, 0]])
+        out["p.positive_raises"] = np.array(0)
+    except ValueError:
+        out["p.positive_raises"] = np.array(1)
+    out["names"], out["npcases"] = np.array(names), np.array(len(pcases))
+    save("rans_cache_kat.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["rans", "tables", "topo", "mconv", "ar", "framing", "harness", "search", "arpgm", "arjoint", "codec", "grouped", "tans", "ardyn", "train", "arquant", "arops"]
-    fn = dict(rans=rans_kats, tables=gauss_tables, topo=topo_maps, mconv=masked_conv, ar=ar_coder, framing=framing, harness=harness, search=complexity_search, arpgm=ar_coder_pgm, arjoint=ar_coder_joint, codec=codec_graph, grouped=grouped, tans=tans_kats, ardyn=ar_coder_dynamic, train=train_mode, arquant=ar_coder_quant, arops=ar_ops_kats)
+    which = sys.argv[1:] or ["rans", "tables", "topo", "mconv", "ar", "framing", "harness", "search", "arpgm", "arjoint", "codec", "grouped", "tans", "ardyn", "train", "arquant", "arops", "ranscache"]
+    fn = dict(rans=rans_kats, tables=gauss_tables, topo=topo_maps, mconv=masked_conv, ar=ar_coder, framing=framing, harness=harness, search=complexity_search, arpgm=ar_coder_pgm, arjoint=ar_coder_joint, codec=codec_graph, grouped=grouped, tans=tans_kats, ardyn=ar_coder_dynamic, train=train_mode, arquant=ar_coder_quant, arops=ar_ops_kats, ranscache=rans_cache_kats)
     for w in which:
         fn[w]()

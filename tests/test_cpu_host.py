@@ -574,3 +574,20 @@ def test_gaussian_conditional_buffers_travel_in_checkpoints():
         eb._bias0.add_(0.3)
     assert eb.update() is False and torch.equal(eb._quantized_cdf, first)
     assert eb.update(force=True) is True and not torch.equal(eb._quantized_cdf, first)
+
+
+def test_create_ar_ptrs_matches_reference_binding():
+    """ANSBase::create_ar_ptrs (ans_interface.cpp:34-73) as the reference's compiled cbench.ans returns it
+    (tests/golden/rans_cache_kat.npz), including its ValueError for a positive offset; on both coder classes."""
+    from cbench_basic_amd import ans
+    z = np.load(os.path.join(ROOT, "tests", "golden", "rans_cache_kat.npz"))
+    for cls in (ans.Rans64Encoder, ans.Rans64Decoder):
+        c = cls(16, True, 4)
+        for i in range(int(z["npcases"])):
+            shape = tuple(int(v) for v in z[f"p{i}.shape"])
+            offs = [row[: int(n)].tolist() for row, n in zip(z[f"p{i}.offsets"], z[f"p{i}.nd"])]
+            got = c.create_ar_ptrs(np.zeros(shape, np.int32), offs)
+            assert np.array_equal(np.array(got, dtype=np.int64), z[f"p{i}.ptrs"]), i
+        assert int(z["p.positive_raises"]) == 1
+        with pytest.raises(ValueError):
+            c.create_ar_ptrs(np.zeros((1, 3, 3), np.int32), [[1, 0]])

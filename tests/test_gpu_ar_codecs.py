@@ -321,3 +321,60 @@ def test_streams_do_not_depend_on_batch_or_launch_shape(kind):
                 for j in range(B):
                     one = codec.decompress(ref[j])
                     assert torch.equal(one[0], xhat[j]), (kind, j)
+
+
+# ---------------------------------------------------------------- BASELINE configs[2] / [3] at the size the metric is quoted on
+@pytest.mark.parametrize("kind", ["checkerboard", "basic-l0", "basic-l7"])
+def test_kodak_shaped_ar_codecs_full_size(kind):
+    """One Kodak-shaped image (3 x 512 x 768: latent 192 x 32 x 48, 294,912 symbols; the scan-line schedule of BaSIC is 1,536
+    coding steps = ~6,100 in-kernel device barriers of the persistent launch) through compress / decompress:
+      * deterministic: the same bytes twice;
+      * decode == encode: the decoder's latent equals the encoder's coded buffer EXACTLY (hence x-hat of decompress equals the
+        synthesis transform of the encoder's buffer);
+      * the persistent scan-line launch and the per-step path (HIP-graph replay of ~6 launches per step) write the same bytes
+        and read each other's streams; basic_scanline_status clean after both directions;
+      * PSNR / bytes are in the range the weights imply (no garbage): decode is within 0.5 of y everywhere."""
+    from cbench_basic_amd.presets import basic_codec, seed_synthetic_weights, topogroup_ar_codec
+    if kind.startswith("basic"):
+        codec = seed_synthetic_weights(basic_codec(), seed=0).eval().cuda()
+        codec.update_state()
+        codec.set_complex_level(int(kind[-1]))
+    else:
+        codec = seed_synthetic_weights(topogroup_ar_codec("checkerboard"), seed=0).eval().cuda()
+        codec.update_state()
+    ec = codec.entropy_coder
+    yc = ec.latent_node_entropy_coders["y"]
+    g = torch.Generator().manual_seed(21)
+    x = torch.rand(1, 3, 512, 768, generator=g).cuda()
+    data = codec.compress(x)
+    assert codec.compress(x) == data
+    xhat = codec.decompress(data)
+    assert xhat.shape == x.shape and bool(torch.isfinite(xhat).all())
+    # decode == encode at the y-coder, on a Kodak-shaped latent with parameters spread over the scale table
+    C, H, W = 192, 32, 48
+    y = (torch.randn(1, C, H, W, generator=g) * 3).cuda()
+    prior = torch.stack([torch.randn(1, C, H, W, generator=g), torch.rand(1, C, H, W, generator=g) * 3 + 0.1], 2).reshape(1, 2 * C, H, W).cuda()
+    sym, idx, ybuf, plan = yc._run_encode(y, prior)
+    assert float((ybuf - y).abs().max()) <= 0.5 + 1e-4
+    ybytes = yc.encode(y, prior=prior)
+    assert yc.encode(y, prior=prior) == ybytes
+    assert torch.equal(yc.decode(ybytes, prior=prior), ybuf)
+    if kind.startswith("basic"):
+        sl = yc._layers["scanline"][0]
+        assert sl is not None and yc._scanline_plan(plan, prior, 1) is sl, "the BaSIC y-coder at batch 1 runs the persistent launch"
+        sl.check()
+        assert len(plan.groups) == 32 * 48
+        # the per-step path: same bytes, reads the persistent path's stream (and vice versa)
+        yc.use_persistent_scanline = False
+        try:
+            assert codec.compress(x) == data
+            assert torch.equal(codec.decompress(data), xhat)
+            assert yc.encode(y, prior=prior) == ybytes and torch.equal(yc.decode(ybytes, prior=prior), ybuf)
+        finally:
+            yc.use_persistent_scanline = True
+        assert torch.equal(yc.decode(ybytes, prior=prior), ybuf)
+        sl.check()
+    bpp = len(data) * 8 / (512 * 768)
+    mse = float(((xhat - x) ** 2).mean())
+    print(f"{kind}: {len(data)} bytes ({bpp:.3f} bpp), PSNR {-10 * torch.log10(torch.tensor(mse)):.2f} dB")
+    assert 0.01 < bpp < 24 and mse < 1.0

@@ -65,8 +65,19 @@ def test_transforms_and_symbols(setup, shape):
     i_mis = int((idx.cpu() != a["y_idx"]).sum())
     n = a["y_sym"].numel()
     print(f"symbol mismatches vs fp32 CPU reference: z {z_mis}/{a['z_sym'].numel()}, y {y_mis}/{n}, idx {i_mis}/{n}")
-    # rounding / threshold flips caused by 1e-6-level float differences must stay rare
-    assert y_mis <= max(2, n // 2000) and i_mis <= max(2, n // 2000) and z_mis <= 2
+    # Differences may only be fp32 rounding TIES between the MFMA and the torch-CPU summation orders: every differing element
+    # is located and must sit within 2e-4 of a decision boundary of the ORACLE's own values (a half-integer latent for a
+    # symbol, a scale-table entry for an index), and there may be at most 2 of each.
+    assert y_mis <= 2 and i_mis <= 2 and z_mis <= 2
+    if z_mis == 0:
+        yo, so = a["y"].reshape(-1), a["scales"].reshape(-1)
+        for e in torch.nonzero(sym.cpu().reshape(-1) != a["y_sym"].reshape(-1)).reshape(-1).tolist():
+            frac = abs(float(yo[e]) - math.floor(float(yo[e])) - 0.5)
+            assert frac < 2e-4, (e, float(yo[e]))
+        table = yc.scale_table.cpu()
+        for e in torch.nonzero(idx.cpu().reshape(-1) != a["y_idx"].reshape(-1)).reshape(-1).tolist():
+            sv = max(float(so[e]), 0.11)
+            assert float((table - sv).abs().min()) < 2e-4 * max(1.0, sv), (e, sv)
     # the oracle's reconstruction from ITS symbols vs ours from OURS
     xhat_ref = oracle.g_s(a["y_sym"].float())
     xhat = ec.latent_generative_modules["y_x"](sym.float())

@@ -110,6 +110,21 @@ def test_rans_fork_tables_changing_between_buffered_calls():
     assert out.tolist() == s1 + s2
 
 
+def test_symbol_cache_peek_and_flush_vs_reference():
+    """encode_with_indexes(..., cache=True) / peek_cache / flush (rans64.cpp:237-386, rans64.hpp:78-86) against the
+    reference's compiled Rans64Encoder: the (start, range, bypass) rows after every cached call and the flushed bytes."""
+    from cbench_basic_amd import ans
+    z = load("rans_cache_kat.npz")
+    for k in (str(n) for n in z["names"]):
+        enc = ans.Rans64Encoder(16, bool(int(z[f"{k}.bypass"])), 4)
+        enc.init_params(z[f"{k}.freqs"], z[f"{k}.nsym"], z[f"{k}.offsets"])
+        for j in range(int(z[f"{k}.ncalls"])):
+            assert enc.encode_with_indexes(z[f"{k}.sym{j}"], z[f"{k}.idx{j}"], cache=True) == b""
+            assert np.array_equal(enc.peek_cache(), z[f"{k}.peek{j}"]), (k, j)
+        assert enc.flush() == z[f"{k}.flush"].tobytes(), k
+        assert enc.peek_cache().shape == (0, 3) and z[f"{k}.peek_after"].shape == (0, 3)
+
+
 def test_masked_conv_reference_outputs_on_hip():
     """TopoGroupDynamicMaskConv2d.forward outputs of the reference (masked_conv.py:102-228; 5x5 / 3x3 / 1x1 kernels,
     1-4 channel groups, allow_same_topogroup_conv, channel_group_mask) reproduced by masked_conv_pos_kernel."""
