@@ -59,6 +59,7 @@ def parse():
                     help="transform phases of the workers admitted at a time (1: full batches; 2: small batches, whose launches leave compute units idle); default by batch size")
     ap.add_argument("--strong-workers", type=int, default=6,
                     help="stream workers of the strong_per_gpu_proxy leg (total/8 images per step = one rank's share of the N = 8 strong-scaling leg)")
+    ap.add_argument("--strong-in-process", action="store_true", help="N = 1: also run the strong leg's per-GPU share inside this process (the N > 1 code path)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="bound of the CPU-baseline sample of the AR workload lines")
     ap.add_argument("--no-ar-workloads", action="store_true", help="do not add the ar_workloads lines (child processes) to the N = 1 line")
     ap.add_argument("--cpu-images", type=int, default=2000, help="bounded CPU-baseline sample (images)")
@@ -265,7 +266,10 @@ def run_ar_workload(args):
     # Whole batches in flight on concurrent stream workers, as in the headline: one worker's rANS chains run beside another's
     # convolutions; the scan-line schedule's launch-bound step sequences (HIP graphs) of several workers interleave on the chip.
     from cbench_basic_amd.benchmark.stream_workers import StreamWorkerPool
-    pool = StreamWorkerPool(make_codec, workers, dev)
+    # one pool for every leg: the strong-scaling leg (world > 1, or --strong-in-process at N = 1) codes small batches and wants
+    # more of them in flight than the headline leg (see strong_proxy_child)
+    strong_w = max(workers, args.strong_workers) if (by_steps and (world > 1 or args.strong_in_process)) else workers
+    pool = StreamWorkerPool(make_codec, strong_w, dev)
     codec = pool.codecs[0]
     x = torch.stack([image(i, args.size) for i in range(batch)]).to(dev)
 
@@ -396,15 +400,43 @@ def ar_workload_children(args):
     return out
 
 
+def strong_proxy_child(args):
+    """One rank's share of the N = 8 strong-scaling leg (BASELINE configs[4] as written: `total` images per step over 8 GPUs) on
+    THIS GPU: `bench.py --batch total/8` with the worker count and token lanes a small batch needs (its ~12 ms of rANS chain
+    latency per call against ~3 ms of transforms wants >= 5 batches in flight; its launches leave compute units idle and their
+    tile counts quantise badly, so several sessions' transform phases run side by side).  A child process started before this
+    one touches the GPU, so the leg runs under exactly the conditions of scripts/workers_sweep.sh (profiles/r03_batch32_*)."""
+    import subprocess
+    sb, sw, lanes = max(1, args.total // 8), max(2, args.strong_workers), 4
+    steps = max(8 * args.steps, 4 * sw)
+    cmd = [sys.executable, os.path.abspath(__file__), "--batch", str(sb), "--workers", str(sw), "--token-lanes", str(lanes), "--steps", str(steps),
+           "--warmup", str(sw), "--size", str(args.size), "--no-cpu-baseline", "--no-extra-legs", "--no-dominant"]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode != 0 or not lines:
+            return dict(error=f"exit code {r.returncode}", stderr_tail=r.stderr[-400:])
+        d = json.loads(lines[-1])
+        return dict(value=d["value"], unit="Mpix/s", images_per_step=sb, steps=steps, workers=sw, batches_in_flight=sw, token_lanes=lanes,
+                    ms_per_step=d["ms_per_step"], call_latency_ms=d["config"].get("call_latency_ms"), predicted_8gpu_strong=8 * d["value"],
+                    note=f"BASELINE configs[4] as written is {args.total} images per step over 8 GPUs = {sb} per GPU: this leg runs that share on one GPU "
+                         "(image-sharded, no data-path collective, so the N = 8 strong figure is 8 x it up to launch jitter); own process, `" + " ".join(cmd[1:]) + "`")
+    except Exception as e:
+        return dict(error=repr(e))
+
+
 def main():
     args = parse()
     if args.workload != "hyperprior":
         if args.gpus != 1:
             raise SystemExit("the AR workloads are single-GPU extra lines")
         return run_ar_workload(args)
-    ar_lines = None
-    if args.gpus == 1 and os.environ.get("WORLD_SIZE") is None and not args.no_ar_workloads and not args.no_extra_legs:
-        ar_lines = ar_workload_children(args)   # before anything here initialises the GPU
+    ar_lines = strong_proxy = None
+    if args.gpus == 1 and os.environ.get("WORLD_SIZE") is None and not args.no_extra_legs:   # before anything here initialises the GPU
+        if not args.no_ar_workloads:
+            ar_lines = ar_workload_children(args)
+        if args.batch == args.total:   # the headline configuration: add its strong-scaling share
+            strong_proxy = strong_proxy_child(args)
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is None and args.gpus > 1:
         raise SystemExit(self_launch(args))
@@ -444,13 +476,13 @@ def main():
     # packing more image streams into one rANS workgroup frees compute units for the other workers' transforms at the
     # price of a longer chain (+2 % at 4, +10 % at 8, x2 at 16): with whole batches in flight the chain has slack
     waves = args.rans_waves if args.rans_waves >= 0 else (8 if by_steps else 4 if workers > 1 else 0)
-    token_lanes = args.token_lanes if args.token_lanes is not None else (1 if args.batch >= 128 else 2)
+    token_lanes = args.token_lanes if args.token_lanes is not None else (1 if args.batch >= 128 else 4)
 
-    def make_codec(lanes=None):
+    def make_codec():
         c = seed_synthetic_weights(hyperprior_codec(), seed=0).eval().to(dev)   # every replica: the same seeded weights
         c.update_state()
         c.entropy_coder.fused_rans_waves = waves
-        c.entropy_coder.fused_transform_token = (token_lanes if lanes is None else lanes) if workers > 1 else 0
+        c.entropy_coder.fused_transform_token = token_lanes if workers > 1 else 0
         return c
 
     def barrier():
@@ -458,9 +490,12 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    def run_leg(pool, batch, steps, warmup, workers=workers):
-        """Exactly K steps (K x the whole batch through compress + decompress) spread over the workers; returns (seconds,
-        bytes of one step, [(bytes, xhat)] of one whole batch in image order, mean seconds of one compress+decompress call)."""
+    def run_leg(pool, batch, steps, warmup, workers=workers, lanes=None):
+        """Exactly K steps (K x the whole batch through compress + decompress) spread over the first `workers` workers of the
+        pool; returns (seconds, bytes of one step, [(bytes, xhat)] of one whole batch in image order, mean seconds of one
+        compress+decompress call).  lanes: transform phases admitted at a time in this leg (default: the run's setting)."""
+        for c in pool.codecs:
+            c.entropy_coder.fused_transform_token = (token_lanes if lanes is None else lanes) if workers > 1 else 0
         if by_steps:   # step k on worker k mod W: whole batches, W of them in flight
             work = [(batch, len(range(w, steps, workers)), max(1, len(range(w, warmup, workers))) if warmup else 0)
                     for w in range(workers)]
@@ -491,7 +526,10 @@ def main():
     weak_ids = list(range(rank * args.batch, (rank + 1) * args.batch))
     x_host = torch.stack([image(i, args.size) for i in weak_ids]).pin_memory()
     x = x_host.to(dev)
-    pool = StreamWorkerPool(make_codec, workers, dev)
+    # one pool for every leg: the strong-scaling leg (world > 1, or --strong-in-process at N = 1) codes small batches and wants
+    # more of them in flight than the headline leg (see strong_proxy_child)
+    strong_w = max(workers, args.strong_workers) if (by_steps and (world > 1 or args.strong_in_process)) else workers
+    pool = StreamWorkerPool(make_codec, strong_w, dev)
     codec = pool.codecs[0]
     cpu_state = {k: v.detach().cpu().clone() for k, v in codec.entropy_coder.state_dict().items()}
 
@@ -524,32 +562,18 @@ def main():
                                        ms_per_step=hred["time_s"] / args.steps * 1e3,
                                        note="same run, batch in page-locked host memory, H2D inside compress() (general_codec.py:46-47)")
         # (2) BASELINE configs[4] as written: `total` images per step over all GPUs (strong scaling)
-        if world > 1:
-            ids = shard_indices(args.total, rank, world)
+        if world > 1 or args.strong_in_process:
+            ids = shard_indices(args.total, rank, world) if world > 1 else list(range(max(1, args.total // 8)))
             xs = torch.stack([image(i, args.size) for i in ids]).to(dev)
-            sdt, _, _, _ = run_leg(pool, xs, args.steps, 1)
-            sred = reduce_metric_sums(dict(time_s=sdt, images=float(len(ids) * args.steps)), device=dev)
+            small = len(ids) < 128   # small batches: more of them in flight, four transform phases side by side
+            ssteps = args.steps * (8 if small else 1)
+            sdt, _, _, _ = run_leg(pool, xs, ssteps, strong_w if small else 1, workers=strong_w if small else workers, lanes=4 if small else None)
+            sred = reduce_metric_sums(dict(time_s=sdt, images=float(len(ids) * ssteps)), device=dev)
             extra["strong"] = dict(value=sred["images"] * args.size ** 2 / sred["time_s"] / 1e6, unit="Mpix/s", scaling="strong",
-                                   images_total_per_step=args.total, images_per_gpu=len(ids),
-                                   ms_per_step=sred["time_s"] / args.steps * 1e3,
+                                   images_total_per_step=args.total, images_per_gpu=len(ids), steps=ssteps,
+                                   workers=strong_w if small else workers, token_lanes=4 if small else token_lanes,
+                                   ms_per_step=sred["time_s"] / ssteps * 1e3,
                                    note="image i of the step's set on rank i mod world; compare with the N=1 line's value (256 images on one GPU)")
-        # (3) at N = 1: one rank's share of that strong leg on THIS GPU -- total / 8 images per step -- with the worker count and
-        #     token lanes a small batch needs (its ~12 ms of rANS chain latency per call against ~3 ms of transforms wants >= 5
-        #     batches in flight; its launches leave compute units idle, so two sessions' transform phases run side by side).
-        #     No data-path collective exists, so 8 x this figure is what the N = 8 strong leg can reach.
-        if world == 1 and by_steps and args.total // 8 >= 1:
-            sb, sw = args.total // 8, max(2, args.strong_workers)
-            pool.close()
-            pool = StreamWorkerPool(lambda: make_codec(2), sw, dev)
-            ssteps = max(8 * args.steps, 4 * sw)
-            pdt, _, _, pcall = run_leg(pool, x[:sb].contiguous(), ssteps, sw, workers=sw)
-            pv = sb * ssteps * args.size ** 2 / pdt / 1e6
-            extra["strong_per_gpu_proxy"] = dict(
-                value=pv, unit="Mpix/s", images_per_step=sb, steps=ssteps, workers=sw, batches_in_flight=sw, token_lanes=2,
-                ms_per_step=pdt / ssteps * 1e3, call_latency_ms=pcall * 1e3, frac_of_value=pv / (red["images"] * args.size ** 2 / red["time_s"] / 1e6),
-                predicted_8gpu_strong=8 * pv,
-                note=f"BASELINE configs[4] as written is {args.total} images per step over 8 GPUs = {sb} per GPU: this leg runs that share on one GPU "
-                     "(image-sharded, no data-path collective, so the N = 8 strong figure is 8 x it up to launch jitter)")
     pool.close()
 
     if rank == 0:
@@ -591,6 +615,10 @@ def main():
                           dominant=None if args.no_dominant else measure_dominant_kernel(codec, x)),
         )
         out.update(extra)
+        if strong_proxy is not None:
+            if "value" in strong_proxy:
+                strong_proxy["frac_of_value"] = strong_proxy["value"] / out["value"]
+            out["strong_per_gpu_proxy"] = strong_proxy
         if ar_lines is not None:
             out["ar_workloads"] = ar_lines
         if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only; at N > 1 the other ranks would just wait for it

@@ -86,7 +86,7 @@ struct MaskedLaunch {
     int units, blocks_per_slab;
     // dma kernel
     int n_pchunks, n_rchunks, x_bytes;
-    int debug;   // BASIC_MCONV_DEBUG timing ablations of the dma kernel (wrong results): 1 no staging, 4 no stores
+    int debug;   // BASIC_MCONV_DEBUG dma kernel: timing ablations (wrong results) 1 no staging, 4 no stores
 };
 
 constexpr int kNoStep = INT32_MIN;
@@ -369,15 +369,24 @@ __global__ __launch_bounds__(256) void masked_conv_reduce_kernel(const MaskedLau
 // Workgroups are dealt to the XCDs so that all row chunks of one position chunk run on the SAME XCD back to back: the
 // position chunk's activations (256 x Cin x 4 bytes) come out of the fabric once and are re-read from that XCD's L2.
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int kDmaWaves = 8, kDmaThreads = 64 * kDmaWaves, kDmaCK = 32, kDmaPos = 32 * kDmaWaves, kDmaRows = 128;
-constexpr int kDmaAFloats = kDmaCK * 32 * 4, kDmaBFloats = kDmaCK * kDmaPos, kDmaStage = kDmaAFloats + kDmaBFloats;
+// WAVES = 8: the shape above (three stage buffers of 48 KB, one workgroup per compute unit).  WAVES = 4: 128 positions per
+// workgroup, two stage buffers of 32 KB, TWO workgroups per compute unit -- for launches whose 8-wave grid would be only a
+// round or two of the chip (the 384-row layers: 384 workgroups on 256 compute units take two rounds for one and a half
+// rounds of work); twice as many, half as long workgroups cut that tail, at the price of staging the weights twice as often.
+constexpr int kDmaCK = 32, kDmaRows = 128;
+constexpr int kDmaAFloats = kDmaCK * 32 * 4;
 constexpr int kDmaMaxSlabs = 64;
 constexpr unsigned kOutOfRange = 0x80000000u;
-constexpr int kDmaBufs = 3;
-constexpr size_t kDmaLdsBytes = (kDmaBufs * kDmaStage + 64 + kDmaRows) * sizeof(float);
+constexpr int dma_bufs(int waves) { return waves == 8 ? 3 : 2; }
+constexpr int dma_stage_floats(int waves) { return kDmaAFloats + kDmaCK * 32 * waves; }
+constexpr size_t dma_lds_bytes(int waves) { return (dma_bufs(waves) * dma_stage_floats(waves) + 64 + kDmaRows) * sizeof(float); }
 
-__global__ __launch_bounds__(kDmaThreads, 1) void masked_conv_dma_kernel(const MaskedLaunch g)
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES, (WAVES == 8 ? 1 : 2)) void masked_conv_dma_kernel(const MaskedLaunch g)
 {
+    constexpr int kDmaThreads = 64 * WAVES, kDmaPos = 32 * WAVES, kDmaStage = dma_stage_floats(WAVES), kDmaBufs = dma_bufs(WAVES);
+    constexpr int kChunks = WAVES / 2;                 // 64-position pieces of a B row (4-byte gathers: one piece per wave instruction)
+    constexpr int kAPieces = kDmaAFloats / (kDmaThreads * 4);
     extern __shared__ float lds[];
     unsigned *s_open = reinterpret_cast<unsigned *>(lds + kDmaBufs * kDmaStage);   // [2] slab bitmask, [2] step-rule flag
     float *s_bias = lds + kDmaBufs * kDmaStage + 64;
@@ -399,9 +408,9 @@ __global__ __launch_bounds__(kDmaThreads, 1) void masked_conv_dma_kernel(const M
     if (tid < kDmaRows) s_bias[tid] = g.bias[row0 + tid];
     __syncthreads();
 
-    // the position this lane STAGES (B rows are 256 positions wide: wave w fills columns 64 (w & 3) .. + 63 of k rows
-    // 2 i + (w >> 2)) and the position this lane COMPUTES (column 32 w + col)
-    const Pos dp = decode_pos(g, static_cast<int64_t>(pc) * kDmaPos + (wave & 3) * 64 + lane);
+    // the position this lane STAGES (B rows are kDmaPos positions wide: wave w fills columns 64 (w % kChunks) .. + 63 of k rows
+    // 2 i + w / kChunks) and the position this lane COMPUTES (column 32 w + col)
+    const Pos dp = decode_pos(g, static_cast<int64_t>(pc) * kDmaPos + (wave % kChunks) * 64 + lane);
     const Pos mp = decode_pos(g, static_cast<int64_t>(pc) * kDmaPos + wave * 32 + col);
     const int32_t dcentre = dp.ok ? g.topo_out[grp_o * hw + dp.py * g.w_ + dp.px] : 0;
     if (g.step != kNoStep) {
@@ -423,45 +432,8 @@ __global__ __launch_bounds__(kDmaThreads, 1) void masked_conv_dma_kernel(const M
         for (int d = 32; d > 0; d >>= 1) { lo |= __shfl_xor(lo, d, 64); hi |= __shfl_xor(hi, d, 64); }
         if (lane == 0) { atomicOr(&s_open[0], lo); atomicOr(&s_open[1], hi); }
     }
-    // WIDE staging of B (1x1 layers): when the workgroup's 256 listed positions come in aligned runs of four that are
-    // contiguous in memory (the step-contiguous plane order of the coder's hidden activations, see in_perm) and share their
-    // masks, lane l stages positions 4 l .. 4 l + 3 of a k row with ONE 16-byte piece: 4 gathers per wave and stage instead
-    // of 16 (the texture-address unit takes ~33 cycles per 64-lane gather whatever its width, and 144 of them per stage did
-    // not hide under a 64-MFMA stage).  Checked per workgroup; anything else takes the 4-byte gathers.
-    unsigned wide_voff = kOutOfRange;
-    uint64_t wide_open = 0ull;
-    {
-        bool okw = g.ksize == 1 && (hw & 3) == 0;
-        if (okw) {
-            const int64_t j0 = static_cast<int64_t>(pc) * kDmaPos + 4 * lane;
-            const Pos p0 = decode_pos(g, j0);
-            if (p0.ok) {
-                const int s0 = in_slot(g, p0.py * g.w_ + p0.px);
-                const int32_t c0 = g.topo_out[grp_o * hw + p0.py * g.w_ + p0.px];
-                okw = (s0 & 3) == 0;
-                for (int gin = 0; gin < g.gi; ++gin)
-                    if (tap_open(g, gin, true, p0.py * g.w_ + p0.px, c0)) wide_open |= 1ull << gin;
-                for (int i = 1; i < 4 && okw; ++i) {
-                    const Pos pi = decode_pos(g, j0 + i);
-                    okw = pi.ok && pi.b == p0.b && in_slot(g, pi.py * g.w_ + pi.px) == s0 + i;
-                    if (okw) {
-                        const int32_t ci = g.topo_out[grp_o * hw + pi.py * g.w_ + pi.px];
-                        uint64_t oi = 0ull;
-                        for (int gin = 0; gin < g.gi; ++gin)
-                            if (tap_open(g, gin, true, pi.py * g.w_ + pi.px, ci)) oi |= 1ull << gin;
-                        okw = oi == wide_open;
-                    }
-                }
-                wide_voff = (static_cast<unsigned>(p0.b) * static_cast<unsigned>(g.cin) * static_cast<unsigned>(hw) + static_cast<unsigned>(s0)) * 4u;
-            } else {
-                for (int i = 1; i < 4; ++i) okw = okw && !decode_pos(g, j0 + i).ok;   // a run is listed entirely or not at all
-            }
-        }
-        if (!okw) atomicOr(&s_open[3], 1u);
-    }
     __syncthreads();
     if (g.step != kNoStep && s_open[2] == 0u) return;   // workgroup-uniform
-    const bool wide = __builtin_amdgcn_readfirstlane(s_open[3]) == 0u;
     uint64_t todo = static_cast<uint64_t>(__builtin_amdgcn_readfirstlane(s_open[0])) |
                     (static_cast<uint64_t>(__builtin_amdgcn_readfirstlane(s_open[1])) << 32);
     const int stages_per_slab = g.gs_in / kDmaCK;
@@ -484,7 +456,6 @@ __global__ __launch_bounds__(kDmaThreads, 1) void masked_conv_dma_kernel(const M
     int is_t = is_slab / g.gi, is_gin = is_slab - is_t * g.gi;
     auto slab_voffset = [&](int s, int t) __attribute__((always_inline)) {
         const int yy = dp.py + t / g.ksize - g.pad, xx = dp.px + t % g.ksize - g.pad;
-        if (wide) return ((wide_open >> s) & 1ull) ? wide_voff : kOutOfRange;   // 1x1 layer: slab = input group, the lane's own run
         const bool on = (my_open >> s) & 1ull;
         return on ? img_off + static_cast<unsigned>(in_slot(g, yy * g.w_ + xx)) * 4u : kOutOfRange;
     };
@@ -504,13 +475,10 @@ __global__ __launch_bounds__(kDmaThreads, 1) void masked_conv_dma_kernel(const M
         srca_i = wchunk + (static_cast<int64_t>(is_t) * g.cin + ci0_i) * 128 + tid * 4;                                         \
     } while (0)
 #define BASIC_MCONV_ISSUE_A(J)                                                                                                  \
-    __builtin_amdgcn_global_load_lds((glb_cvoid *)(srca_i + (J) * 2048), (lds_void *)(dst_i + (J) * 2048 + wave * 256), 16, 0, 0)
+    __builtin_amdgcn_global_load_lds((glb_cvoid *)(srca_i + (J) * kDmaThreads * 4), (lds_void *)(dst_i + (J) * kDmaThreads * 4 + wave * 256), 16, 0, 0)
 #define BASIC_MCONV_ISSUE_B(I)                                                                                                  \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_void *)(dst_i + kDmaAFloats + (wave & 3) * 64 + (2 * (I) + (wave >> 2)) * kDmaPos), \
-                                             4, voff, (ci0_i + 2 * (I) + (wave >> 2)) * hw * 4, 0, 0)
-#define BASIC_MCONV_ISSUE_BW(I)   /* wide: k row 4 wave + I, 16 bytes = four positions per lane */                          \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_void *)(dst_i + kDmaAFloats + (4 * wave + (I)) * kDmaPos), 16, voff,   \
-                                             (ci0_i + 4 * wave + (I)) * hw * 4, 0, 0)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_void *)(dst_i + kDmaAFloats + (wave % kChunks) * 64 + (2 * (I) + wave / kChunks) * kDmaPos), \
+                                             4, voff, (ci0_i + 2 * (I) + wave / kChunks) * hw * 4, 0, 0)
 #define BASIC_MCONV_ISSUE_END()                                                                                                 \
     do {                                                                                                                        \
         if (++is_j == stages_per_slab) {                                                                                        \
@@ -527,65 +495,62 @@ __global__ __launch_bounds__(kDmaThreads, 1) void masked_conv_dma_kernel(const M
 #define BASIC_MCONV_ISSUE(BUF)                                                                                                  \
     do {                                                                                                                        \
         BASIC_MCONV_ISSUE_BEGIN(BUF);                                                                                           \
-        BASIC_MCONV_ISSUE_A(0);                                                                                                 \
-        BASIC_MCONV_ISSUE_A(1);                                                                                                 \
-        if (wide) {                                                                                                             \
-            _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) BASIC_MCONV_ISSUE_BW(i_);                                          \
-        } else {                                                                                                                \
-            _Pragma("unroll") for (int i_ = 0; i_ < kDmaCK / 2; ++i_) BASIC_MCONV_ISSUE_B(i_);                                  \
-        }                                                                                                                       \
+        _Pragma("unroll") for (int j_ = 0; j_ < kAPieces; ++j_) BASIC_MCONV_ISSUE_A(j_);                                        \
+        _Pragma("unroll") for (int i_ = 0; i_ < kDmaCK / 2; ++i_) BASIC_MCONV_ISSUE_B(i_);                                      \
         BASIC_MCONV_ISSUE_END();                                                                                                \
     } while (0)
 
-    // Pipeline: THREE stage buffers and ONE workgroup barrier per stage, placed in the MIDDLE of the stage.  At the barrier of
-    // stage n every wave has waited for its own DMAs of stage n+1 (issued a whole stage earlier) -- so after it stage n+1 is
-    // complete in LDS -- and every wave has left stage n-1, whose buffer the DMA of stage n+2 (issued right after the barrier)
-    // overwrites.  The MFMA stream of a wave therefore runs across stage boundaries without a pause: the first fragments of
-    // stage n+1 are read during the last step of stage n.  (With the barrier at the stage boundary and two buffers, every
-    // wave of the workgroup stopped there together, issued its DMAs and waited for its first LDS reads: ~25 % of the time of
-    // a 64-MFMA stage, measured with the staging switched off.)
+    // Pipeline, WAVES = 8: THREE stage buffers and ONE workgroup barrier per stage, placed in the MIDDLE of the stage.  At the
+    // barrier of stage n every wave has waited for its own DMAs of stage n+1 (issued a whole stage earlier) -- so after it
+    // stage n+1 is complete in LDS -- and every wave has left stage n-1, whose buffer the DMA of stage n+2 (issued in pieces
+    // over the steps after the barrier) overwrites.  The MFMA stream of a wave runs across stage boundaries without a pause:
+    // the first fragments of stage n+1 are read during the last step of stage n.
+    // WAVES = 4: TWO buffers, the barrier at the START of stage n (stage n has landed, everyone has left stage n-1), then the
+    // DMA of stage n+1 in pieces; the co-resident workgroup covers the pause at the barrier.
+    constexpr int kSteps = kDmaCK / 2, kBar = kDmaBufs == 3 ? kSteps / 2 : 0;
     if (nstages > 0 && !(g.debug & 1)) {
         BASIC_MCONV_ISSUE(0);
-        if (nstages > 1) BASIC_MCONV_ISSUE(1);
+        if (kDmaBufs == 3 && nstages > 1) BASIC_MCONV_ISSUE(1);
     }
-    __syncthreads();   // stages 0 and 1 have landed
     const int a_lane = (khalf * 32 + col) * 4, b_lane = khalf * kDmaPos + wave * 32 + col;
     float fb[2];
     f32x4 fa[2];
-    fb[0] = lds[kDmaAFloats + b_lane];
-    fa[0] = *reinterpret_cast<const f32x4 *>(lds + a_lane);
-    int buf = 0;   // stage buffer of the current stage (stg % 3)
+    if (kDmaBufs == 3) {
+        __syncthreads();   // stages 0 and 1 have landed
+        fb[0] = lds[kDmaAFloats + b_lane];
+        fa[0] = *reinterpret_cast<const f32x4 *>(lds + a_lane);
+    }
+    int buf = 0;   // stage buffer of the current stage (stg % kDmaBufs)
     // one stage: 16 steps of { next step's LDS reads, 4 MFMAs }.  FIRST = first stage of a canonical block: the chain starts
     // from an inline-constant 0 (no register initialisation).
     auto run_stage = [&](int stg, auto first_tag) __attribute__((always_inline)) {
         constexpr bool kFirst = decltype(first_tag)::value;
-        constexpr int kSteps = kDmaCK / 2;
-        const int nbuf = buf == 2 ? 0 : buf + 1;
+        const int nbuf = buf == kDmaBufs - 1 ? 0 : buf + 1;
         const float *al = lds + buf * kDmaStage + a_lane, *bl = al + (kDmaAFloats + b_lane - a_lane);
         const float *aln = lds + nbuf * kDmaStage + a_lane, *bln = aln + (kDmaAFloats + b_lane - a_lane);
-        const bool issuing = stg + 2 < nstages && !(g.debug & 1);
+        const bool issuing = stg + (kDmaBufs - 1) < nstages && !(g.debug & 1);
 #pragma unroll
         for (int st = 0; st < kSteps; ++st) {
             const int cur = st & 1, nxt = cur ^ 1;
-            if (st == kSteps / 2) {
-                __syncthreads();   // vmcnt(0): my DMAs of stage stg+1 have landed; barrier: everyone's have, and stage stg-1 is free
-                if (issuing) BASIC_MCONV_ISSUE_BEGIN(buf == 0 ? 2 : buf - 1);
-            }
-            if (st >= kSteps / 2 && issuing) {   // stage stg+2's DMA, two or three pieces per step
-                const int q = st - kSteps / 2;
-                if (q < 2) BASIC_MCONV_ISSUE_A(q);
-                if (wide) {
-                    if (q < 4) BASIC_MCONV_ISSUE_BW(q);
-                } else {
-                    BASIC_MCONV_ISSUE_B(2 * q);
-                    BASIC_MCONV_ISSUE_B(2 * q + 1);
+            if (st == kBar) {
+                __syncthreads();   // vmcnt(0): my DMAs of the next stage to be read have landed; barrier: everyone's have, and the oldest buffer is free
+                if (issuing) BASIC_MCONV_ISSUE_BEGIN(kDmaBufs == 3 ? (buf == 0 ? 2 : buf - 1) : nbuf);
+                if (kDmaBufs == 2) {
+                    fb[0] = bl[0];
+                    fa[0] = *reinterpret_cast<const f32x4 *>(al);
                 }
-                if (st == kSteps - 1) BASIC_MCONV_ISSUE_END();
+            }
+            if (st >= kBar && st < kBar + kSteps / 2 && issuing) {   // the next DMA, two or three pieces per step
+                const int q = st - kBar;
+                if (q < kAPieces) BASIC_MCONV_ISSUE_A(q);
+                BASIC_MCONV_ISSUE_B(2 * q);
+                BASIC_MCONV_ISSUE_B(2 * q + 1);
+                if (q == kSteps / 2 - 1) BASIC_MCONV_ISSUE_END();
             }
             if (st + 1 < kSteps) {
                 fb[nxt] = bl[(st + 1) * 2 * kDmaPos];
                 fa[nxt] = *reinterpret_cast<const f32x4 *>(al + (st + 1) * 2 * 128);
-            } else {   // first fragments of the next stage (complete since this stage's barrier; a harmless read after the last stage)
+            } else if (kDmaBufs == 3) {   // first fragments of the next stage (complete since this stage's barrier; a harmless read after the last stage)
                 fb[nxt] = bln[0];
                 fa[nxt] = *reinterpret_cast<const f32x4 *>(aln);
             }
@@ -615,7 +580,6 @@ __global__ __launch_bounds__(kDmaThreads, 1) void masked_conv_dma_kernel(const M
 #undef BASIC_MCONV_ISSUE_BEGIN
 #undef BASIC_MCONV_ISSUE_A
 #undef BASIC_MCONV_ISSUE_B
-#undef BASIC_MCONV_ISSUE_BW
 #undef BASIC_MCONV_ISSUE_END
 
     if (mp.ok && !(g.debug & 4)) {
@@ -721,7 +685,8 @@ extern "C" int basic_mconv_plan_create(const float *weight, const float *bias, i
     if (e == hipSuccess && p->mt > 1) e = upload(&p->d_w1, w1);
     if (e == hipSuccess && dma) e = upload(&p->d_wa, wa);
     if (e == hipSuccess) e = upload(&p->d_bias, hb);
-    if (e == hipSuccess && dma) e = ensure_max_lds(reinterpret_cast<const void *>(&masked_conv_dma_kernel));
+    if (e == hipSuccess && dma) e = ensure_max_lds(reinterpret_cast<const void *>(&masked_conv_dma_kernel<8>));
+    if (e == hipSuccess && dma) e = ensure_max_lds(reinterpret_cast<const void *>(&masked_conv_dma_kernel<4>));
     if (e != hipSuccess) { basic_mconv_plan_destroy(p); return hip_fail(e, "mconv_plan_create", __FILE__, __LINE__); }
     *out = p;
     return BASIC_OK;
@@ -804,12 +769,20 @@ static int mconv_forward(const basic_mconv_plan *p, const float *d_x, const int3
     }
     if (use_dma) {
         g.w = p->d_wa;
-        g.n_pchunks = static_cast<int>((n_pos + kDmaPos - 1) / kDmaPos);
         g.n_rchunks = p->cout / kDmaRows;
         g.x_bytes = static_cast<int>(x_bytes);
         { const char *e = std::getenv("BASIC_MCONV_DEBUG"); g.debug = e ? std::atoi(e) : 0; }
+        // 4 waves (128 positions per workgroup, two workgroups per compute unit) or 8 (256 positions, one workgroup);
+        // BASIC_MCONV_DMA_WAVES picks one
+        // measured (scripts/mconv_probe.py, warm clocks): the 4-wave shape is never slower -- 0.899 vs 0.905 ms on the 1536 -> 1536
+        // layer, 0.31 vs 0.40 / 0.48 vs 0.60 ms on the 384-row layers whose 8-wave grid is one and a half rounds of the chip
+        int waves = 4;
+        if (const char *e = std::getenv("BASIC_MCONV_DMA_WAVES")) waves = std::atoi(e) == 8 ? 8 : 4;
+        const int ppw = 32 * waves;
+        g.n_pchunks = static_cast<int>((n_pos + ppw - 1) / ppw);
         const unsigned grid = static_cast<unsigned>((g.n_pchunks + 7) / 8 * 8) * g.n_rchunks;
-        hipLaunchKernelGGL(masked_conv_dma_kernel, dim3(grid), dim3(kDmaThreads), kDmaLdsBytes, st, g);
+        if (waves == 8) hipLaunchKernelGGL(masked_conv_dma_kernel<8>, dim3(grid), dim3(512), dma_lds_bytes(8), st, g);
+        else hipLaunchKernelGGL(masked_conv_dma_kernel<4>, dim3(grid), dim3(256), dma_lds_bytes(4), st, g);
     } else if (use_block) {
         {
             std::lock_guard<std::mutex> lock(p->mu);

@@ -211,13 +211,16 @@ def _run_mconv_variants(plans, x, topo_in, topo_out, sel, cout, off, variants, *
     B, _, H, W = x.shape
     outs = []
     for pl, kernel in variants:
-        os.environ["BASIC_MCONV_KERNEL"] = kernel
+        os.environ["BASIC_MCONV_KERNEL"] = kernel[:3] if kernel.startswith("dma") else kernel
+        if kernel in ("dma4", "dma8"):   # the two workgroup shapes of the LDS-DMA kernel
+            os.environ["BASIC_MCONV_DMA_WAVES"] = kernel[3]
         try:
             out = torch.full((B, cout + off, H, W), -7.0).cuda()
             plans[pl](x.cuda(), topo_in.int().cuda(), topo_out.int().cuda(), sel.cuda(), out, out_offset=off, **call)
             torch.cuda.synchronize()
         finally:
             del os.environ["BASIC_MCONV_KERNEL"]
+            os.environ.pop("BASIC_MCONV_DMA_WAVES", None)
         outs.append(out.cpu())
     return outs
 
@@ -259,8 +262,8 @@ def test_masked_conv_fuzz(seed):
     sel = torch.randperm(B * H * W, generator=g)[:npos].sort().values.int()
     off = int(rng.choice([0, 3]))
     outs = _run_mconv_variants(dict(p=plan, p1=plan_mt1), x, topo_in, topo_out, sel, cout, off,
-                               [("p", "gather"), ("p1", "gather"), ("p", "block"), ("p", "dma")])
-    for i in (1, 2, 3):
+                               [("p", "gather"), ("p1", "gather"), ("p", "block"), ("p", "dma8"), ("p", "dma4")])
+    for i in (1, 2, 3, 4):
         assert torch.equal(outs[0], outs[i]), f"kernel variant {i} differs from the gather kernel"
     mask = torch.zeros(B * H * W, dtype=torch.bool)
     mask[sel.long()] = True
@@ -302,9 +305,22 @@ def test_masked_conv_codec_sized_layers_all_kernels_identical(case):
     b = torch.randn(cout, generator=g) * 0.1
     plan = K.MaskedConvPlan(w, b, gi, go, same, K.ACT_LEAKY_RELU)
     sel = torch.nonzero((cb.reshape(-1) == 1)[None].expand(B, -1).reshape(-1)).reshape(-1).int()
-    outs = _run_mconv_variants(dict(p=plan), x, topo_in, topo_out, sel, cout, 0, [("p", "gather"), ("p", "dma"), ("p", "block")], **call)
-    assert torch.equal(outs[0], outs[1]), "LDS-DMA kernel differs from the gather kernel"
+    if case == "merger":   # the coder's layout of this layer: step-contiguous planes on both sides (16-byte B pieces in the DMA kernel)
+        perm = torch.empty(H * W, dtype=torch.int32)
+        perm[torch.argsort(1 - cb.reshape(-1), stable=True)] = torch.arange(H * W, dtype=torch.int32)
+        call = dict(in_perm=perm.cuda(), out_perm=perm.cuda())
+        xp = torch.empty_like(x).reshape(B, cin, H * W)
+        xp[:, :, perm.long()] = x.reshape(B, cin, H * W)
+        x_in = xp.reshape(B, cin, H, W)
+    else:
+        perm, x_in = None, x
+    outs = _run_mconv_variants(dict(p=plan), x_in, topo_in, topo_out, sel, cout, 0,
+                               [("p", "gather"), ("p", "dma8"), ("p", "block"), ("p", "dma4")], **call)
+    assert torch.equal(outs[0], outs[1]), "LDS-DMA kernel (8 waves) differs from the gather kernel"
     assert torch.equal(outs[0], outs[2]), "block kernel differs from the gather kernel"
+    assert torch.equal(outs[0], outs[3]), "LDS-DMA kernel (4 waves) differs from the gather kernel"
+    if perm is not None:   # back to row-major planes for the comparison with the reference
+        outs = [o.reshape(B, cout, H * W)[:, :, perm.long()].reshape(B, cout, H, W) for o in outs]
     if case != "step":
         ref = torch.nn.functional.leaky_relu(_masked_conv_ref(x, w, b, topo_in, topo_out, same), 0.01)
         mask = torch.zeros(B * H * W, dtype=torch.bool)
