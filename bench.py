@@ -266,10 +266,7 @@ def run_ar_workload(args):
     # Whole batches in flight on concurrent stream workers, as in the headline: one worker's rANS chains run beside another's
     # convolutions; the scan-line schedule's launch-bound step sequences (HIP graphs) of several workers interleave on the chip.
     from cbench_basic_amd.benchmark.stream_workers import StreamWorkerPool
-    # one pool for every leg: the strong-scaling leg (world > 1, or --strong-in-process at N = 1) codes small batches and wants
-    # more of them in flight than the headline leg (see strong_proxy_child)
-    strong_w = max(workers, args.strong_workers) if (by_steps and (world > 1 or args.strong_in_process)) else workers
-    pool = StreamWorkerPool(make_codec, strong_w, dev)
+    pool = StreamWorkerPool(make_codec, workers, dev)
     codec = pool.codecs[0]
     x = torch.stack([image(i, args.size) for i in range(batch)]).to(dev)
 
@@ -420,7 +417,7 @@ def strong_proxy_child(args):
         return dict(value=d["value"], unit="Mpix/s", images_per_step=sb, steps=steps, workers=sw, batches_in_flight=sw, token_lanes=lanes,
                     ms_per_step=d["ms_per_step"], call_latency_ms=d["config"].get("call_latency_ms"), predicted_8gpu_strong=8 * d["value"],
                     note=f"BASELINE configs[4] as written is {args.total} images per step over 8 GPUs = {sb} per GPU: this leg runs that share on one GPU "
-                         "(image-sharded, no data-path collective, so the N = 8 strong figure is 8 x it up to launch jitter); own process, `" + " ".join(cmd[1:]) + "`")
+                         "(image-sharded, no data-path collective, so the N = 8 strong figure is 8 x it up to launch jitter); own process, `bench.py " + " ".join(cmd[2:]) + "`")
     except Exception as e:
         return dict(error=repr(e))
 

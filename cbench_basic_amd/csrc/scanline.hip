@@ -22,11 +22,19 @@
 // v_mfma_f32_32x32x2_f32 chain of the masked convolution, scripts/micro/mfma_arith.hip); the partials are added in block
 // order, then the bias.  Taps outside the image enter as zeros, as the masked-out slabs do there.
 //
-// Cross-workgroup visibility follows MI355X_MICROARCH.md ("Workgroup dispatch, XCD placement & inter-workgroup visibility",
-// valid-forms table, first row): every handed-over byte is stored sc1 and loaded sc1 (agent-scope relaxed atomics lower to
-// exactly that), every storing wave drains (s_waitcnt vmcnt(0)) before the workgroup barrier, ONE lane then adds to the
-// device counter, the polling lane reads the counter sc1, and the other waves load only after the workgroup barrier the
-// polling wave joins.  One workgroup per compute unit (the LDS footprint guarantees it); every spin is bounded.
+// Cross-workgroup exchange (round 3): DATA-TAGGED GRANULES.  Every value one workgroup hands to the others -- a layer output,
+// a coded latent, a (mean, table row) pair for the decoder wavefronts -- travels as ONE naturally aligned 8-byte word
+// { float bits | tag << 32 } written with an agent-scope (sc1, write-through) store and read with agent-scope loads; the tag
+// is the coding step + 1 for the per-step buffers and the position + 1 for the position-major copy of the coded latent.  A
+// consumer polls the word until its tag is the one it expects: the 8-byte store is single-copy atomic, so a matching tag means
+// the value beside it is the matching value, and no barrier, no store drain and no separate flag is needed -- a layer
+// exchange costs one store-to-load propagation (~2 us) instead of store drain + device barrier + loads (~5 us, measured in
+// round 2).  The buffers are zeroed before the launch (tag 0 never matches).  Overwriting is safe without a second
+// handshake: workgroup X can write step p+1 of layer l only after it has consumed step p+1 of layer l-1 from EVERY workgroup
+// (for l = 0: position p of the coded latent from every producer), and a workgroup that has produced that has -- in program
+// order -- already consumed step p of layer l.  Every poll is bounded (kSpinLimit, and the launch's error flag is checked while
+// spinning): a launch whose grid is not fully resident gives up and reports it instead of hanging.  One workgroup per compute
+// unit (the LDS footprint guarantees it), as MI355X_MICROARCH.md's inter-workgroup visibility section requires of spin-waits.
 #include "common.h"
 
 #include <algorithm>
@@ -49,7 +57,7 @@ struct ScanArgs {
     const float *y;       // [B][C][HW]   (encoder input)
     const float *priorT;  // [B][HW][P]   position-major copy of the prior (nullptr when P == 0)
     float *ybuf;          // [B][C][HW]   coded latent (output)
-    float *yT;            // [B][HW][C]   position-major working copy of the coded latent (the context convolution reads it)
+    uint64_t *yT;         // [B][HW][C]   position-major working copy of the coded latent as granules (tag = position + 1)
     int32_t *sym, *idx;   // [B][HW * C]  position-major: element p * C + c
     const float *table;
     int table_len;
@@ -58,7 +66,7 @@ struct ScanArgs {
     int rows[kMaxLayers], kdim[kMaxLayers], rpw[kMaxLayers], woff[kMaxLayers], act_after[kMaxLayers];
     int kgroup[kMaxLayers], bpg[kMaxLayers], kpad[kMaxLayers];   // channels / canonical blocks per K group; padded LDS row (see padded_k)
     const float *w[kMaxLayers], *bias[kMaxLayers];
-    float *act[kMaxLayers];   // exchange buffers [B][rows_l]
+    uint64_t *act[kMaxLayers];   // exchange buffers [B][rows_l] of granules (tag = coding step + 1)
     int tap_off[kMaxTaps], tap_dy[kMaxTaps], tap_dx[kMaxTaps];
     int bc, xs_off, ps_off, tab_off, part_off, part_floats, flag_off;   // LDS float offsets (the whole LDS is dynamic)
     unsigned *bar;
@@ -66,8 +74,8 @@ struct ScanArgs {
     int debug;   // BASIC_SCAN_DEBUG timing ablations (wrong results): 1 no barrier wait, 2 no input staging, 4 no dot products
     // decoder only
     int ncompute;          // workgroups [0, ncompute) compute, the rest decode (4 image streams each)
-    float *mu;             // [B][C] means of the current step (compute -> decoder workgroups)
-    int32_t *idx_step;     // [B][C] table rows of the current step
+    uint64_t *mu;          // [B][C] means of the current step (compute -> decoder workgroups), granules
+    uint64_t *idx_step;    // [B][C] table rows of the current step, granules (the row's bits in the value half)
     RansFastView tv;
     const uint32_t *words; // all streams back to back
     const int64_t *word_off;   // [B + 1]
@@ -75,52 +83,28 @@ struct ScanArgs {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ float ld_sc1(const float *p)
+__device__ __forceinline__ uint64_t ld_gran(const uint64_t *p)
 {
-    return __uint_as_float(__hip_atomic_load(reinterpret_cast<unsigned *>(const_cast<float *>(p)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    return __hip_atomic_load(const_cast<uint64_t *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ int ld_sc1_i(const int32_t *p)
+__device__ __forceinline__ void st_gran(uint64_t *p, uint32_t bits, uint32_t tag)
 {
-    return __hip_atomic_load(const_cast<int32_t *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(p, static_cast<uint64_t>(bits) | (static_cast<uint64_t>(tag) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void st_sc1(float *p, float v)
-{
-    __hip_atomic_store(reinterpret_cast<unsigned *>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void st_sc1_i(int32_t *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// 16-byte write-through-side load (global_load_dwordx4 ... sc1).  The compiler does not track inline-asm loads: the
-// caller issues a batch and then waits with ld_wait() before it touches the results.
-__device__ __forceinline__ f4 ld_sc1_x4(const float *p)
-{
-    f4 v;
-    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
-    return v;
-}
-__device__ __forceinline__ void ld_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void st_gran(uint64_t *p, float v, uint32_t tag) { st_gran(p, __float_as_uint(v), tag); }
 
-// device-wide barrier of the resident grid (see the header comment); returns false when the launch has been poisoned
-__device__ __forceinline__ bool grid_barrier(const ScanArgs &a, unsigned &epoch, int *s_flag)
+// polls a granule until it carries `tag`; false when the launch is poisoned (bounded spin / another workgroup gave up)
+__device__ __forceinline__ bool wait_gran(const ScanArgs &a, const uint64_t *p, uint32_t tag, uint64_t &g)
 {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's sc1 stores have left
-    __syncthreads();
-    if (a.debug & 1) { ++epoch; return true; }
-    if (threadIdx.x == 0) {
-        const unsigned target = (epoch + 1u) * gridDim.x;
-        __hip_atomic_fetch_add(a.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        unsigned spins = 0;
-        int ok = 1;
-        while (__hip_atomic_load(a.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            if (++spins > kSpinLimit || (spins % 4096u == 0u && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-                __hip_atomic_store(a.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ok = 0;
-                break;
-            }
+    unsigned spins = 0;
+    while (static_cast<uint32_t>(g >> 32) != tag) {
+        if (++spins > kSpinLimit || (spins % 1024u == 0u && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+            __hip_atomic_store(a.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
         }
-        *s_flag = ok;
+        g = ld_gran(p);
     }
-    __syncthreads();
-    ++epoch;
-    return *s_flag != 0;
+    return true;
 }
 
 __device__ __forceinline__ float wave_sum(float v)
@@ -142,70 +126,67 @@ __device__ __forceinline__ int nearest_scale(float s, const float *tab, int n)
     return best;
 }
 
-// ---- inputs of `nb` images for layer l at position p -> xs[bi][k]
-__device__ __forceinline__ void stage_inputs(const ScanArgs &a, int l, int p, int py, int px, int b0, int nb, float *xs)
+// ---- inputs of `nb` images for layer l at position p -> xs[bi][k]; every exchanged value is polled until it carries the
+//      expected tag (context layer: the neighbour's position + 1; dense layers: this step + 1).  Returns false when poisoned.
+__device__ __forceinline__ bool stage_inputs(const ScanArgs &a, int l, int p, int py, int px, int b0, int nb, float *xs)
 {
     const int tid = threadIdx.x, HW = a.H * a.W, K = a.kdim[l];
-    constexpr int U = 8;
-    if (a.vec4) {
-        const int K4 = K >> 2, total = nb * K4;
-        const int C4 = a.C >> 2, prev4 = l ? a.rows[l - 1] >> 2 : 0;
-        for (int e0 = tid; e0 < total; e0 += kThreads * U) {
-            f4 v[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int e = e0 + u * kThreads;
-                v[u] = f4{0.f, 0.f, 0.f, 0.f};
-                if (e < total) {
-                    const int bi = e / K4, k4 = e - bi * K4;
-                    const int64_t b = b0 + bi;
-                    if (l == 0) {   // causal neighbourhood of the coded latent: [tap][c]
-                        const int t = k4 / C4, c4 = k4 - t * C4;
-                        const int ny = py + a.tap_dy[t], nx = px + a.tap_dx[t];
-                        if (ny >= 0 && nx >= 0 && nx < a.W) v[u] = ld_sc1_x4(a.yT + ((b * HW + p + a.tap_off[t]) * a.C + 4 * c4));
-                    } else if (k4 < prev4) {
-                        v[u] = ld_sc1_x4(a.act[l - 1] + b * a.rows[l - 1] + 4 * k4);
-                    } else if (a.priorT) {   // cat(ctx, prior); the prior is an input of the launch: ordinary loads
-                        v[u] = *reinterpret_cast<const f4 *>(a.priorT + (b * HW + p) * a.P + 4 * (k4 - prev4));
-                    }
-                }
-            }
-            ld_wait();
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int e = e0 + u * kThreads;
-                if (e < total) reinterpret_cast<f4 *>(xs)[e] = v[u];
-            }
-        }
-        return;
-    }
     const int total = nb * K, prev = l ? a.rows[l - 1] : 0;
+    constexpr int U = 8;
+    bool ok = true;
     for (int e0 = tid; e0 < total; e0 += kThreads * U) {
-        float v[U];
+        const uint64_t *src[U];
+        uint64_t g[U];
+        uint32_t want[U];
+        float plain[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
+        for (int u = 0; u < U; ++u) {   // all loads of the batch in flight before the first tag is looked at
             const int e = e0 + u * kThreads;
-            v[u] = 0.f;
+            src[u] = nullptr; g[u] = 0ull; want[u] = 0u; plain[u] = 0.f;
             if (e < total) {
                 const int bi = e / K, kk = e - bi * K;
                 const int64_t b = b0 + bi;
-                if (l == 0) {
+                if (l == 0) {   // causal neighbourhood of the coded latent: [tap][c]
                     const int t = kk / a.C, c = kk - t * a.C;
                     const int ny = py + a.tap_dy[t], nx = px + a.tap_dx[t];
-                    if (ny >= 0 && nx >= 0 && nx < a.W) v[u] = ld_sc1(a.yT + ((b * HW + p + a.tap_off[t]) * a.C + c));
+                    if (ny >= 0 && nx >= 0 && nx < a.W) {
+                        src[u] = a.yT + ((b * HW + p + a.tap_off[t]) * a.C + c);
+                        want[u] = static_cast<uint32_t>(p + a.tap_off[t] + 1);
+                    }
                 } else if (kk < prev) {
-                    v[u] = ld_sc1(a.act[l - 1] + b * prev + kk);
-                } else if (a.priorT) {
-                    v[u] = a.priorT[(b * HW + p) * a.P + (kk - prev)];
+                    src[u] = a.act[l - 1] + b * prev + kk;
+                    want[u] = static_cast<uint32_t>(p + 1);
+                } else if (a.priorT) {   // cat(ctx, prior); the prior is an input of the launch: ordinary loads
+                    plain[u] = a.priorT[(b * HW + p) * a.P + (kk - prev)];
                 }
+                if (src[u]) g[u] = ld_gran(src[u]);
             }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int e = e0 + u * kThreads;
-            if (e < total) xs[e] = v[u];
+            if (e < total) {
+                if (src[u]) {
+                    ok = wait_gran(a, src[u], want[u], g[u]) && ok;
+                    xs[e] = __uint_as_float(static_cast<uint32_t>(g[u]));
+                } else {
+                    xs[e] = plain[u];
+                }
+            }
         }
     }
+    // A position at the start of a row has no left neighbour, so nothing above makes it wait for the previous position --
+    // but the overwrite argument of the exchange buffers (header comment) needs every workgroup's step p+1 to start after
+    // position p is coded: wait for its granules without using the values.
+    if (l == 0 && p > 0 && px == 0) {
+        for (int e = tid; e < nb * a.C; e += kThreads) {
+            const int bi = e / a.C, c = e - bi * a.C;
+            const uint64_t *src = a.yT + ((static_cast<int64_t>(b0 + bi) * HW + p - 1) * a.C + c);
+            uint64_t g = ld_gran(src);
+            ok = wait_gran(a, src, static_cast<uint32_t>(p), g) && ok;
+        }
+    }
+    return ok;
 }
 
 constexpr int kKB = BASIC_MCONV_BLOCK_CHANNELS;
@@ -334,56 +315,57 @@ __global__ __launch_bounds__(kThreads) void scanline_persistent_kernel(const Sca
     const int wg = blockIdx.x;
     const int HW = a.H * a.W;
     const int last = a.nlayers - 1;
-    unsigned epoch = 0;
 
     if (DECODE && wg >= a.ncompute) {
         // ================= decoder workgroups: one wavefront per image stream, the search image in LDS =================
         uint32_t *img = reinterpret_cast<uint32_t *>(lds);
-        int *s_flag = reinterpret_cast<int *>(img + ((a.tv.image_words + 3) & ~3));
         for (int e = tid; e < a.tv.image_words; e += kThreads) img[e] = a.tv.image[e];
         __syncthreads();
         const int b = (wg - a.ncompute) * (kThreads / 64) + wave;
-        const bool live = b < a.B;
+        if (b >= a.B) return;
         WaveDecoder d;
-        if (live) {
+        {
             const int64_t w0 = a.word_off[b];
             d.init(a.tv, img, a.words + w0, static_cast<int>(a.word_off[b + 1] - w0), lane);
         }
         for (int p = 0; p < HW; ++p) {
-            for (int l = 0; l <= last; ++l)
-                if (!grid_barrier(a, epoch, s_flag)) return;
-            if (live) {
-                for (int c0 = 0; c0 < a.C; c0 += 64) {
-                    const int c = c0 + lane;
-                    int32_t row = 0;
-                    float mu = 0.f;
-                    if (c < a.C) { row = ld_sc1_i(a.idx_step + static_cast<int64_t>(b) * a.C + c); mu = ld_sc1(a.mu + static_cast<int64_t>(b) * a.C + c); }
-                    row = row < 0 ? 0 : (row >= a.tv.rows ? a.tv.rows - 1 : row);
-                    const uint32_t meta_l = a.tv.meta[row];
-                    const int32_t size_l = a.tv.sizes[row], off_l = a.tv.offsets[row];
-                    const int cnt = (a.C - c0) < 64 ? (a.C - c0) : 64;
-                    int32_t mine = 0;
-                    for (int j = 0; j < cnt; ++j) {
-                        const int32_t s = d.decode(__builtin_amdgcn_readlane(meta_l, j), __builtin_amdgcn_readlane(size_l, j), lane);
-                        if (lane == j) mine = s;
-                    }
-                    if (c < a.C) {
-                        const int32_t value = mine + off_l;
-                        const float v = static_cast<float>(value) + mu;           // pgm_coder.py:973-978
-                        a.sym[static_cast<int64_t>(b) * a.C * HW + static_cast<int64_t>(p) * a.C + c] = value;
-                        a.idx[static_cast<int64_t>(b) * a.C * HW + static_cast<int64_t>(p) * a.C + c] = row;
-                        a.ybuf[(static_cast<int64_t>(b) * a.C + c) * HW + p] = v;
-                        st_sc1(a.yT + (static_cast<int64_t>(b) * HW + p) * a.C + c, v);
-                    }
+            const uint32_t tag = static_cast<uint32_t>(p + 1);
+            for (int c0 = 0; c0 < a.C; c0 += 64) {
+                const int c = c0 + lane;
+                int32_t row = 0;
+                float mu = 0.f;
+                bool ok = true;
+                if (c < a.C) {   // this step's (table row, mean) of channel c: granules from the compute workgroup that owns it
+                    const uint64_t *pi = a.idx_step + static_cast<int64_t>(b) * a.C + c, *pm = a.mu + static_cast<int64_t>(b) * a.C + c;
+                    uint64_t gi = ld_gran(pi), gm = ld_gran(pm);
+                    ok = wait_gran(a, pi, tag, gi) && wait_gran(a, pm, tag, gm);
+                    row = static_cast<int32_t>(static_cast<uint32_t>(gi));
+                    mu = __uint_as_float(static_cast<uint32_t>(gm));
+                }
+                if (__ballot(!ok) != 0ull) return;   // poisoned launch: wave-uniform exit
+                row = row < 0 ? 0 : (row >= a.tv.rows ? a.tv.rows - 1 : row);
+                const uint32_t meta_l = a.tv.meta[row];
+                const int32_t size_l = a.tv.sizes[row], off_l = a.tv.offsets[row];
+                const int cnt = (a.C - c0) < 64 ? (a.C - c0) : 64;
+                int32_t mine = 0;
+                for (int j = 0; j < cnt; ++j) {
+                    const int32_t s = d.decode(__builtin_amdgcn_readlane(meta_l, j), __builtin_amdgcn_readlane(size_l, j), lane);
+                    if (lane == j) mine = s;
+                }
+                if (c < a.C) {
+                    const int32_t value = mine + off_l;
+                    const float v = static_cast<float>(value) + mu;           // pgm_coder.py:973-978
+                    st_gran(a.yT + (static_cast<int64_t>(b) * HW + p) * a.C + c, v, tag);   // first: the compute workgroups wait for it
+                    a.sym[static_cast<int64_t>(b) * a.C * HW + static_cast<int64_t>(p) * a.C + c] = value;
+                    a.idx[static_cast<int64_t>(b) * a.C * HW + static_cast<int64_t>(p) * a.C + c] = row;
+                    a.ybuf[(static_cast<int64_t>(b) * a.C + c) * HW + p] = v;
                 }
             }
-            if (!grid_barrier(a, epoch, s_flag)) return;
         }
         return;
     }
 
     // ================= compute workgroups: a fixed slice of every layer's rows, weights resident in LDS =================
-    int *s_flag = reinterpret_cast<int *>(lds + a.flag_off);
     int rows_w[kMaxLayers];
     for (int l = 0; l < a.nlayers; ++l) {
         int r = a.rows[l] - wg * a.rpw[l];
@@ -397,17 +379,24 @@ __global__ __launch_bounds__(kThreads) void scanline_persistent_kernel(const Sca
     float *tab = lds + a.tab_off;
     for (int e = tid; e < a.table_len; e += kThreads) tab[e] = a.table[e];
     float *xs = lds + a.xs_off, *ps = lds + a.ps_off, *part = lds + a.part_off;
+    int *s_flag = reinterpret_cast<int *>(lds + a.flag_off);
+    if (tid == 0) *s_flag = 0;
     __syncthreads();
     for (int p = 0; p < HW; ++p) {
         const int py = p / a.W, px = p - py * a.W;
+        const uint32_t tag = static_cast<uint32_t>(p + 1);
         for (int l = 0; l <= last; ++l) {
             const int K = a.kdim[l], rw = rows_w[l];
+            if (rw == 0) continue;   // a workgroup without rows of this layer has nothing to produce -- and nothing to wait for
             const float *wl = lds + a.woff[l];
             const int r_first = wg * a.rpw[l];
             for (int b0 = 0; b0 < a.B; b0 += a.bc) {
                 const int nb = (a.B - b0) < a.bc ? (a.B - b0) : a.bc;
-                if (rw > 0 && !(a.debug & 2)) stage_inputs(a, l, p, py, px, b0, nb, xs);
+                bool ok = true;
+                if (!(a.debug & 2)) ok = stage_inputs(a, l, p, py, px, b0, nb, xs);
+                if (!ok) *s_flag = 1;    // (a flag in the dynamic LDS: __syncthreads_or would add static LDS on top of the 160 KB)
                 __syncthreads();
+                if (*s_flag) return;     // poisoned launch: the whole workgroup leaves
                 // units = (canonical block, image, row), one FMA chain each; `part` holds one round of partials as
                 // [block][item]; the finishing threads add an item's partials in block order, then bias and activation
                 const int items = (a.debug & 4) ? 0 : nb * rw, Kp = a.kpad[l];
@@ -429,7 +418,7 @@ __global__ __launch_bounds__(kThreads) void scanline_persistent_kernel(const Sca
                         for (int blk = 0; blk < nblk; ++blk) v += part[blk * n_it + it];
                         v += a.bias[l] ? a.bias[l][r_first + r] : 0.f;
                         if (a.act_after[l]) v = v > 0.f ? v : 0.01f * v;   // LeakyReLU(0.01)
-                        if (l < last) st_sc1(a.act[l] + static_cast<int64_t>(b0 + bi) * a.rows[l] + r_first + r, v);
+                        if (l < last) st_gran(a.act[l] + static_cast<int64_t>(b0 + bi) * a.rows[l] + r_first + r, v, tag);
                         else ps[bi * a.rpw[l] + r] = v;
                     }
                     __syncthreads();   // `part` is reused by the next round; ps is complete for the Gaussian step
@@ -444,24 +433,22 @@ __global__ __launch_bounds__(kThreads) void scanline_persistent_kernel(const Sca
                         const float mu = ps[bi * a.rpw[l] + 2 * j], sg = ps[bi * a.rpw[l] + 2 * j + 1];
                         const int row = nearest_scale(sg, tab, a.table_len);
                         if (DECODE) {
-                            st_sc1_i(a.idx_step + b * a.C + c, row);
-                            st_sc1(a.mu + b * a.C + c, mu);
+                            st_gran(a.idx_step + b * a.C + c, static_cast<uint32_t>(row), tag);
+                            st_gran(a.mu + b * a.C + c, mu, tag);
                         } else {
                             const int64_t e = (b * a.C + c) * HW + p;
                             const int64_t o = b * a.C * HW + static_cast<int64_t>(p) * a.C + c;
                             const float q = rintf(a.y[e] - mu);          // torch.round: half to even
+                            st_gran(a.yT + (b * HW + p) * a.C + c, q + mu, tag);   // first: every workgroup's next step waits for it
                             a.idx[o] = row;
                             a.sym[o] = static_cast<int32_t>(q);
                             a.ybuf[e] = q + mu;
-                            st_sc1(a.yT + (b * HW + p) * a.C + c, q + mu);
                         }
                     }
                 }
                 __syncthreads();   // xs / ps are reused by the next chunk
             }
-            if (!grid_barrier(a, epoch, s_flag)) return;
         }
-        if (DECODE && !grid_barrier(a, epoch, s_flag)) return;   // the decoder workgroups have written position p
     }
 }
 
@@ -678,31 +665,34 @@ int fill_args(basic_scanline_plan *p, ScanArgs &a, int batch, int h, int w, cons
     a.B = batch; a.C = p->C; a.H = h; a.W = w; a.P = p->P;
     a.nlayers = p->nlayers; a.ntaps = p->ntaps; a.vec4 = p->vec4;
     a.table = d_table; a.table_len = table_len;
+    // scratch: [granule regions: layer exchange buffers, position-major coded latent, step means / rows][position-major prior]
     size_t floats = 0;
-    for (int l = 0; l < p->nlayers; ++l) floats += align4(static_cast<size_t>(batch) * p->rows[l]);
-    const size_t yT_off = floats;     floats += align4(static_cast<size_t>(batch) * HW * p->C);
+    for (int l = 0; l < p->nlayers; ++l) floats += align4(2 * static_cast<size_t>(batch) * p->rows[l]);
+    const size_t yT_off = floats;     floats += align4(2 * static_cast<size_t>(batch) * HW * p->C);
+    const size_t mu_off = floats;     floats += align4(2 * static_cast<size_t>(batch) * p->C);
+    const size_t is_off = floats;     floats += align4(2 * static_cast<size_t>(batch) * p->C);
+    const size_t gran_floats = floats;
     const size_t pT_off = floats;     floats += align4(static_cast<size_t>(batch) * HW * p->P);
-    const size_t mu_off = floats;     floats += align4(static_cast<size_t>(batch) * p->C);
-    const size_t is_off = floats;     floats += align4(static_cast<size_t>(batch) * p->C);
     if (floats > p->scratch_cap) {
         if (p->d_scratch) (void)hipFree(p->d_scratch);
         p->d_scratch = nullptr; p->scratch_cap = 0;
         BASIC_HIP_TRY(hipMalloc(&p->d_scratch, floats * sizeof(float)));
         p->scratch_cap = floats;
     }
+    BASIC_HIP_TRY(hipMemsetAsync(p->d_scratch, 0, gran_floats * sizeof(float), st));   // tag 0 = "not written in this launch"
     size_t ao = 0;
     int kmax = 0;
     for (int l = 0; l < p->nlayers; ++l) {
         a.rows[l] = p->rows[l]; a.kdim[l] = p->kdim[l]; a.rpw[l] = p->rpw[l]; a.woff[l] = p->woff[l]; a.act_after[l] = p->act_after[l];
         a.kgroup[l] = p->kgroup[l]; a.bpg[l] = p->bpg[l]; a.kpad[l] = p->kpad[l];
         a.w[l] = p->d_w[l]; a.bias[l] = p->d_b[l];
-        a.act[l] = p->d_scratch + ao;
-        ao += align4(static_cast<size_t>(batch) * p->rows[l]);
+        a.act[l] = reinterpret_cast<uint64_t *>(p->d_scratch + ao);
+        ao += align4(2 * static_cast<size_t>(batch) * p->rows[l]);
         kmax = p->kdim[l] > kmax ? p->kdim[l] : kmax;
     }
-    a.yT = p->d_scratch + yT_off;
-    a.mu = p->d_scratch + mu_off;
-    a.idx_step = reinterpret_cast<int32_t *>(p->d_scratch + is_off);
+    a.yT = reinterpret_cast<uint64_t *>(p->d_scratch + yT_off);
+    a.mu = reinterpret_cast<uint64_t *>(p->d_scratch + mu_off);
+    a.idx_step = reinterpret_cast<uint64_t *>(p->d_scratch + is_off);
     a.priorT = nullptr;
     if (p->P > 0) {
         float *pT = p->d_scratch + pT_off;

@@ -13,7 +13,10 @@ with torch.no_grad():
         p.copy_(torch.randn(p.shape, generator=g) * (0.03 if p.dim() > 1 else 0.02))
 c = c.eval().cuda()
 c.update_state()
-for B, H, W in ((1, 32, 48), (8, 16, 16), (64, 16, 16), (24, 32, 48)):
+shapes = ((1, 32, 48), (8, 16, 16), (64, 16, 16), (24, 32, 48))
+if os.environ.get("PROBE_SHAPES"):   # ablation runs (BASIC_SCAN_DEBUG: wrong results, timing only): the batch-1 Kodak shape
+    shapes = shapes[:int(os.environ["PROBE_SHAPES"])]
+for B, H, W in shapes:
     y = (torch.randn(B, C, H, W, generator=g) * 2).cuda()
     prior = torch.stack([torch.randn(B, C, H, W, generator=g), torch.rand(B, C, H, W, generator=g) * 3 + 0.1], 2).reshape(B, 2 * C, H, W).cuda()
     res = {}
