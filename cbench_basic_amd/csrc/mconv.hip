@@ -326,21 +326,30 @@ __global__ __launch_bounds__(256) void masked_conv_reduce_kernel(const MaskedLau
     const float *src = g.scratch + (tile * g.units * 16 + 4 * wave) * 64 + lane;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     constexpr int kBatch = 16;
-    for (int u0 = 0; u0 < g.units; u0 += kBatch) {
-        float v[kBatch][4];
-        bool on[kBatch];
+    // The open units as bit masks first (one coalesced load of the flags per 64 units), then their partials a batch at a
+    // time in ascending unit order with every load of a batch in flight: a loop that looked at a flag and then loaded that
+    // unit's partial paid two dependent round trips per batch -- ten per context-layer launch of a scan-line step.
+    for (int ub = 0; ub < g.units; ub += 128) {
+        uint64_t m0 = __ballot(ub + lane < g.units && flags[ub + lane] != 0);
+        uint64_t m1 = __ballot(ub + 64 + lane < g.units && flags[ub + 64 + lane] != 0);
+        while (m0 | m1) {
+            int u[kBatch];
+            float v[kBatch][4];
 #pragma unroll
-        for (int s = 0; s < kBatch; ++s) {
-            on[s] = u0 + s < g.units && flags[u0 + s] != 0;      // wave-uniform
+            for (int s = 0; s < kBatch; ++s) {
+                if (m0) { u[s] = ub + __builtin_ctzll(m0); m0 &= m0 - 1; }
+                else if (m1) { u[s] = ub + 64 + __builtin_ctzll(m1); m1 &= m1 - 1; }
+                else u[s] = -1;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) v[s][q] = on[s] ? src[(static_cast<int64_t>(u0 + s) * 16 + q) * 64] : 0.f;
-        }
-#pragma unroll
-        for (int s = 0; s < kBatch; ++s)
-            if (on[s]) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) acc[q] += v[s][q];
+                for (int q = 0; q < 4; ++q) v[s][q] = u[s] >= 0 ? src[(static_cast<int64_t>(u[s]) * 16 + q) * 64] : 0.f;
             }
+#pragma unroll
+            for (int s = 0; s < kBatch; ++s)
+                if (u[s] >= 0) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[q] += v[s][q];
+                }
+        }
     }
     if (!p.ok) return;
     float *yb = g.y + (static_cast<int64_t>(p.b) * g.out_total + g.out_off) * hw + out_slot(g, p);
