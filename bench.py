@@ -545,9 +545,11 @@ def main():
                     note="image i of the step's set on rank i mod world; compare with the N=1 line's value (256 images on one GPU)")
 
     # The strong leg runs BEFORE the weak legs: measured at N = 1 (--strong-in-process), the 32-image leg reaches 523 Mpix/s as
-    # the first leg of a process (= the figure of its own process, strong_proxy_child) but 245-288 when it follows 256-image
-    # legs in the same process, whose cause was not found (fresh sessions and streams do not cure it); the 256-image legs are
-    # not affected by what ran before them (667 vs 673 Mpix/s, run-to-run spread).
+    # the first leg of a process (= the figure of its own process, strong_proxy_child) and after plain 256-image legs
+    # (scripts/leg_order_probe.py: 524-532), but 245-288 once the PCIe-inclusive leg has run (BENCH_SKIP_PCIE=1 restores 525):
+    # that leg makes three sessions create their copy streams, after which the entropy side streams of the three sessions
+    # that first run in the strong leg land on hardware queues that already carry busy streams (15 HIP streams on 8 queues).
+    # The 256-image legs are not affected by what ran before them (667 vs 673 Mpix/s, run-to-run spread).
     strong_first = args.strong_first or world > 1
     strong_first_result = None
     if (world > 1 or args.strong_in_process) and strong_first and not args.no_extra_legs:
@@ -575,11 +577,12 @@ def main():
     extra = {}
     if not args.no_extra_legs:
         # (1) input in page-locked HOST memory, uploaded inside compress() (the reference's timed region)
-        hdt, _, _, _ = run_leg(pool, x_host, args.steps, 1)
-        hred = reduce_metric_sums(dict(time_s=hdt, images=float(args.batch * args.steps)), device=dev)
-        extra["pcie_inclusive"] = dict(value=hred["images"] * args.size ** 2 / hred["time_s"] / 1e6, unit="Mpix/s",
-                                       ms_per_step=hred["time_s"] / args.steps * 1e3,
-                                       note="same run, batch in page-locked host memory, H2D inside compress() (general_codec.py:46-47)")
+        if not os.environ.get("BENCH_SKIP_PCIE"):
+            hdt, _, _, _ = run_leg(pool, x_host, args.steps, 1)
+            hred = reduce_metric_sums(dict(time_s=hdt, images=float(args.batch * args.steps)), device=dev)
+            extra["pcie_inclusive"] = dict(value=hred["images"] * args.size ** 2 / hred["time_s"] / 1e6, unit="Mpix/s",
+                                           ms_per_step=hred["time_s"] / args.steps * 1e3,
+                                           note="same run, batch in page-locked host memory, H2D inside compress() (general_codec.py:46-47)")
         # (2) BASELINE configs[4] as written: `total` images per step over all GPUs (strong scaling)
         if (world > 1 or args.strong_in_process) and not strong_first:
             extra["strong"] = strong_leg()
