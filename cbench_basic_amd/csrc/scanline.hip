@@ -68,10 +68,11 @@ struct ScanArgs {
     const float *w[kMaxLayers], *bias[kMaxLayers];
     uint64_t *act[kMaxLayers];   // exchange buffers [B][rows_l] of granules (tag = coding step + 1)
     int tap_off[kMaxTaps], tap_dy[kMaxTaps], tap_dx[kMaxTaps];
-    int bc, xs_off, ps_off, tab_off, part_off, part_floats, flag_off;   // LDS float offsets (the whole LDS is dynamic)
+    int bc, xs_off, ps_off, tab_off, part_off, part_floats, flag_off, bias_off;   // LDS float offsets (the whole LDS is dynamic)
     unsigned *bar;
     int *err;
-    int debug;   // BASIC_SCAN_DEBUG timing ablations (wrong results): 1 no barrier wait, 2 no input staging, 4 no dot products
+    int debug;   // BASIC_SCAN_DEBUG timing ablations (wrong results): 2 no input staging, 4 no dot products
+    long long *prof;   // BASIC_SCAN_PROFILE=1: [layer][2] cycles of workgroup 0 spent staging (incl. waiting) / computing, summed over the steps
     // decoder only
     int ncompute;          // workgroups [0, ncompute) compute, the rest decode (4 image streams each)
     uint64_t *mu;          // [B][C] means of the current step (compute -> decoder workgroups), granules
@@ -92,6 +93,15 @@ __device__ __forceinline__ void st_gran(uint64_t *p, uint32_t bits, uint32_t tag
     __hip_atomic_store(p, static_cast<uint64_t>(bits) | (static_cast<uint64_t>(tag) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ void st_gran(uint64_t *p, float v, uint32_t tag) { st_gran(p, __float_as_uint(v), tag); }
+
+// Workgroup barrier for LDS hand-overs only: waits for this wave's LDS traffic, NOT for its global stores -- __syncthreads()
+// also drains vmcnt, i.e. it would wait ~1-1.5 us per layer for the write-through stores of the granules just published.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
 
 // polls a granule until it carries `tag`; false when the launch is poisoned (bounded spin / another workgroup gave up)
 __device__ __forceinline__ bool wait_gran(const ScanArgs &a, const uint64_t *p, uint32_t tag, uint64_t &g)
@@ -114,9 +124,21 @@ __device__ __forceinline__ float wave_sum(float v)
     return v;
 }
 
-// argmin_j |s - table[j]|, first minimum (pgm_coder.py:802-821; same as entropy.hip::nearest_scale)
-__device__ __forceinline__ int nearest_scale(float s, const float *tab, int n)
+// argmin_j |s - table[j]|, first minimum (pgm_coder.py:802-821; same as entropy.hip::nearest_scale).  On a strictly
+// increasing table (the scale table is: checked once per workgroup) the minimum lies at the first entry >= s or the one
+// before it, the earlier of the two on a tie: a 6-step search instead of a 64-step scan on the step's critical path.
+__device__ __forceinline__ int nearest_scale(float s, const float *tab, int n, bool sorted)
 {
+    if (sorted && __builtin_isfinite(s)) {   // (NaN / infinite scales: the scan below defines the result)
+        int lo = 0, hi = n;   // first index with tab[idx] >= s, in [0, n]
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (tab[mid] < s) lo = mid + 1; else hi = mid;
+        }
+        if (lo == 0) return 0;
+        if (lo == n) return n - 1;
+        return fabsf(s - tab[lo]) < fabsf(s - tab[lo - 1]) ? lo : lo - 1;
+    }
     int best = 0;
     float bd = fabsf(s - tab[0]);
     for (int j = 1; j < n; ++j) {
@@ -132,7 +154,7 @@ __device__ __forceinline__ bool stage_inputs(const ScanArgs &a, int l, int p, in
 {
     const int tid = threadIdx.x, HW = a.H * a.W, K = a.kdim[l];
     const int total = nb * K, prev = l ? a.rows[l - 1] : 0;
-    constexpr int U = 8;
+    constexpr int U = 12;   // loads in flight per thread: the context layer at batch 1 is 9 granules per thread -- ONE round trip, not two
     bool ok = true;
     for (int e0 = tid; e0 < total; e0 += kThreads * U) {
         const uint64_t *src[U];
@@ -380,8 +402,22 @@ __global__ __launch_bounds__(kThreads) void scanline_persistent_kernel(const Sca
     for (int e = tid; e < a.table_len; e += kThreads) tab[e] = a.table[e];
     float *xs = lds + a.xs_off, *ps = lds + a.ps_off, *part = lds + a.part_off;
     int *s_flag = reinterpret_cast<int *>(lds + a.flag_off);
-    if (tid == 0) *s_flag = 0;
+    // this workgroup's biases in LDS (a global load per output on the finishing threads cost ~1 us per layer and step)
+    float *bias_l[kMaxLayers];
+    {
+        int off = a.bias_off;
+        for (int l = 0; l < a.nlayers; ++l) {
+            bias_l[l] = lds + off;
+            for (int e = tid; e < rows_w[l]; e += kThreads) bias_l[l][e] = a.bias[l] ? a.bias[l][wg * a.rpw[l] + e] : 0.f;
+            off += a.rpw[l];
+        }
+    }
+    if (tid == 0) { s_flag[0] = 0; s_flag[1] = 1; }
     __syncthreads();
+    for (int e = tid; e + 1 < a.table_len; e += kThreads)
+        if (!(tab[e] < tab[e + 1])) s_flag[1] = 0;   // not strictly increasing: nearest_scale scans
+    __syncthreads();
+    const bool tab_sorted = s_flag[1] != 0;
     for (int p = 0; p < HW; ++p) {
         const int py = p / a.W, px = p - py * a.W;
         const uint32_t tag = static_cast<uint32_t>(p + 1);
@@ -393,10 +429,18 @@ __global__ __launch_bounds__(kThreads) void scanline_persistent_kernel(const Sca
             for (int b0 = 0; b0 < a.B; b0 += a.bc) {
                 const int nb = (a.B - b0) < a.bc ? (a.B - b0) : a.bc;
                 bool ok = true;
+                const long long t0 = a.prof ? wall_clock64() : 0;
+                // encoder: this thread's latent of the Gaussian step, requested before the last layer's inputs are waited for
+                float y_pre = 0.f;
+                if (!DECODE && l == last && tid < nb * (rw >> 1)) {
+                    const int bi = tid / (rw >> 1), j = tid - bi * (rw >> 1);
+                    y_pre = a.y[((static_cast<int64_t>(b0 + bi)) * a.C + (r_first >> 1) + j) * HW + p];
+                }
                 if (!(a.debug & 2)) ok = stage_inputs(a, l, p, py, px, b0, nb, xs);
                 if (!ok) *s_flag = 1;    // (a flag in the dynamic LDS: __syncthreads_or would add static LDS on top of the 160 KB)
                 __syncthreads();
                 if (*s_flag) return;     // poisoned launch: the whole workgroup leaves
+                const long long t1 = a.prof ? wall_clock64() : 0;
                 // units = (canonical block, image, row), one FMA chain each; `part` holds one round of partials as
                 // [block][item]; the finishing threads add an item's partials in block order, then bias and activation
                 const int items = (a.debug & 4) ? 0 : nb * rw, Kp = a.kpad[l];
@@ -411,17 +455,17 @@ __global__ __launch_bounds__(kThreads) void scanline_persistent_kernel(const Sca
                         const int k0 = g * kg + j * kKB, len = (kg - j * kKB) < kKB ? (kg - j * kKB) : kKB;
                         part[u] = block_dot(wl + r * Kp + g * (kg + kBlockPad * bpg) + j * (kKB + kBlockPad), xs + bi * K + k0, len, a.vec4);
                     }
-                    __syncthreads();
+                    lds_barrier();
                     for (int it = tid; it < n_it; it += kThreads) {
                         const int item = i0 + it, bi = item / rw, r = item - bi * rw;
                         float v = 0.f;
                         for (int blk = 0; blk < nblk; ++blk) v += part[blk * n_it + it];
-                        v += a.bias[l] ? a.bias[l][r_first + r] : 0.f;
+                        v += bias_l[l][r];
                         if (a.act_after[l]) v = v > 0.f ? v : 0.01f * v;   // LeakyReLU(0.01)
                         if (l < last) st_gran(a.act[l] + static_cast<int64_t>(b0 + bi) * a.rows[l] + r_first + r, v, tag);
                         else ps[bi * a.rpw[l] + r] = v;
                     }
-                    __syncthreads();   // `part` is reused by the next round; ps is complete for the Gaussian step
+                    lds_barrier();   // `part` is reused by the next round; ps is complete for the Gaussian step
                 }
                 if (l == last) {
                     // ---- Gaussian step on this workgroup's (mean, scale) pairs: rows 2c, 2c + 1 ("split_interleave")
@@ -431,14 +475,14 @@ __global__ __launch_bounds__(kThreads) void scanline_persistent_kernel(const Sca
                         const int64_t b = b0 + bi;
                         const int c = c_first + j;
                         const float mu = ps[bi * a.rpw[l] + 2 * j], sg = ps[bi * a.rpw[l] + 2 * j + 1];
-                        const int row = nearest_scale(sg, tab, a.table_len);
+                        const int row = nearest_scale(sg, tab, a.table_len, tab_sorted);
                         if (DECODE) {
                             st_gran(a.idx_step + b * a.C + c, static_cast<uint32_t>(row), tag);
                             st_gran(a.mu + b * a.C + c, mu, tag);
                         } else {
                             const int64_t e = (b * a.C + c) * HW + p;
                             const int64_t o = b * a.C * HW + static_cast<int64_t>(p) * a.C + c;
-                            const float q = rintf(a.y[e] - mu);          // torch.round: half to even
+                            const float q = rintf((it == tid ? y_pre : a.y[e]) - mu);          // torch.round: half to even
                             st_gran(a.yT + (b * HW + p) * a.C + c, q + mu, tag);   // first: every workgroup's next step waits for it
                             a.idx[o] = row;
                             a.sym[o] = static_cast<int32_t>(q);
@@ -446,7 +490,11 @@ __global__ __launch_bounds__(kThreads) void scanline_persistent_kernel(const Sca
                         }
                     }
                 }
-                __syncthreads();   // xs / ps are reused by the next chunk
+                lds_barrier();   // xs / ps are reused by the next chunk
+                if (a.prof && wg == 0 && tid == 0) {
+                    a.prof[2 * l] += t1 - t0;
+                    a.prof[2 * l + 1] += wall_clock64() - t1;
+                }
             }
         }
     }
@@ -714,20 +762,27 @@ int fill_args(basic_scanline_plan *p, ScanArgs &a, int batch, int h, int w, cons
     a.part_floats = 1024;
     for (int l = 0; l < p->nlayers; ++l)
         BASIC_REQUIRE((p->kdim[l] / p->kgroup[l]) * p->bpg[l] <= a.part_floats, "scanline: too many summation blocks in a layer");
-    auto need = [&](int n) { return a.ps_off + static_cast<int>(align4(n * rpw_last)) + static_cast<int>(align4(n * kmax)) + a.part_floats + 4; };
+    int bias_need = 0;
+    for (int l = 0; l < p->nlayers; ++l) bias_need += p->rpw[l];
+    auto need = [&](int n) { return a.ps_off + static_cast<int>(align4(n * rpw_last)) + static_cast<int>(align4(n * kmax)) + a.part_floats + 4 + static_cast<int>(align4(bias_need)); };
     while (bc > 1 && need(bc) > total_floats) --bc;
     BASIC_REQUIRE(need(bc) <= total_floats, "scanline: layer inputs do not fit the LDS");
     a.bc = bc;
     a.xs_off = a.ps_off + static_cast<int>(align4(bc * rpw_last));
     a.part_off = a.xs_off + static_cast<int>(align4(bc * kmax));
     a.flag_off = a.part_off + a.part_floats;
-    *lds_bytes = static_cast<size_t>(a.flag_off + 4) * sizeof(float);
+    a.bias_off = a.flag_off + 4;
+    int bias_floats = 0;
+    for (int l = 0; l < p->nlayers; ++l) bias_floats += p->rpw[l];
+    *lds_bytes = static_cast<size_t>(a.bias_off + static_cast<int>(align4(bias_floats))) * sizeof(float);
     a.bar = p->d_bar;
     a.err = reinterpret_cast<int *>(p->d_bar + 1);
     { const char *e = getenv("BASIC_SCAN_DEBUG"); a.debug = e ? atoi(e) : 0; }
     BASIC_HIP_TRY(hipMemsetAsync(p->d_bar, 0, 2 * sizeof(unsigned), st));
     return BASIC_OK;
 }
+
+inline long long h_w_steps(int h, int w) { return static_cast<long long>(h) * w; }
 
 int device_cus(int *cus)
 {
@@ -760,7 +815,24 @@ extern "C" int basic_scanline_encode_dev(basic_scanline_plan *p, const float *d_
     // more than half of a compute unit's LDS per workgroup: exactly one workgroup per unit, as the barrier protocol assumes
     if (lds_bytes < 96 * 1024) lds_bytes = 96 * 1024;
     BASIC_HIP_TRY(ensure_max_lds(reinterpret_cast<const void *>(scanline_persistent_kernel<false>)));
-    return chained_launch(p, st, p->nwg, cus, [&] { hipLaunchKernelGGL(scanline_persistent_kernel<false>, dim3(p->nwg), dim3(kThreads), lds_bytes, st, a); });
+    long long *d_prof = nullptr;
+    if (getenv("BASIC_SCAN_PROFILE")) {   // debugging aid: where does workgroup 0 spend a coding step?
+        BASIC_HIP_TRY(hipMalloc(&d_prof, 2 * kMaxLayers * sizeof(long long)));
+        BASIC_HIP_TRY(hipMemsetAsync(d_prof, 0, 2 * kMaxLayers * sizeof(long long), st));
+        a.prof = d_prof;
+    }
+    rc = chained_launch(p, st, p->nwg, cus, [&] { hipLaunchKernelGGL(scanline_persistent_kernel<false>, dim3(p->nwg), dim3(kThreads), lds_bytes, st, a); });
+    if (d_prof) {
+        long long h[2 * kMaxLayers];
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpy(h, d_prof, sizeof(h), hipMemcpyDeviceToHost);
+        (void)hipFree(d_prof);
+        const double steps = static_cast<double>(h_w_steps(a.H, a.W));
+        fprintf(stderr, "scan-line profile (workgroup 0, 100 MHz wall clock ticks per step): ");
+        for (int l = 0; l < p->nlayers; ++l) fprintf(stderr, "layer %d stage+wait %.1f compute %.1f | ", l, h[2 * l] / steps, h[2 * l + 1] / steps);
+        fprintf(stderr, "\n");
+    }
+    return rc;
 }
 
 extern "C" int basic_scanline_decode_dev(basic_scanline_plan *p, const basic_rans_tables *tables, const uint32_t *d_words,
