@@ -41,6 +41,7 @@
 #include <mutex>
 
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 using namespace basic;
@@ -72,7 +73,8 @@ struct ScanArgs {
     unsigned *bar;
     int *err;
     int debug;   // BASIC_SCAN_DEBUG timing ablations (wrong results): 2 no input staging, 4 no dot products
-    long long *prof;   // BASIC_SCAN_PROFILE=1: [layer][2] cycles of workgroup 0 spent staging (incl. waiting) / computing, summed over the steps
+    long long *prof;   // BASIC_SCAN_PROFILE=1: [layer][4] 100 MHz ticks of workgroup 0 spent staging (incl. waiting) / in the block dots / finishing / in the
+                       // Gaussian step, summed over the steps; [4 * kMaxLayers .. +1] = shader clocks and ticks of the whole loop
     // decoder only
     int ncompute;          // workgroups [0, ncompute) compute, the rest decode (4 image streams each)
     uint64_t *mu;          // [B][C] means of the current step (compute -> decoder workgroups), granules
@@ -246,7 +248,21 @@ __device__ __forceinline__ float block_dot(const float *wr, const float *xr, int
 }
 
 // ---- in-place rANS decoder of ONE stream held by one wavefront (decode_stream semantics, csrc/ans/rans64.cpp:501-598;
-//      the same search image and the same arithmetic as rans_decode_fast_kernel, without its chunk unrolling)
+//      the search image, the arithmetic and the chunk schedule of rans_decode_fast_kernel in rans.hip: a lone wave is bound by
+//      its instruction count, so a symbol's 16-byte image entry -- which depends on its table row only, not on the coder
+//      state -- is read from LDS two symbols ahead, every lane advances the state for ITS candidate symbol, and one
+//      compare + ballot picks the lane that is right; renormalisation, the bypass sentinel and wide rows (image frequency 0)
+//      all hide behind the single test "new state < 2^31")
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+template <int kBegin, int kEnd, class F> __device__ __forceinline__ void static_pairs(F &&f)
+{
+    if constexpr (kBegin < kEnd) {
+        f(std::integral_constant<int, kBegin>{});
+        static_pairs<kBegin + 2, kEnd>(f);
+    }
+}
+
 struct WaveDecoder {
     const uint32_t *img;     // LDS
     const uint32_t *words;
@@ -256,6 +272,10 @@ struct WaveDecoder {
     uint32_t prec, mask, bprec, maxbv;
     bool bypass;
     __device__ __forceinline__ uint32_t bc32(uint32_t v, int l) const { return __builtin_amdgcn_readlane(v, l); }
+    __device__ __forceinline__ uint64_t bc64(uint64_t v, int l) const
+    {
+        return static_cast<uint64_t>(bc32(static_cast<uint32_t>(v), l)) | (static_cast<uint64_t>(bc32(static_cast<uint32_t>(v >> 32), l)) << 32);
+    }
     __device__ __forceinline__ void init(const RansFastView &tv, const uint32_t *image_lds, const uint32_t *w, int nwords, int lane)
     {
         img = image_lds; words = w; limit = nwords;
@@ -282,50 +302,92 @@ struct WaveDecoder {
         if (x < kRansLow) x = (x << 32) | next_word(lane);
         return v;
     }
-    // one symbol of table row `row` (wave-uniform); returns value - offset[row] is added by the caller
-    __device__ __forceinline__ int32_t decode(uint32_t meta, int32_t size, int lane)
+    // the rare path of a symbol whose candidate state came out below 2^31: renormalisation, bypass sentinel, wide row.
+    // `first` = narrow-row symbol + 1 found by the ballot; returns the symbol + 1
+    __device__ __forceinline__ int32_t slow_path(const u32x4 &e, int32_t first, uint32_t meta, int32_t size, uint32_t cf, uint64_t t, int lane)
     {
-        const uint32_t cf = static_cast<uint32_t>(x) & mask;
-        const uint64_t t = x >> prec;
-        const uint32_t *e = img + (meta >> 2) + lane * 4;   // {key, start, freq, pad} of this lane
-        const uint32_t key = e[0], st = e[1], fq = e[2];
-        const uint64_t cand = static_cast<uint64_t>(fq) * t + static_cast<uint64_t>(cf - st);
-        const int first = __builtin_ctzll(__ballot(key > cf));   // symbol + 1 (lane 0 of a wide row always wins: freq 0)
-        x = static_cast<uint64_t>(bc32(static_cast<uint32_t>(cand), first)) | (static_cast<uint64_t>(bc32(static_cast<uint32_t>(cand >> 32), first)) << 32);
+        const uint32_t base = meta >> 2;
         int32_t sym = first - 1;
-        if (x < kRansLow) {
-            const uint32_t base = meta >> 2;
-            if (size > 64) {   // wide row: 64 block-end probes after the dummy lane, then the row; two-level search
-                const uint32_t pr = img[base + 4 + lane];
-                const int blk = __builtin_ctzll(__ballot(pr > cf));
-                const int32_t step = (size + 63) >> 6;
-                const int32_t lo = blk * step;
-                const int32_t span = (lo + step <= size) ? step : (size - lo);
-                const uint32_t va = (lane < span) ? img[base + 68 + lo + lane] : 0x7FFFFFFFu;
-                const int tl = __builtin_ctzll(__ballot(va > cf));
-                const uint32_t c_t = bc32(va, tl);
-                const uint32_t c_s = tl > 0 ? bc32(va, tl - 1) : bc32(pr, blk - 1);   // blk, tl == 0 together never happens: cdf[0] = 0 <= cf
-                sym = lo + tl - 1;
-                x = static_cast<uint64_t>(c_t - c_s) * t + (cf - c_s);
-            } else if (bypass && sym == size - 2) {   // the sentinel's image frequency is 0: redo its update with the true one
-                const uint32_t c_t = bc32(key, first), c_s = bc32(st, first);
-                x = static_cast<uint64_t>(c_t - c_s) * t + (cf - c_s);
-            }
-            if (x < kRansLow) x = (x << 32) | next_word(lane);
-            if (bypass && sym == size - 2) {   // bypass value: count nibbles, then the payload low-first (rans64.cpp:466-487)
-                uint32_t v = get_bits(bprec, lane);
-                uint32_t nb = v;
-                while (v == maxbv) { v = get_bits(bprec, lane); nb += v; }
-                uint32_t raw = 0;
-                for (uint32_t k = 0; k < nb; ++k) {
-                    const uint32_t nib = get_bits(bprec, lane);
-                    if (k * bprec < 32u) raw |= nib << (k * bprec);
-                }
-                sym = static_cast<int32_t>(raw >> 1);
-                if (raw & 1u) sym = -sym - 1; else sym += size - 2;
-            }
+        if (size > 64) {   // wide row: 64 block-end probes after the dummy lane, then the row; two-level search
+            const uint32_t pr = img[base + 4 + lane];
+            const int blk = __builtin_ctzll(__ballot(pr > cf));
+            const int32_t step = (size + 63) >> 6;
+            const int32_t lo = blk * step;
+            const int32_t span = (lo + step <= size) ? step : (size - lo);
+            const uint32_t va = (lane < span) ? img[base + 68 + lo + lane] : 0x7FFFFFFFu;
+            const int tl = __builtin_ctzll(__ballot(va > cf));
+            const uint32_t c_t = bc32(va, tl);
+            const uint32_t c_s = tl > 0 ? bc32(va, tl - 1) : bc32(pr, blk - 1);   // blk, tl == 0 together never happens: cdf[0] = 0 <= cf
+            sym = lo + tl - 1;
+            x = static_cast<uint64_t>(c_t - c_s) * t + (cf - c_s);
+        } else if (bypass && sym == size - 2) {   // the sentinel's image frequency is 0: redo its update with the true one
+            const uint32_t c_t = bc32(e[0], first), c_s = bc32(e[1], first);
+            x = static_cast<uint64_t>(c_t - c_s) * t + (cf - c_s);
         }
-        return sym;
+        if (x < kRansLow) x = (x << 32) | next_word(lane);
+        if (bypass && sym == size - 2) {   // bypass value: count nibbles, then the payload low-first (rans64.cpp:466-487)
+            uint32_t v = get_bits(bprec, lane);
+            uint32_t nb = v;
+            while (v == maxbv) { v = get_bits(bprec, lane); nb += v; }
+            uint32_t raw = 0;
+            for (uint32_t k = 0; k < nb; ++k) {
+                const uint32_t nib = get_bits(bprec, lane);
+                if (k * bprec < 32u) raw |= nib << (k * bprec);
+            }
+            sym = static_cast<int32_t>(raw >> 1);
+            if (raw & 1u) sym = -sym - 1; else sym += size - 2;
+        }
+        return sym + 1;
+    }
+    // `cnt` symbols (1..64); lane j holds symbol j's image offset (meta, bytes) and row size.  Returns symbol j + 1 on lane j.
+    __device__ __forceinline__ int32_t decode_chunk(uint32_t meta_l, int32_t size_l, int cnt, int lane)
+    {
+        int32_t result = 1;
+        auto fetch = [&](int jj, u32x4 &e) {
+            const uint32_t m = bc32(meta_l, jj);
+            e = *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(img) + m + lane * 16);
+        };
+        auto decode_one = [&](auto jc, const u32x4 &e) {   // jc: int, or std::integral_constant (lane ids become immediates)
+            const int j = jc;
+            int32_t &res = result;
+            const uint32_t cf = static_cast<uint32_t>(x) & mask;
+            const uint64_t t = x >> prec;
+            // x = freq * (x >> prec) + (cf - start)   (rans64.h:128-142), per lane for its own candidate
+            const uint64_t addend = static_cast<uint64_t>(cf - e[1]) |
+                                    (static_cast<uint64_t>(__umul24(e[2], static_cast<uint32_t>(t >> 32))) << 32);   // freq <= 2^16, t_hi < 2^15
+            uint64_t cand;
+            asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(cand) : "v"(e[2]), "s"(static_cast<uint32_t>(t)), "v"(addend) : "vcc");
+            int32_t first = __builtin_ctzll(__ballot(e[0] > cf));   // symbol + 1
+            x = bc64(cand, first);
+            if (__builtin_expect(x < kRansLow, 0))
+                first = slow_path(e, first, bc32(meta_l, j), static_cast<int32_t>(bc32(static_cast<uint32_t>(size_l), j)), cf, t, lane);
+            if constexpr (std::is_integral<decltype(jc)>::value)
+                asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(res) : "s"(first), "s"(j) : "m0");
+            else
+                asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(res) : "s"(first), "n"(decltype(jc)::value));
+        };
+        u32x4 ea, eb;
+        fetch(0, ea);
+        fetch(cnt > 1 ? 1 : 0, eb);
+        if (cnt == 64) {   // a full chunk, fully unrolled: every lane id is an immediate
+            static_pairs<0, 64>([&](auto jc) {
+                constexpr int J = decltype(jc)::value;
+                decode_one(std::integral_constant<int, J>{}, ea);
+                if constexpr (J + 2 < 64) fetch(J + 2, ea);
+                decode_one(std::integral_constant<int, J + 1>{}, eb);
+                if constexpr (J + 3 < 64) fetch(J + 3, eb);
+            });
+            return result;
+        }
+        int j = 0;
+        for (; j + 1 < cnt; j += 2) {
+            decode_one(j, ea);
+            fetch(j + 2 < cnt ? j + 2 : cnt - 1, ea);
+            decode_one(j + 1, eb);
+            fetch(j + 3 < cnt ? j + 3 : cnt - 1, eb);
+        }
+        if (j < cnt) decode_one(j, ea);
+        return result;
     }
 };
 
@@ -342,40 +404,41 @@ __global__ __launch_bounds__(kThreads) void scanline_persistent_kernel(const Sca
         // ================= decoder workgroups: one wavefront per image stream, the search image in LDS =================
         uint32_t *img = reinterpret_cast<uint32_t *>(lds);
         for (int e = tid; e < a.tv.image_words; e += kThreads) img[e] = a.tv.image[e];
+        // per table row {image offset, size, symbol offset}: three dependent global loads per chunk on the step's critical path otherwise
+        u32x4 *rowtab = reinterpret_cast<u32x4 *>(img + ((a.tv.image_words + 3) & ~3));
+        for (int r = tid; r < a.tv.rows; r += kThreads)
+            rowtab[r] = u32x4{a.tv.meta[r], static_cast<uint32_t>(a.tv.sizes[r]), static_cast<uint32_t>(a.tv.offsets[r]), 0u};
         __syncthreads();
         const int b = (wg - a.ncompute) * (kThreads / 64) + wave;
         if (b >= a.B) return;
+        __builtin_amdgcn_s_setprio(3);   // a serial chain: never lose the issue arbitration to the waves spinning beside it
         WaveDecoder d;
         {
             const int64_t w0 = a.word_off[b];
             d.init(a.tv, img, a.words + w0, static_cast<int>(a.word_off[b + 1] - w0), lane);
         }
+        const uint64_t *pi0 = a.idx_step + static_cast<int64_t>(b) * a.C, *pm0 = a.mu + static_cast<int64_t>(b) * a.C;
         for (int p = 0; p < HW; ++p) {
             const uint32_t tag = static_cast<uint32_t>(p + 1);
+            // this step's (table row, mean) granules come from the compute workgroups that own the channels; the next chunk's
+            // are requested before the current chunk is decoded
+            uint64_t gi = 0ull, gm = 0ull;
+            if (lane < a.C) { gi = ld_gran(pi0 + lane); gm = ld_gran(pm0 + lane); }
             for (int c0 = 0; c0 < a.C; c0 += 64) {
                 const int c = c0 + lane;
-                int32_t row = 0;
-                float mu = 0.f;
                 bool ok = true;
-                if (c < a.C) {   // this step's (table row, mean) of channel c: granules from the compute workgroup that owns it
-                    const uint64_t *pi = a.idx_step + static_cast<int64_t>(b) * a.C + c, *pm = a.mu + static_cast<int64_t>(b) * a.C + c;
-                    uint64_t gi = ld_gran(pi), gm = ld_gran(pm);
-                    ok = wait_gran(a, pi, tag, gi) && wait_gran(a, pm, tag, gm);
-                    row = static_cast<int32_t>(static_cast<uint32_t>(gi));
-                    mu = __uint_as_float(static_cast<uint32_t>(gm));
-                }
+                if (c < a.C) ok = wait_gran(a, pi0 + c, tag, gi) && wait_gran(a, pm0 + c, tag, gm);
                 if (__ballot(!ok) != 0ull) return;   // poisoned launch: wave-uniform exit
+                int32_t row = static_cast<int32_t>(static_cast<uint32_t>(gi));
+                const float mu = __uint_as_float(static_cast<uint32_t>(gm));
+                gi = 0ull; gm = 0ull;
+                if (c + 64 < a.C) { gi = ld_gran(pi0 + c + 64); gm = ld_gran(pm0 + c + 64); }
                 row = row < 0 ? 0 : (row >= a.tv.rows ? a.tv.rows - 1 : row);
-                const uint32_t meta_l = a.tv.meta[row];
-                const int32_t size_l = a.tv.sizes[row], off_l = a.tv.offsets[row];
+                const u32x4 rt = rowtab[row];
                 const int cnt = (a.C - c0) < 64 ? (a.C - c0) : 64;
-                int32_t mine = 0;
-                for (int j = 0; j < cnt; ++j) {
-                    const int32_t s = d.decode(__builtin_amdgcn_readlane(meta_l, j), __builtin_amdgcn_readlane(size_l, j), lane);
-                    if (lane == j) mine = s;
-                }
+                const int32_t mine = d.decode_chunk(rt[0], static_cast<int32_t>(rt[1]), cnt, lane) - 1;
                 if (c < a.C) {
-                    const int32_t value = mine + off_l;
+                    const int32_t value = mine + static_cast<int32_t>(rt[2]);
                     const float v = static_cast<float>(value) + mu;           // pgm_coder.py:973-978
                     st_gran(a.yT + (static_cast<int64_t>(b) * HW + p) * a.C + c, v, tag);   // first: the compute workgroups wait for it
                     a.sym[static_cast<int64_t>(b) * a.C * HW + static_cast<int64_t>(p) * a.C + c] = value;
@@ -418,6 +481,7 @@ __global__ __launch_bounds__(kThreads) void scanline_persistent_kernel(const Sca
         if (!(tab[e] < tab[e + 1])) s_flag[1] = 0;   // not strictly increasing: nearest_scale scans
     __syncthreads();
     const bool tab_sorted = s_flag[1] != 0;
+    const long long loop_c0 = a.prof ? clock64() : 0, loop_t0 = a.prof ? wall_clock64() : 0;
     for (int p = 0; p < HW; ++p) {
         const int py = p / a.W, px = p - py * a.W;
         const uint32_t tag = static_cast<uint32_t>(p + 1);
@@ -441,6 +505,7 @@ __global__ __launch_bounds__(kThreads) void scanline_persistent_kernel(const Sca
                 __syncthreads();
                 if (*s_flag) return;     // poisoned launch: the whole workgroup leaves
                 const long long t1 = a.prof ? wall_clock64() : 0;
+                long long t2 = t1, t3 = t1;
                 // units = (canonical block, image, row), one FMA chain each; `part` holds one round of partials as
                 // [block][item]; the finishing threads add an item's partials in block order, then bias and activation
                 const int items = (a.debug & 4) ? 0 : nb * rw, Kp = a.kpad[l];
@@ -456,6 +521,7 @@ __global__ __launch_bounds__(kThreads) void scanline_persistent_kernel(const Sca
                         part[u] = block_dot(wl + r * Kp + g * (kg + kBlockPad * bpg) + j * (kKB + kBlockPad), xs + bi * K + k0, len, a.vec4);
                     }
                     lds_barrier();
+                    if (a.prof && wg == 0 && tid == 0) t2 = wall_clock64();
                     for (int it = tid; it < n_it; it += kThreads) {
                         const int item = i0 + it, bi = item / rw, r = item - bi * rw;
                         float v = 0.f;
@@ -466,6 +532,7 @@ __global__ __launch_bounds__(kThreads) void scanline_persistent_kernel(const Sca
                         else ps[bi * a.rpw[l] + r] = v;
                     }
                     lds_barrier();   // `part` is reused by the next round; ps is complete for the Gaussian step
+                    if (a.prof && wg == 0 && tid == 0) t3 = wall_clock64();
                 }
                 if (l == last) {
                     // ---- Gaussian step on this workgroup's (mean, scale) pairs: rows 2c, 2c + 1 ("split_interleave")
@@ -492,11 +559,17 @@ __global__ __launch_bounds__(kThreads) void scanline_persistent_kernel(const Sca
                 }
                 lds_barrier();   // xs / ps are reused by the next chunk
                 if (a.prof && wg == 0 && tid == 0) {
-                    a.prof[2 * l] += t1 - t0;
-                    a.prof[2 * l + 1] += wall_clock64() - t1;
+                    a.prof[4 * l] += t1 - t0;
+                    a.prof[4 * l + 1] += t2 - t1;
+                    a.prof[4 * l + 2] += t3 - t2;
+                    a.prof[4 * l + 3] += wall_clock64() - t3;
                 }
             }
         }
+    }
+    if (a.prof && wg == 0 && tid == 0) {
+        a.prof[4 * kMaxLayers] = clock64() - loop_c0;
+        a.prof[4 * kMaxLayers + 1] = wall_clock64() - loop_t0;
     }
 }
 
@@ -782,7 +855,34 @@ int fill_args(basic_scanline_plan *p, ScanArgs &a, int batch, int h, int w, cons
     return BASIC_OK;
 }
 
-inline long long h_w_steps(int h, int w) { return static_cast<long long>(h) * w; }
+// BASIC_SCAN_PROFILE=1 (debugging aid): where does workgroup 0 spend a coding step?  Synchronises the stream.
+struct ScanProfile {
+    static constexpr int kSlots = 4 * kMaxLayers + 2;
+    long long *d = nullptr;
+    int begin(ScanArgs &a, hipStream_t st)
+    {
+        if (!getenv("BASIC_SCAN_PROFILE")) return BASIC_OK;
+        BASIC_HIP_TRY(hipMalloc(&d, kSlots * sizeof(long long)));
+        BASIC_HIP_TRY(hipMemsetAsync(d, 0, kSlots * sizeof(long long), st));
+        a.prof = d;
+        return BASIC_OK;
+    }
+    void report(const ScanArgs &a, hipStream_t st, const char *what)
+    {
+        if (!d) return;
+        long long h[kSlots];
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+        (void)hipFree(d);
+        d = nullptr;
+        const double steps = static_cast<double>(a.H) * a.W;
+        fprintf(stderr, "scan-line %s profile (workgroup 0; 10 ns ticks per coding step: stage+wait / dots / finish / gauss): ", what);
+        for (int l = 0; l < a.nlayers; ++l)
+            fprintf(stderr, "L%d %.1f / %.1f / %.1f / %.1f | ", l, h[4 * l] / steps, h[4 * l + 1] / steps, h[4 * l + 2] / steps, h[4 * l + 3] / steps);
+        fprintf(stderr, "loop %.1f ticks per step, %.2f shader clocks per tick\n", h[4 * kMaxLayers + 1] / steps,
+                h[4 * kMaxLayers + 1] ? static_cast<double>(h[4 * kMaxLayers]) / h[4 * kMaxLayers + 1] : 0.0);
+    }
+};
 
 int device_cus(int *cus)
 {
@@ -815,23 +915,11 @@ extern "C" int basic_scanline_encode_dev(basic_scanline_plan *p, const float *d_
     // more than half of a compute unit's LDS per workgroup: exactly one workgroup per unit, as the barrier protocol assumes
     if (lds_bytes < 96 * 1024) lds_bytes = 96 * 1024;
     BASIC_HIP_TRY(ensure_max_lds(reinterpret_cast<const void *>(scanline_persistent_kernel<false>)));
-    long long *d_prof = nullptr;
-    if (getenv("BASIC_SCAN_PROFILE")) {   // debugging aid: where does workgroup 0 spend a coding step?
-        BASIC_HIP_TRY(hipMalloc(&d_prof, 2 * kMaxLayers * sizeof(long long)));
-        BASIC_HIP_TRY(hipMemsetAsync(d_prof, 0, 2 * kMaxLayers * sizeof(long long), st));
-        a.prof = d_prof;
-    }
+    ScanProfile prof;
+    rc = prof.begin(a, st);
+    if (rc) return rc;
     rc = chained_launch(p, st, p->nwg, cus, [&] { hipLaunchKernelGGL(scanline_persistent_kernel<false>, dim3(p->nwg), dim3(kThreads), lds_bytes, st, a); });
-    if (d_prof) {
-        long long h[2 * kMaxLayers];
-        (void)hipStreamSynchronize(st);
-        (void)hipMemcpy(h, d_prof, sizeof(h), hipMemcpyDeviceToHost);
-        (void)hipFree(d_prof);
-        const double steps = static_cast<double>(h_w_steps(a.H, a.W));
-        fprintf(stderr, "scan-line profile (workgroup 0, 100 MHz wall clock ticks per step): ");
-        for (int l = 0; l < p->nlayers; ++l) fprintf(stderr, "layer %d stage+wait %.1f compute %.1f | ", l, h[2 * l] / steps, h[2 * l + 1] / steps);
-        fprintf(stderr, "\n");
-    }
+    prof.report(a, st, "encode");
     return rc;
 }
 
@@ -856,12 +944,17 @@ extern "C" int basic_scanline_decode_dev(basic_scanline_plan *p, const basic_ran
     rc = device_cus(&cus);
     if (rc) return rc;
     BASIC_REQUIRE(p->nwg + ndec <= cus, "scanline_decode: more workgroups than compute units (the grid must be resident)");
-    const size_t dec_lds = (static_cast<size_t>((a.tv.image_words + 3) & ~3) + 4) * sizeof(uint32_t);
+    const size_t dec_lds = (static_cast<size_t>((a.tv.image_words + 3) & ~3) + 4 * static_cast<size_t>(a.tv.rows) + 4) * sizeof(uint32_t);
     if (dec_lds > lds_bytes) lds_bytes = dec_lds;
     if (lds_bytes < 96 * 1024) lds_bytes = 96 * 1024;
     BASIC_REQUIRE(lds_bytes <= 160 * 1024, "scanline_decode: the search image does not fit the LDS");
     BASIC_HIP_TRY(ensure_max_lds(reinterpret_cast<const void *>(scanline_persistent_kernel<true>)));
-    return chained_launch(p, st, p->nwg + ndec, cus, [&] { hipLaunchKernelGGL(scanline_persistent_kernel<true>, dim3(p->nwg + ndec), dim3(kThreads), lds_bytes, st, a); });
+    ScanProfile prof;
+    rc = prof.begin(a, st);
+    if (rc) return rc;
+    rc = chained_launch(p, st, p->nwg + ndec, cus, [&] { hipLaunchKernelGGL(scanline_persistent_kernel<true>, dim3(p->nwg + ndec), dim3(kThreads), lds_bytes, st, a); });
+    prof.report(a, st, "decode");
+    return rc;
 }
 
 // Whether basic_scanline_decode_dev can serve `batch` streams of this table set on the current device (the set has a fast
@@ -877,7 +970,7 @@ extern "C" int basic_scanline_can_decode(const basic_scanline_plan *p, const bas
     int rc = device_cus(&cus);
     if (rc) return rc;
     const int ndec = (batch + kThreads / 64 - 1) / (kThreads / 64);
-    const size_t dec_lds = (static_cast<size_t>((tv.image_words + 3) & ~3) + 4) * sizeof(uint32_t);
+    const size_t dec_lds = (static_cast<size_t>((tv.image_words + 3) & ~3) + 4 * static_cast<size_t>(tv.rows) + 4) * sizeof(uint32_t);
     *ok = p->nwg + ndec <= cus && dec_lds <= 160 * 1024;
     return BASIC_OK;
 }
