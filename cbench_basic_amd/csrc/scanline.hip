@@ -41,6 +41,7 @@
 #include <mutex>
 
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 #include <vector>
 
@@ -70,6 +71,7 @@ struct ScanArgs {
     uint64_t *act[kMaxLayers];   // exchange buffers [B][rows_l] of granules (tag = coding step + 1)
     int tap_off[kMaxTaps], tap_dy[kMaxTaps], tap_dx[kMaxTaps];
     int bc, xs_off, ps_off, tab_off, part_off, part_floats, flag_off, bias_off;   // LDS float offsets (the whole LDS is dynamic)
+    int x0_off, early_off, desc_off;   // pipelined kernel only: context window [B][K0], early sums, unit descriptors
     unsigned *bar;
     int *err;
     int debug;   // BASIC_SCAN_DEBUG timing ablations (wrong results): 2 no input staging, 4 no dot products
@@ -391,6 +393,59 @@ struct WaveDecoder {
     }
 };
 
+// ================= decoder workgroups: one wavefront per image stream, the search image in LDS =================
+__device__ __forceinline__ void decoder_workgroup(const ScanArgs &a, float *lds)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wg = blockIdx.x;
+    const int HW = a.H * a.W;
+    uint32_t *img = reinterpret_cast<uint32_t *>(lds);
+    for (int e = tid; e < a.tv.image_words; e += kThreads) img[e] = a.tv.image[e];
+    // per table row {image offset, size, symbol offset}: three dependent global loads per chunk on the step's critical path otherwise
+    u32x4 *rowtab = reinterpret_cast<u32x4 *>(img + ((a.tv.image_words + 3) & ~3));
+    for (int r = tid; r < a.tv.rows; r += kThreads)
+        rowtab[r] = u32x4{a.tv.meta[r], static_cast<uint32_t>(a.tv.sizes[r]), static_cast<uint32_t>(a.tv.offsets[r]), 0u};
+    __syncthreads();
+    const int b = (wg - a.ncompute) * (kThreads / 64) + wave;
+    if (b >= a.B) return;
+    __builtin_amdgcn_s_setprio(3);   // a serial chain: never lose the issue arbitration to the waves spinning beside it
+    WaveDecoder d;
+    {
+        const int64_t w0 = a.word_off[b];
+        d.init(a.tv, img, a.words + w0, static_cast<int>(a.word_off[b + 1] - w0), lane);
+    }
+    const uint64_t *pi0 = a.idx_step + static_cast<int64_t>(b) * a.C, *pm0 = a.mu + static_cast<int64_t>(b) * a.C;
+    for (int p = 0; p < HW; ++p) {
+        const uint32_t tag = static_cast<uint32_t>(p + 1);
+        // this step's (table row, mean) granules come from the compute workgroups that own the channels; the next chunk's
+        // are requested before the current chunk is decoded
+        uint64_t gi = 0ull, gm = 0ull;
+        if (lane < a.C) { gi = ld_gran(pi0 + lane); gm = ld_gran(pm0 + lane); }
+        for (int c0 = 0; c0 < a.C; c0 += 64) {
+            const int c = c0 + lane;
+            bool ok = true;
+            if (c < a.C) ok = wait_gran(a, pi0 + c, tag, gi) && wait_gran(a, pm0 + c, tag, gm);
+            if (__ballot(!ok) != 0ull) return;   // poisoned launch: wave-uniform exit
+            int32_t row = static_cast<int32_t>(static_cast<uint32_t>(gi));
+            const float mu = __uint_as_float(static_cast<uint32_t>(gm));
+            gi = 0ull; gm = 0ull;
+            if (c + 64 < a.C) { gi = ld_gran(pi0 + c + 64); gm = ld_gran(pm0 + c + 64); }
+            row = row < 0 ? 0 : (row >= a.tv.rows ? a.tv.rows - 1 : row);
+            const u32x4 rt = rowtab[row];
+            const int cnt = (a.C - c0) < 64 ? (a.C - c0) : 64;
+            const int32_t mine = d.decode_chunk(rt[0], static_cast<int32_t>(rt[1]), cnt, lane) - 1;
+            if (c < a.C) {
+                const int32_t value = mine + static_cast<int32_t>(rt[2]);
+                const float v = static_cast<float>(value) + mu;           // pgm_coder.py:973-978
+                st_gran(a.yT + (static_cast<int64_t>(b) * HW + p) * a.C + c, v, tag);   // first: the compute workgroups wait for it
+                a.sym[static_cast<int64_t>(b) * a.C * HW + static_cast<int64_t>(p) * a.C + c] = value;
+                a.idx[static_cast<int64_t>(b) * a.C * HW + static_cast<int64_t>(p) * a.C + c] = row;
+                a.ybuf[(static_cast<int64_t>(b) * a.C + c) * HW + p] = v;
+            }
+        }
+    }
+}
+
 template <bool DECODE>
 __global__ __launch_bounds__(kThreads) void scanline_persistent_kernel(const ScanArgs a)
 {
@@ -400,55 +455,7 @@ __global__ __launch_bounds__(kThreads) void scanline_persistent_kernel(const Sca
     const int HW = a.H * a.W;
     const int last = a.nlayers - 1;
 
-    if (DECODE && wg >= a.ncompute) {
-        // ================= decoder workgroups: one wavefront per image stream, the search image in LDS =================
-        uint32_t *img = reinterpret_cast<uint32_t *>(lds);
-        for (int e = tid; e < a.tv.image_words; e += kThreads) img[e] = a.tv.image[e];
-        // per table row {image offset, size, symbol offset}: three dependent global loads per chunk on the step's critical path otherwise
-        u32x4 *rowtab = reinterpret_cast<u32x4 *>(img + ((a.tv.image_words + 3) & ~3));
-        for (int r = tid; r < a.tv.rows; r += kThreads)
-            rowtab[r] = u32x4{a.tv.meta[r], static_cast<uint32_t>(a.tv.sizes[r]), static_cast<uint32_t>(a.tv.offsets[r]), 0u};
-        __syncthreads();
-        const int b = (wg - a.ncompute) * (kThreads / 64) + wave;
-        if (b >= a.B) return;
-        __builtin_amdgcn_s_setprio(3);   // a serial chain: never lose the issue arbitration to the waves spinning beside it
-        WaveDecoder d;
-        {
-            const int64_t w0 = a.word_off[b];
-            d.init(a.tv, img, a.words + w0, static_cast<int>(a.word_off[b + 1] - w0), lane);
-        }
-        const uint64_t *pi0 = a.idx_step + static_cast<int64_t>(b) * a.C, *pm0 = a.mu + static_cast<int64_t>(b) * a.C;
-        for (int p = 0; p < HW; ++p) {
-            const uint32_t tag = static_cast<uint32_t>(p + 1);
-            // this step's (table row, mean) granules come from the compute workgroups that own the channels; the next chunk's
-            // are requested before the current chunk is decoded
-            uint64_t gi = 0ull, gm = 0ull;
-            if (lane < a.C) { gi = ld_gran(pi0 + lane); gm = ld_gran(pm0 + lane); }
-            for (int c0 = 0; c0 < a.C; c0 += 64) {
-                const int c = c0 + lane;
-                bool ok = true;
-                if (c < a.C) ok = wait_gran(a, pi0 + c, tag, gi) && wait_gran(a, pm0 + c, tag, gm);
-                if (__ballot(!ok) != 0ull) return;   // poisoned launch: wave-uniform exit
-                int32_t row = static_cast<int32_t>(static_cast<uint32_t>(gi));
-                const float mu = __uint_as_float(static_cast<uint32_t>(gm));
-                gi = 0ull; gm = 0ull;
-                if (c + 64 < a.C) { gi = ld_gran(pi0 + c + 64); gm = ld_gran(pm0 + c + 64); }
-                row = row < 0 ? 0 : (row >= a.tv.rows ? a.tv.rows - 1 : row);
-                const u32x4 rt = rowtab[row];
-                const int cnt = (a.C - c0) < 64 ? (a.C - c0) : 64;
-                const int32_t mine = d.decode_chunk(rt[0], static_cast<int32_t>(rt[1]), cnt, lane) - 1;
-                if (c < a.C) {
-                    const int32_t value = mine + static_cast<int32_t>(rt[2]);
-                    const float v = static_cast<float>(value) + mu;           // pgm_coder.py:973-978
-                    st_gran(a.yT + (static_cast<int64_t>(b) * HW + p) * a.C + c, v, tag);   // first: the compute workgroups wait for it
-                    a.sym[static_cast<int64_t>(b) * a.C * HW + static_cast<int64_t>(p) * a.C + c] = value;
-                    a.idx[static_cast<int64_t>(b) * a.C * HW + static_cast<int64_t>(p) * a.C + c] = row;
-                    a.ybuf[(static_cast<int64_t>(b) * a.C + c) * HW + p] = v;
-                }
-            }
-        }
-        return;
-    }
+    if (DECODE && wg >= a.ncompute) { decoder_workgroup(a, lds); return; }
 
     // ================= compute workgroups: a fixed slice of every layer's rows, weights resident in LDS =================
     int rows_w[kMaxLayers];
@@ -564,6 +571,335 @@ __global__ __launch_bounds__(kThreads) void scanline_persistent_kernel(const Sca
                     a.prof[4 * l + 2] += t3 - t2;
                     a.prof[4 * l + 3] += wall_clock64() - t3;
                 }
+            }
+        }
+    }
+    if (a.prof && wg == 0 && tid == 0) {
+        a.prof[4 * kMaxLayers] = clock64() - loop_c0;
+        a.prof[4 * kMaxLayers + 1] = wall_clock64() - loop_t0;
+    }
+}
+
+// ================================================================================================================
+// Pipelined variant for the batches whose whole working set fits the LDS beside the weights (batch 1-2 of the BaSIC
+// coder: the reference harness's setting).  Same exchange protocol, same canonical sums, same results; what changes is
+// the length of the dependent chain of a coding step:
+//   * context layer split in two.  Of the ntaps causal taps only the LAST -- the left neighbour, position p - 1 -- is
+//     coded during the previous step; the other taps' blocks (the first (ntaps - 1) * blocks-per-tap of the canonical
+//     order) are summed one step AHEAD, right after this workgroup has published its context rows and while the next
+//     layer's inputs are still in flight.  On the critical path stay C granules, blocks-per-tap dot products per row
+//     and a short sum, instead of ntaps * C granules and the whole layer;
+//   * a (block, image, row) unit's addresses are computed once per launch (descriptor table in LDS), not with four
+//     integer divisions per unit and step -- a workgroup is four lone waves, each issuing one instruction per ~8-10
+//     clocks, so instruction count IS the latency;
+//   * a unit loads its whole block (16 + 16 16-byte LDS reads) before the FMA chain starts;
+//   * the last layer's finishing thread owns a (mean, scale) pair and runs the Gaussian step itself: no hand-over
+//     through LDS, two workgroup barriers per layer instead of three.
+// ================================================================================================================
+
+// all `len` channels of a block in flight, then the chain (len == kKB, vec4); the generic block_dot otherwise
+__device__ __forceinline__ float block_dot_preloaded(const float *wr, const float *xr, int len, int vec4)
+{
+    if (len == kKB && vec4) {
+        const f4 *x4 = reinterpret_cast<const f4 *>(xr), *w4 = reinterpret_cast<const f4 *>(wr);
+        f4 xv[kKB / 4], wv[kKB / 4];
+#pragma unroll
+        for (int i = 0; i < kKB / 4; ++i) { wv[i] = w4[i]; xv[i] = x4[i]; }
+        float p = 0.f;
+#pragma unroll
+        for (int i = 0; i < kKB / 4; ++i) {
+            p = fmaf(wv[i][0], xv[i][0], p); p = fmaf(wv[i][1], xv[i][1], p); p = fmaf(wv[i][2], xv[i][2], p); p = fmaf(wv[i][3], xv[i][3], p);
+        }
+        return p;
+    }
+    return block_dot(wr, xr, len, vec4);
+}
+
+// v + part[0] + part[stride] + ... (n terms, in that order); eight LDS reads in flight per round -- a finishing thread is
+// alone on its SIMD, a read-wait-add loop costs ~130 clocks per term
+__device__ __forceinline__ float sum_partials(float v, const float *part, int stride, int n)
+{
+    int blk = 0;
+    for (; blk + 8 <= n; blk += 8) {
+        float t[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t[i] = part[(blk + i) * stride];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v += t[i];
+    }
+    for (; blk + 2 <= n; blk += 2) {
+        const float t0 = part[blk * stride], t1 = part[(blk + 1) * stride];
+        v += t0; v += t1;
+    }
+    if (blk < n) v += part[blk * stride];
+    return v;
+}
+
+// U granules per thread in flight, then ONE polling loop over those still carrying an old tag.  get(e, src, want, dst):
+// element e of this batch -> granule address (nullptr: dst gets `plain`), expected tag, LDS destination.
+template <int U, class Get>
+__device__ __forceinline__ bool stage_granules(const ScanArgs &a, int total, Get &&get)
+{
+    const int tid = threadIdx.x;
+    bool ok = true;
+    for (int e0 = tid; e0 < total; e0 += kThreads * U) {
+        const uint64_t *src[U];
+        uint64_t g[U];
+        uint32_t want[U];
+        float *dst[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = e0 + u * kThreads;
+            src[u] = nullptr; g[u] = 0ull; want[u] = 0u; dst[u] = nullptr;
+            if (e < total) {
+                float plain = 0.f;
+                get(e, src[u], want[u], dst[u], plain);
+                if (src[u]) g[u] = ld_gran(src[u]);
+                else *dst[u] = plain;
+            }
+        }
+        unsigned spins = 0;
+        for (;;) {
+            bool all = true;
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (src[u] && static_cast<uint32_t>(g[u] >> 32) != want[u]) { g[u] = ld_gran(src[u]); all = false; }
+            if (all) break;
+            if (++spins > kSpinLimit || (spins % 1024u == 0u && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                __hip_atomic_store(a.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = false;
+                break;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (src[u]) *dst[u] = __uint_as_float(static_cast<uint32_t>(g[u]));
+    }
+    return ok;
+}
+
+template <bool DECODE>
+__global__ __launch_bounds__(kThreads) void scanline_pipelined_kernel(const ScanArgs a)
+{
+    extern __shared__ float lds[];
+    const int tid = threadIdx.x;
+    const int wg = blockIdx.x;
+    const int HW = a.H * a.W, B = a.B;
+    const int last = a.nlayers - 1;
+    if (DECODE && wg >= a.ncompute) { decoder_workgroup(a, lds); return; }
+
+    // ---- this workgroup's weight slices, scale table, biases (as in scanline_persistent_kernel)
+    int rows_w[kMaxLayers];
+    for (int l = 0; l < a.nlayers; ++l) {
+        int r = a.rows[l] - wg * a.rpw[l];
+        r = r < 0 ? 0 : (r > a.rpw[l] ? a.rpw[l] : r);
+        rows_w[l] = r;
+        const float *src = a.w[l] + static_cast<int64_t>(wg) * a.rpw[l] * a.kdim[l];
+        float *dst = lds + a.woff[l];
+        const int Kl = a.kdim[l], Kp = a.kpad[l];
+        for (int e = tid; e < r * Kl; e += kThreads) { const int rr = e / Kl; dst[rr * Kp + padded_k(e - rr * Kl, a.kgroup[l], a.bpg[l])] = src[e]; }
+    }
+    float *tab = lds + a.tab_off;
+    for (int e = tid; e < a.table_len; e += kThreads) tab[e] = a.table[e];
+    float *x0 = lds + a.x0_off, *xs = lds + a.xs_off, *part = lds + a.part_off, *early = lds + a.early_off;
+    uint2 *desc = reinterpret_cast<uint2 *>(lds + a.desc_off);
+    int *s_flag = reinterpret_cast<int *>(lds + a.flag_off);
+    int bias_at[kMaxLayers], dbase[kMaxLayers], units[kMaxLayers], nblk[kMaxLayers];
+    {
+        int off = a.bias_off, db = 0;
+        for (int l = 0; l < a.nlayers; ++l) {
+            bias_at[l] = off;
+            for (int e = tid; e < rows_w[l]; e += kThreads) lds[off + e] = a.bias[l] ? a.bias[l][wg * a.rpw[l] + e] : 0.f;
+            off += a.rpw[l];
+            // unit u = blk * n_it + it (it = image * rows + row): LDS float offsets of its weight block and input block, its length
+            const int rw = rows_w[l], n_it = B * rw, K = a.kdim[l], Kp = a.kpad[l], kg = a.kgroup[l], bpg = a.bpg[l];
+            nblk[l] = (K / kg) * bpg;
+            units[l] = n_it * nblk[l];
+            dbase[l] = db;
+            const int x_base = l == 0 ? a.x0_off : a.xs_off;
+            for (int u = tid; u < units[l]; u += kThreads) {
+                const int blk = u / n_it, it = u - blk * n_it, bi = it / rw, r = it - bi * rw;
+                const int g = blk / bpg, j = blk - g * bpg;
+                const int len = (kg - j * kKB) < kKB ? (kg - j * kKB) : kKB;
+                const int w_off = a.woff[l] + r * Kp + g * (kg + kBlockPad * bpg) + j * (kKB + kBlockPad);
+                const int x_off = x_base + bi * K + g * kg + j * kKB;
+                desc[db + u] = make_uint2(static_cast<uint32_t>(w_off) | (static_cast<uint32_t>(x_off) << 16), static_cast<uint32_t>(len));
+            }
+            db += units[l];
+        }
+    }
+    if (tid == 0) { s_flag[0] = 0; s_flag[1] = 1; }
+    __syncthreads();
+    for (int e = tid; e + 1 < a.table_len; e += kThreads)
+        if (!(tab[e] < tab[e + 1])) s_flag[1] = 0;   // not strictly increasing: nearest_scale scans
+    __syncthreads();
+    const bool tab_sorted = s_flag[1] != 0;
+
+    const int rw0 = rows_w[0], n_it0 = B * rw0, K0 = a.kdim[0], C = a.C;
+    const int early_blk = (a.ntaps - 1) * a.bpg[0];      // blocks of the taps coded at least two steps ago
+    const int early_units = early_blk * n_it0;
+    const int r_first0 = wg * a.rpw[0];
+
+    auto dots = [&](int l, int u0, int u1) {
+        for (int u = u0 + tid; u < u1; u += kThreads) {
+            const uint2 d = desc[dbase[l] + u];
+            part[u] = block_dot_preloaded(lds + (d.x & 0xFFFFu), lds + (d.x >> 16), static_cast<int>(d.y), a.vec4);
+        }
+    };
+    // context window of position q, taps [t0, t1) of every image -> x0 (zeros outside the image)
+    auto stage_window = [&](auto uc, int q, int t0, int t1) -> bool {
+        constexpr int U = decltype(uc)::value;
+        const int qy = q / a.W, qx = q - qy * a.W;
+        const int span = (t1 - t0) * C;
+        return stage_granules<U>(a, B * span, [&](int e, const uint64_t *&src, uint32_t &want, float *&dst, float &plain) {
+            const int bi = e / span, kk = e - bi * span;
+            const int t = t0 + kk / C, c = kk - (t - t0) * C;
+            const int ny = qy + a.tap_dy[t], nx = qx + a.tap_dx[t];
+            dst = x0 + bi * K0 + t * C + c;
+            if (ny >= 0 && nx >= 0 && nx < a.W) {
+                src = a.yT + ((static_cast<int64_t>(bi) * HW + q + a.tap_off[t]) * C + c);
+                want = static_cast<uint32_t>(q + a.tap_off[t] + 1);
+            }
+        });
+    };
+    // early half of the context layer for position q -- the sums over the first early_blk blocks, in block order from zero --
+    // in three pieces that need a workgroup barrier between them: the main loop runs one piece in the shadow of each of the
+    // following layers' exchanges (their barriers separate the pieces); with fewer layers than pieces the rest run back to back
+    float *part_e = lds + a.early_off + ((B * a.rpw[0] + 3) & ~3);   // the early blocks' partials: not shared with the dense layers
+    auto early_piece = [&](int piece, int q) -> bool {
+        if (piece == 0) {
+            if (a.ntaps > 1 && !stage_window(std::integral_constant<int, 12>{}, q, 0, a.ntaps - 1)) return false;
+        } else if (piece == 1) {
+            for (int u = tid; u < early_units; u += kThreads) {
+                const uint2 d = desc[dbase[0] + u];
+                part_e[u] = block_dot_preloaded(lds + (d.x & 0xFFFFu), lds + (d.x >> 16), static_cast<int>(d.y), a.vec4);
+            }
+        } else {
+            for (int it = tid; it < n_it0; it += kThreads) early[it] = sum_partials(0.f, part_e + it, n_it0, early_blk);
+        }
+        return true;
+    };
+    auto early_pieces_from = [&](int first, int q) -> bool {   // pieces first..2, barriers in between
+        for (int piece = first; piece < 3; ++piece) {
+            if (piece > first) lds_barrier();
+            if (!early_piece(piece, q)) *s_flag = 1;
+        }
+        return true;
+    };
+
+    if (rw0 > 0) {
+        early_pieces_from(0, 0);
+        lds_barrier();
+        if (*s_flag) return;
+    }
+    const long long loop_c0 = a.prof ? clock64() : 0, loop_t0 = a.prof ? wall_clock64() : 0;
+    for (int p = 0; p < HW; ++p) {
+        const int py = p / a.W, px = p - py * a.W;
+        const uint32_t tag = static_cast<uint32_t>(p + 1);
+        long long t0 = a.prof ? wall_clock64() : 0;
+        // encoder: this thread's latent of the Gaussian step, requested a whole step before it is needed
+        const int pairs = rows_w[last] >> 1, c_first = (wg * a.rpw[last]) >> 1;
+        float y_pre = 0.f;
+        if (!DECODE && tid < B * pairs) {
+            const int bi = tid / pairs, j = tid - bi * pairs;
+            y_pre = a.y[(static_cast<int64_t>(bi) * C + c_first + j) * HW + p];
+        }
+        if (rw0 > 0) {
+            // ---------- context layer, late half: the left neighbour's blocks, the bias, the activation
+            bool ok = stage_window(std::integral_constant<int, 2>{}, p, a.ntaps - 1, a.ntaps);
+            if (p > 0 && px == 0) {
+                // a row's first position has no left neighbour, but the overwrite argument of the exchange buffers (header
+                // comment) needs this workgroup's step p to start after position p - 1 is coded: wait for it, unused
+                for (int e = tid; e < B * C; e += kThreads) {
+                    const int bi = e / C, c = e - bi * C;
+                    const uint64_t *src = a.yT + ((static_cast<int64_t>(bi) * HW + p - 1) * C + c);
+                    uint64_t g = ld_gran(src);
+                    ok = wait_gran(a, src, static_cast<uint32_t>(p), g) && ok;
+                }
+            }
+            if (!ok) *s_flag = 1;
+            lds_barrier();
+            if (*s_flag) return;
+            const long long t1 = a.prof ? wall_clock64() : 0;
+            dots(0, early_units, units[0]);
+            lds_barrier();
+            const long long t2 = a.prof ? wall_clock64() : 0;
+            for (int it = tid; it < n_it0; it += kThreads) {
+                const int bi = it / rw0, r = it - bi * rw0;
+                float v = sum_partials(early[it], part + early_blk * n_it0 + it, n_it0, nblk[0] - early_blk);
+                v += lds[bias_at[0] + r];
+                if (a.act_after[0]) v = v > 0.f ? v : 0.01f * v;   // LeakyReLU(0.01)
+                st_gran(a.act[0] + static_cast<int64_t>(bi) * a.rows[0] + r_first0 + r, v, tag);
+            }
+            const long long t3 = a.prof ? wall_clock64() : 0;
+            // ---------- early half for the next position: first piece here, in the shadow of this layer's exchange (a poisoned
+            // wait shows in the flag at the next layer's barrier; with a single dense layer all three pieces run here)
+            if (p + 1 < HW) {
+                if (last >= 3) { if (!early_piece(0, p + 1)) *s_flag = 1; }
+                else early_pieces_from(0, p + 1);
+            }
+            if (a.prof && wg == 0 && tid == 0) {
+                a.prof[0] += t1 - t0; a.prof[1] += t2 - t1; a.prof[2] += t3 - t2; a.prof[3] += wall_clock64() - t3;
+            }
+        }
+        for (int l = 1; l <= last; ++l) {
+            const int rw = rows_w[l];
+            const bool piece_due = rw0 > 0 && p + 1 < HW && last >= 3 && l <= 2;   // see early_piece
+            if (rw == 0) {   // nothing to produce here -- and nothing to wait for
+                if (piece_due) { lds_barrier(); early_piece(l, p + 1); }
+                continue;
+            }
+            t0 = a.prof ? wall_clock64() : 0;
+            const int K = a.kdim[l], prev = a.rows[l - 1], n_it = B * rw, r_first = wg * a.rpw[l];
+            const bool ok = stage_granules<4>(a, B * K, [&](int e, const uint64_t *&src, uint32_t &want, float *&dst, float &plain) {
+                const int bi = e / K, kk = e - bi * K;
+                dst = xs + e;
+                if (kk < prev) { src = a.act[l - 1] + static_cast<int64_t>(bi) * prev + kk; want = tag; }
+                else if (a.priorT) plain = a.priorT[(static_cast<int64_t>(bi) * HW + p) * a.P + (kk - prev)];   // cat(ctx, prior): an input of the launch
+            });
+            if (!ok) *s_flag = 1;
+            lds_barrier();
+            if (*s_flag) return;
+            const long long t1 = a.prof ? wall_clock64() : 0;
+            dots(l, 0, units[l]);
+            lds_barrier();
+            const long long t2 = a.prof ? wall_clock64() : 0;
+            if (l < last) {
+                for (int it = tid; it < n_it; it += kThreads) {
+                    const int bi = it / rw, r = it - bi * rw;
+                    float v = sum_partials(0.f, part + it, n_it, nblk[l]);
+                    v += lds[bias_at[l] + r];
+                    if (a.act_after[l]) v = v > 0.f ? v : 0.01f * v;
+                    st_gran(a.act[l] + static_cast<int64_t>(bi) * a.rows[l] + r_first + r, v, tag);
+                }
+                // the context layer's early half for the next position, second / third piece (see early_piece)
+                if (piece_due) early_piece(l, p + 1);
+            } else {
+                // ---- (mean, scale) = rows 2j, 2j + 1 ("split_interleave") summed by ONE thread, which then codes the channel
+                for (int it = tid; it < B * pairs; it += kThreads) {
+                    const int bi = it / pairs, j = it - bi * pairs;
+                    const int i0 = bi * rw + 2 * j;
+                    float mu = sum_partials(0.f, part + i0, n_it, nblk[l]), sg = sum_partials(0.f, part + i0 + 1, n_it, nblk[l]);
+                    mu += lds[bias_at[l] + 2 * j]; sg += lds[bias_at[l] + 2 * j + 1];
+                    if (a.act_after[l]) { mu = mu > 0.f ? mu : 0.01f * mu; sg = sg > 0.f ? sg : 0.01f * sg; }
+                    const int c = c_first + j;
+                    const int row = nearest_scale(sg, tab, a.table_len, tab_sorted);
+                    if (DECODE) {
+                        st_gran(a.idx_step + static_cast<int64_t>(bi) * C + c, static_cast<uint32_t>(row), tag);
+                        st_gran(a.mu + static_cast<int64_t>(bi) * C + c, mu, tag);
+                    } else {
+                        const int64_t e = (static_cast<int64_t>(bi) * C + c) * HW + p;
+                        const int64_t o = static_cast<int64_t>(bi) * C * HW + static_cast<int64_t>(p) * C + c;
+                        const float q = rintf((it == tid ? y_pre : a.y[e]) - mu);          // torch.round: half to even
+                        st_gran(a.yT + (static_cast<int64_t>(bi) * HW + p) * C + c, q + mu, tag);   // first: every workgroup's next step waits for it
+                        a.idx[o] = row;
+                        a.sym[o] = static_cast<int32_t>(q);
+                        a.ybuf[e] = q + mu;
+                    }
+                }
+            }
+            if (a.prof && wg == 0 && tid == 0) {
+                a.prof[4 * l] += t1 - t0; a.prof[4 * l + 1] += t2 - t1; a.prof[4 * l + 2] += wall_clock64() - t2;
             }
         }
     }
@@ -780,7 +1116,7 @@ size_t align4(size_t n) { return (n + 3) & ~static_cast<size_t>(3); }
 
 // fills the launch arguments shared by both directions; *lds_bytes = LDS of a compute workgroup
 int fill_args(basic_scanline_plan *p, ScanArgs &a, int batch, int h, int w, const float *d_prior, const float *d_table, int table_len,
-              size_t *lds_bytes, hipStream_t st)
+              size_t *lds_bytes, bool *pipelined, hipStream_t st)
 {
     const int64_t HW = static_cast<int64_t>(h) * w;
     a.B = batch; a.C = p->C; a.H = h; a.W = w; a.P = p->P;
@@ -848,6 +1184,37 @@ int fill_args(basic_scanline_plan *p, ScanArgs &a, int batch, int h, int w, cons
     int bias_floats = 0;
     for (int l = 0; l < p->nlayers; ++l) bias_floats += p->rpw[l];
     *lds_bytes = static_cast<size_t>(a.bias_off + static_cast<int>(align4(bias_floats))) * sizeof(float);
+    // pipelined kernel: [weights][table][biases][context window B x K0][dense inputs B x Kd][partials][early sums][unit descriptors][flag]
+    // -- taken when all of it fits (BASIC_SCAN_KERNEL=generic|pipelined overrides; results are identical either way)
+    {
+        int kd = 0, units_total = 0, units_max = 0;
+        for (int l = 0; l < p->nlayers; ++l) {
+            if (l > 0) kd = p->kdim[l] > kd ? p->kdim[l] : kd;
+            const int u = batch * p->rpw[l] * (p->kdim[l] / p->kgroup[l]) * p->bpg[l];
+            units_total += u;
+            units_max = u > units_max ? u : units_max;
+        }
+        const size_t bias_off = align4(static_cast<size_t>(a.tab_off) + table_len);
+        const size_t x0_off = bias_off + align4(bias_need);
+        const size_t xs_off = x0_off + align4(static_cast<size_t>(batch) * p->kdim[0]);
+        const size_t part_off = xs_off + align4(static_cast<size_t>(batch) * kd);
+        const size_t early_off = part_off + align4(units_max);
+        const size_t desc_off = early_off + align4(static_cast<size_t>(batch) * p->rpw[0]) +
+                                align4(static_cast<size_t>(batch) * p->rpw[0] * (p->kdim[0] / p->kgroup[0]) * p->bpg[0]);   // early sums + the early blocks' partials
+        const size_t flag_off = desc_off + align4(2 * static_cast<size_t>(units_total));
+        bool fits = flag_off + 4 <= static_cast<size_t>(total_floats);
+        const char *e = getenv("BASIC_SCAN_KERNEL");
+        if (e && !strcmp(e, "generic")) fits = false;
+        if (e && !strcmp(e, "pipelined")) BASIC_REQUIRE(fits, "scanline: BASIC_SCAN_KERNEL=pipelined, but this batch does not fit the LDS");
+        *pipelined = fits;
+        if (fits) {
+            a.bias_off = static_cast<int>(bias_off); a.x0_off = static_cast<int>(x0_off); a.xs_off = static_cast<int>(xs_off);
+            a.part_off = static_cast<int>(part_off); a.early_off = static_cast<int>(early_off); a.desc_off = static_cast<int>(desc_off);
+            a.flag_off = static_cast<int>(flag_off);
+            a.bc = batch;
+            *lds_bytes = (flag_off + 4) * sizeof(float);
+        }
+    }
     a.bar = p->d_bar;
     a.err = reinterpret_cast<int *>(p->d_bar + 1);
     { const char *e = getenv("BASIC_SCAN_DEBUG"); a.debug = e ? atoi(e) : 0; }
@@ -904,7 +1271,8 @@ extern "C" int basic_scanline_encode_dev(basic_scanline_plan *p, const float *d_
     hipStream_t st = as_stream(hip_stream);
     ScanArgs a{};
     size_t lds_bytes = 0;
-    int rc = fill_args(p, a, batch, h, w, d_prior, d_table, table_len, &lds_bytes, st);
+    bool pipelined = false;
+    int rc = fill_args(p, a, batch, h, w, d_prior, d_table, table_len, &lds_bytes, &pipelined, st);
     if (rc) return rc;
     a.y = d_y; a.ybuf = d_ybuf; a.sym = d_symbols; a.idx = d_indexes;
     a.ncompute = p->nwg;
@@ -915,10 +1283,14 @@ extern "C" int basic_scanline_encode_dev(basic_scanline_plan *p, const float *d_
     // more than half of a compute unit's LDS per workgroup: exactly one workgroup per unit, as the barrier protocol assumes
     if (lds_bytes < 96 * 1024) lds_bytes = 96 * 1024;
     BASIC_HIP_TRY(ensure_max_lds(reinterpret_cast<const void *>(scanline_persistent_kernel<false>)));
+    BASIC_HIP_TRY(ensure_max_lds(reinterpret_cast<const void *>(scanline_pipelined_kernel<false>)));
     ScanProfile prof;
     rc = prof.begin(a, st);
     if (rc) return rc;
-    rc = chained_launch(p, st, p->nwg, cus, [&] { hipLaunchKernelGGL(scanline_persistent_kernel<false>, dim3(p->nwg), dim3(kThreads), lds_bytes, st, a); });
+    rc = chained_launch(p, st, p->nwg, cus, [&] {
+        if (pipelined) hipLaunchKernelGGL(scanline_pipelined_kernel<false>, dim3(p->nwg), dim3(kThreads), lds_bytes, st, a);
+        else hipLaunchKernelGGL(scanline_persistent_kernel<false>, dim3(p->nwg), dim3(kThreads), lds_bytes, st, a);
+    });
     prof.report(a, st, "encode");
     return rc;
 }
@@ -933,7 +1305,8 @@ extern "C" int basic_scanline_decode_dev(basic_scanline_plan *p, const basic_ran
     hipStream_t st = as_stream(hip_stream);
     ScanArgs a{};
     size_t lds_bytes = 0;
-    int rc = fill_args(p, a, batch, h, w, d_prior, d_table, table_len, &lds_bytes, st);
+    bool pipelined = false;
+    int rc = fill_args(p, a, batch, h, w, d_prior, d_table, table_len, &lds_bytes, &pipelined, st);
     if (rc) return rc;
     rc = rans_fast_view(tables, &a.tv);
     if (rc) return rc;
@@ -949,10 +1322,14 @@ extern "C" int basic_scanline_decode_dev(basic_scanline_plan *p, const basic_ran
     if (lds_bytes < 96 * 1024) lds_bytes = 96 * 1024;
     BASIC_REQUIRE(lds_bytes <= 160 * 1024, "scanline_decode: the search image does not fit the LDS");
     BASIC_HIP_TRY(ensure_max_lds(reinterpret_cast<const void *>(scanline_persistent_kernel<true>)));
+    BASIC_HIP_TRY(ensure_max_lds(reinterpret_cast<const void *>(scanline_pipelined_kernel<true>)));
     ScanProfile prof;
     rc = prof.begin(a, st);
     if (rc) return rc;
-    rc = chained_launch(p, st, p->nwg + ndec, cus, [&] { hipLaunchKernelGGL(scanline_persistent_kernel<true>, dim3(p->nwg + ndec), dim3(kThreads), lds_bytes, st, a); });
+    rc = chained_launch(p, st, p->nwg + ndec, cus, [&] {
+        if (pipelined) hipLaunchKernelGGL(scanline_pipelined_kernel<true>, dim3(p->nwg + ndec), dim3(kThreads), lds_bytes, st, a);
+        else hipLaunchKernelGGL(scanline_persistent_kernel<true>, dim3(p->nwg + ndec), dim3(kThreads), lds_bytes, st, a);
+    });
     prof.report(a, st, "decode");
     return rc;
 }

@@ -3,6 +3,8 @@ path of the same coder (one masked-conv launch sequence per step).  Both sum eve
 order of csrc/mconv.hip, so they must agree EXACTLY -- integer symbols / indexes, the coded latent bit for bit, the bytes --
 for the BaSIC context-model coder, the in-coder merger and the joint-AR raster variant at several batch sizes: a stream may
 be written by either path at any batch size and read by the other."""
+import os
+
 import pytest
 import torch
 
@@ -30,7 +32,8 @@ def _coder(kind, C):
 
 
 @pytest.mark.parametrize("kind,C,B,H,W", [("ctxmodel", 32, 1, 6, 5), ("ctxmodel", 32, 3, 4, 7), ("ctxmodel", 192, 2, 5, 6), ("merger", 32, 2, 5, 5),
-                                           ("merger-expand", 16, 1, 4, 4), ("joint", 32, 2, 3, 6), ("ctxmodel", 192, 11, 3, 4), ("ctxmodel", 48, 1, 1, 1)])
+                                           ("merger-expand", 16, 1, 4, 4), ("joint", 32, 2, 3, 6), ("ctxmodel", 192, 11, 3, 4), ("ctxmodel", 48, 1, 1, 1),
+                                           ("ctxmodel", 192, 1, 7, 9), ("merger", 192, 2, 4, 5), ("joint", 64, 1, 5, 4), ("ctxmodel", 30, 2, 3, 5)])
 def test_persistent_encode_equals_per_step_path(kind, C, B, H, W):
     coder = _coder(kind, C)
     g = torch.Generator().manual_seed(B * 100 + H * 10 + W)
@@ -44,18 +47,34 @@ def test_persistent_encode_equals_per_step_path(kind, C, B, H, W):
     coder.use_persistent_scanline = True
     coder.persistent_scanline_max_batch = 64
     assert coder._scanline_plan(plan, prior, B) is not None
-    s1, i1, y1, _ = coder._run_encode(y, prior)
-    coder._layers["scanline"][0].check()
-    ms, mi = int((s0 != s1).sum()), int((i0 != i1).sum())
-    print(f"{kind} C={C} B={B} {H}x{W}: workgroups {coder._layers['scanline'][0].workgroups}, symbol diffs {ms}, index diffs {mi} of {s0.numel()}")
-    assert ms == 0 and mi == 0
-    assert torch.equal(y0, y1), float((y0 - y1).abs().max())
-    # decode: the persistent launch (compute workgroups + one decoder wavefront per image stream) reproduces the encoder's
-    # buffer exactly; the per-step path codes the same bytes and decodes the persistent path's stream to the same latent
-    data = coder.encode(y, prior=prior)
-    yhat = coder.decode(data, prior=prior)
-    coder._layers["scanline"][0].check()
-    assert torch.equal(yhat, y1), float((yhat - y1).abs().max())
+    # both persistent kernels: the generic one (any batch) and the pipelined one (batches whose working set fits the LDS)
+    ran = []
+    for kernel in ("generic", "pipelined", None):
+        if kernel is None:
+            os.environ.pop("BASIC_SCAN_KERNEL", None)
+        else:
+            os.environ["BASIC_SCAN_KERNEL"] = kernel
+        try:
+            try:
+                s1, i1, y1, _ = coder._run_encode(y, prior)
+            except (RuntimeError, ValueError) as e:
+                assert kernel == "pipelined" and "does not fit" in str(e) and B > 2, e
+                continue
+            coder._layers["scanline"][0].check()
+            ms, mi = int((s0 != s1).sum()), int((i0 != i1).sum())
+            print(f"{kind} C={C} B={B} {H}x{W} [{kernel}]: workgroups {coder._layers['scanline'][0].workgroups}, symbol diffs {ms}, index diffs {mi} of {s0.numel()}")
+            assert ms == 0 and mi == 0
+            assert torch.equal(y0, y1), float((y0 - y1).abs().max())
+            # decode: the persistent launch (compute workgroups + one decoder wavefront per image stream) reproduces the encoder's
+            # buffer exactly; the per-step path codes the same bytes and decodes the persistent path's stream to the same latent
+            data = coder.encode(y, prior=prior)
+            yhat = coder.decode(data, prior=prior)
+            coder._layers["scanline"][0].check()
+            assert torch.equal(yhat, y1), float((yhat - y1).abs().max())
+            ran.append(kernel)
+        finally:
+            os.environ.pop("BASIC_SCAN_KERNEL", None)
+    assert "generic" in ran and (B > 2 or "pipelined" in ran)
     coder.use_persistent_scanline = False
     assert coder.encode(y, prior=prior) == data
     assert torch.equal(coder.decode(data, prior=prior), y1)
