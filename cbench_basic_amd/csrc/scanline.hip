@@ -635,97 +635,130 @@ __device__ __forceinline__ float sum_partials(float v, const float *part, int st
     return v;
 }
 
-// U granules per thread in flight, then ONE polling loop over those still carrying an old tag.  get(e, src, want, dst):
-// element e of this batch -> granule address (nullptr: dst gets `plain`), expected tag, LDS destination.
-template <int U, class Get>
-__device__ __forceinline__ bool stage_granules(const ScanArgs &a, int total, Get &&get)
+// Two neighbouring granules with one 16-byte load.  Each 8-byte half validates itself by its own tag, so nothing is asked
+// of the load beyond what an aligned 8-byte access gives; volatile = cache-bypassing (sc0 sc1) on gfx950, as ld_gran's.
+typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u64x2 ld_gran2(const uint64_t *p)
 {
-    const int tid = threadIdx.x;
+    typedef const volatile u64x2 __attribute__((address_space(1))) *global_ptr;   // (a generic pointer would make it a flat load)
+    return *(global_ptr)(reinterpret_cast<uintptr_t>(p));
+}
+__device__ __forceinline__ bool tags_are(const u64x2 &g, uint32_t want)
+{
+    return static_cast<uint32_t>(g[0] >> 32) == want && static_cast<uint32_t>(g[1] >> 32) == want;
+}
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 values_of(const u64x2 &g)
+{
+    return f2{__uint_as_float(static_cast<uint32_t>(g[0])), __uint_as_float(static_cast<uint32_t>(g[1]))};
+}
+
+// n granule pairs src[2i], src[2i + 1] (all carrying `want` once written) -> dst[2i], dst[2i + 1]; thread i, i + 256, ...,
+// two pairs of a thread in flight.  No divisions, no per-element address arithmetic beyond one add: the workgroup's
+// waves are alone on their SIMDs and issue one instruction per ~10 clocks.
+__device__ __forceinline__ bool stage_pairs(const ScanArgs &a, const uint64_t *src, int n, uint32_t want, float *dst)
+{
     bool ok = true;
-    for (int e0 = tid; e0 < total; e0 += kThreads * U) {
-        const uint64_t *src[U];
-        uint64_t g[U];
-        uint32_t want[U];
-        float *dst[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int e = e0 + u * kThreads;
-            src[u] = nullptr; g[u] = 0ull; want[u] = 0u; dst[u] = nullptr;
-            if (e < total) {
-                float plain = 0.f;
-                get(e, src[u], want[u], dst[u], plain);
-                if (src[u]) g[u] = ld_gran(src[u]);
-                else *dst[u] = plain;
-            }
-        }
+    for (int i0 = threadIdx.x; i0 < n; i0 += 2 * kThreads) {
+        const int i1 = i0 + kThreads;
+        const bool two = i1 < n;
+        u64x2 g0 = ld_gran2(src + 2 * i0), g1 = two ? ld_gran2(src + 2 * i1) : u64x2{0ull, 0ull};
         unsigned spins = 0;
         for (;;) {
-            bool all = true;
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-                if (src[u] && static_cast<uint32_t>(g[u] >> 32) != want[u]) { g[u] = ld_gran(src[u]); all = false; }
-            if (all) break;
+            const bool r0 = !tags_are(g0, want), r1 = two && !tags_are(g1, want);
+            if (!r0 && !r1) break;
             if (++spins > kSpinLimit || (spins % 1024u == 0u && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
                 __hip_atomic_store(a.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 ok = false;
                 break;
             }
+            if (r0) g0 = ld_gran2(src + 2 * i0);
+            if (r1) g1 = ld_gran2(src + 2 * i1);
         }
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-            if (src[u]) *dst[u] = __uint_as_float(static_cast<uint32_t>(g[u]));
+        *reinterpret_cast<f2 *>(dst + 2 * i0) = values_of(g0);
+        if (two) *reinterpret_cast<f2 *>(dst + 2 * i1) = values_of(g1);
     }
     return ok;
+}
+
+constexpr int kWinU = 6;   // early-window granule pairs per thread: (ntaps - 1) * C / 2 <= 6 * 256 per image
+
+// per-thread state of one layer of the pipelined kernel; the layer index is a compile-time constant wherever these are
+// used, so they live in registers
+struct LayerRegs {
+    int rw, n_it, K, prev, nblk, units, dbase, r_first;
+    float bias0, bias1;   // of this thread's finishing item (last layer: of its (mean, scale) pair)
+    int fin_bi, fin_r;    // this thread's finishing item: image, row (last layer: pair)
+};
+
+template <int kFrom, int kTo, class F> __device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (kFrom < kTo) {
+        f(std::integral_constant<int, kFrom>{});
+        static_for<kFrom + 1, kTo>(f);
+    }
 }
 
 template <bool DECODE>
 __global__ __launch_bounds__(kThreads) void scanline_pipelined_kernel(const ScanArgs a)
 {
     extern __shared__ float lds[];
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
     const int wg = blockIdx.x;
-    const int HW = a.H * a.W, B = a.B;
+    const int HW = a.H * a.W, B = a.B, C = a.C;
     const int last = a.nlayers - 1;
     if (DECODE && wg >= a.ncompute) { decoder_workgroup(a, lds); return; }
 
-    // ---- this workgroup's weight slices, scale table, biases (as in scanline_persistent_kernel)
-    int rows_w[kMaxLayers];
-    for (int l = 0; l < a.nlayers; ++l) {
-        int r = a.rows[l] - wg * a.rpw[l];
-        r = r < 0 ? 0 : (r > a.rpw[l] ? a.rpw[l] : r);
-        rows_w[l] = r;
-        const float *src = a.w[l] + static_cast<int64_t>(wg) * a.rpw[l] * a.kdim[l];
-        float *dst = lds + a.woff[l];
-        const int Kl = a.kdim[l], Kp = a.kpad[l];
-        for (int e = tid; e < r * Kl; e += kThreads) { const int rr = e / Kl; dst[rr * Kp + padded_k(e - rr * Kl, a.kgroup[l], a.bpg[l])] = src[e]; }
-    }
+    // ---- this workgroup's weight slices, scale table, unit descriptors
     float *tab = lds + a.tab_off;
     for (int e = tid; e < a.table_len; e += kThreads) tab[e] = a.table[e];
     float *x0 = lds + a.x0_off, *xs = lds + a.xs_off, *part = lds + a.part_off, *early = lds + a.early_off;
+    float *part_e = lds + a.early_off + ((B * a.rpw[0] + 3) & ~3);   // the early blocks' partials: not shared with the dense layers
     uint2 *desc = reinterpret_cast<uint2 *>(lds + a.desc_off);
     int *s_flag = reinterpret_cast<int *>(lds + a.flag_off);
-    int bias_at[kMaxLayers], dbase[kMaxLayers], units[kMaxLayers], nblk[kMaxLayers];
+    LayerRegs L[kMaxLayers];
+    int pairs = 0, my_c = 0, my_b = 0;   // the last layer's (mean, scale) pairs of this workgroup; this thread's channel and image
     {
-        int off = a.bias_off, db = 0;
-        for (int l = 0; l < a.nlayers; ++l) {
-            bias_at[l] = off;
-            for (int e = tid; e < rows_w[l]; e += kThreads) lds[off + e] = a.bias[l] ? a.bias[l][wg * a.rpw[l] + e] : 0.f;
-            off += a.rpw[l];
+        int db = 0;
+#pragma unroll
+        for (int l = 0; l < kMaxLayers; ++l) {
+            L[l] = LayerRegs{};
+            if (l >= a.nlayers) continue;
+            int r = a.rows[l] - wg * a.rpw[l];
+            r = r < 0 ? 0 : (r > a.rpw[l] ? a.rpw[l] : r);
+            const int Kl = a.kdim[l], Kp = a.kpad[l], kg = a.kgroup[l], bpg = a.bpg[l];
+            {
+                const float *src = a.w[l] + static_cast<int64_t>(wg) * a.rpw[l] * Kl;
+                float *dst = lds + a.woff[l];
+                for (int e = tid; e < r * Kl; e += kThreads) { const int rr = e / Kl; dst[rr * Kp + padded_k(e - rr * Kl, kg, bpg)] = src[e]; }
+            }
+            L[l].rw = r; L[l].n_it = B * r; L[l].K = Kl; L[l].prev = l ? a.rows[l - 1] : 0;
+            L[l].nblk = (Kl / kg) * bpg; L[l].units = L[l].n_it * L[l].nblk; L[l].dbase = db; L[l].r_first = wg * a.rpw[l];
             // unit u = blk * n_it + it (it = image * rows + row): LDS float offsets of its weight block and input block, its length
-            const int rw = rows_w[l], n_it = B * rw, K = a.kdim[l], Kp = a.kpad[l], kg = a.kgroup[l], bpg = a.bpg[l];
-            nblk[l] = (K / kg) * bpg;
-            units[l] = n_it * nblk[l];
-            dbase[l] = db;
             const int x_base = l == 0 ? a.x0_off : a.xs_off;
-            for (int u = tid; u < units[l]; u += kThreads) {
-                const int blk = u / n_it, it = u - blk * n_it, bi = it / rw, r = it - bi * rw;
+            for (int u = tid; u < L[l].units; u += kThreads) {
+                const int blk = u / L[l].n_it, it = u - blk * L[l].n_it, bi = it / r, rr = it - bi * r;
                 const int g = blk / bpg, j = blk - g * bpg;
                 const int len = (kg - j * kKB) < kKB ? (kg - j * kKB) : kKB;
-                const int w_off = a.woff[l] + r * Kp + g * (kg + kBlockPad * bpg) + j * (kKB + kBlockPad);
-                const int x_off = x_base + bi * K + g * kg + j * kKB;
+                const int w_off = a.woff[l] + rr * Kp + g * (kg + kBlockPad * bpg) + j * (kKB + kBlockPad);
+                const int x_off = x_base + bi * Kl + g * kg + j * kKB;
                 desc[db + u] = make_uint2(static_cast<uint32_t>(w_off) | (static_cast<uint32_t>(x_off) << 16), static_cast<uint32_t>(len));
             }
-            db += units[l];
+            db += L[l].units;
+            // this thread's finishing item (host guarantees B * rows-per-workgroup <= kThreads: one item per thread)
+            const int items = l == last ? B * (r >> 1) : B * r, per = l == last ? (r >> 1) : r;
+            if (l == last) pairs = r >> 1;
+            if (tid < items) {
+                L[l].fin_bi = tid / per; L[l].fin_r = tid - L[l].fin_bi * per;
+                const float *bias = a.bias[l];
+                if (l == last) {
+                    L[l].bias0 = bias ? bias[L[l].r_first + 2 * L[l].fin_r] : 0.f;
+                    L[l].bias1 = bias ? bias[L[l].r_first + 2 * L[l].fin_r + 1] : 0.f;
+                    my_c = (L[l].r_first >> 1) + L[l].fin_r; my_b = L[l].fin_bi;
+                } else {
+                    L[l].bias0 = bias ? bias[L[l].r_first + L[l].fin_r] : 0.f;
+                }
+            }
         }
     }
     if (tid == 0) { s_flag[0] = 0; s_flag[1] = 1; }
@@ -735,56 +768,80 @@ __global__ __launch_bounds__(kThreads) void scanline_pipelined_kernel(const Scan
     __syncthreads();
     const bool tab_sorted = s_flag[1] != 0;
 
-    const int rw0 = rows_w[0], n_it0 = B * rw0, K0 = a.kdim[0], C = a.C;
+    const int rw0 = L[0].rw, n_it0 = L[0].n_it, K0 = L[0].K;
     const int early_blk = (a.ntaps - 1) * a.bpg[0];      // blocks of the taps coded at least two steps ago
     const int early_units = early_blk * n_it0;
-    const int r_first0 = wg * a.rpw[0];
+    const int late_off = (a.ntaps - 1) * C;              // the left neighbour's channels in a context window
 
-    auto dots = [&](int l, int u0, int u1) {
-        for (int u = u0 + tid; u < u1; u += kThreads) {
-            const uint2 d = desc[dbase[l] + u];
-            part[u] = block_dot_preloaded(lds + (d.x & 0xFFFFu), lds + (d.x >> 16), static_cast<int>(d.y), a.vec4);
-        }
-    };
-    // context window of position q, taps [t0, t1) of every image -> x0 (zeros outside the image)
-    auto stage_window = [&](auto uc, int q, int t0, int t1) -> bool {
-        constexpr int U = decltype(uc)::value;
-        const int qy = q / a.W, qx = q - qy * a.W;
-        const int span = (t1 - t0) * C;
-        return stage_granules<U>(a, B * span, [&](int e, const uint64_t *&src, uint32_t &want, float *&dst, float &plain) {
-            const int bi = e / span, kk = e - bi * span;
-            const int t = t0 + kk / C, c = kk - (t - t0) * C;
-            const int ny = qy + a.tap_dy[t], nx = qx + a.tap_dx[t];
-            dst = x0 + bi * K0 + t * C + c;
-            if (ny >= 0 && nx >= 0 && nx < a.W) {
-                src = a.yT + ((static_cast<int64_t>(bi) * HW + q + a.tap_off[t]) * C + c);
-                want = static_cast<uint32_t>(q + a.tap_off[t] + 1);
+    // ---- early window: this thread's granule pairs (tap t, channels 2 c2, 2 c2 + 1) of one image, as offsets from the window's position
+    int win_rel[kWinU], win_dst[kWinU], win_tap[kWinU], win_toff[kWinU];
+    {
+        const int half = C >> 1, E = (a.ntaps - 1) * half;
+#pragma unroll
+        for (int u = 0; u < kWinU; ++u) {
+            const int e = tid + u * kThreads;
+            win_rel[u] = 0; win_dst[u] = 0; win_tap[u] = 63; win_toff[u] = 0;
+            if (e < E) {
+                const int t = e / half, c2 = e - t * half;
+                win_tap[u] = t; win_toff[u] = a.tap_off[t];
+                win_rel[u] = a.tap_off[t] * C + 2 * c2;
+                win_dst[u] = t * C + 2 * c2;
             }
-        });
+        }
+    }
+    // lane t of every wave keeps tap t's (dy, dx): the taps inside the image at a position become one ballot
+    const int my_dy = lane < a.ntaps ? a.tap_dy[lane] : -(1 << 20), my_dx = lane < a.ntaps ? a.tap_dx[lane] : 0;
+
+    auto dots = [&](float *out, int dbase, int u0, int u1) {
+        for (int u = u0 + tid; u < u1; u += kThreads) {
+            const uint2 d = desc[dbase + u];
+            out[u] = block_dot_preloaded(lds + (d.x & 0xFFFFu), lds + (d.x >> 16), static_cast<int>(d.y), a.vec4);
+        }
     };
     // early half of the context layer for position q -- the sums over the first early_blk blocks, in block order from zero --
     // in three pieces that need a workgroup barrier between them: the main loop runs one piece in the shadow of each of the
     // following layers' exchanges (their barriers separate the pieces); with fewer layers than pieces the rest run back to back
-    float *part_e = lds + a.early_off + ((B * a.rpw[0] + 3) & ~3);   // the early blocks' partials: not shared with the dense layers
     auto early_piece = [&](int piece, int q) -> bool {
+        bool ok = true;
         if (piece == 0) {
-            if (a.ntaps > 1 && !stage_window(std::integral_constant<int, 12>{}, q, 0, a.ntaps - 1)) return false;
-        } else if (piece == 1) {
-            for (int u = tid; u < early_units; u += kThreads) {
-                const uint2 d = desc[dbase[0] + u];
-                part_e[u] = block_dot_preloaded(lds + (d.x & 0xFFFFu), lds + (d.x >> 16), static_cast<int>(d.y), a.vec4);
+            const int qy = q / a.W, qx = q - qy * a.W;
+            const uint64_t inside = __ballot(qy + my_dy >= 0 && qx + my_dx >= 0 && qx + my_dx < a.W);
+            for (int bi = 0; bi < B; ++bi) {
+                const uint64_t *base = a.yT + (static_cast<int64_t>(bi) * HW + q) * C;
+                float *dst = x0 + bi * K0;
+                u64x2 g[kWinU];
+                bool live[kWinU];
+#pragma unroll
+                for (int u = 0; u < kWinU; ++u) {
+                    live[u] = ((inside >> win_tap[u]) & 1ull) != 0ull;   // (tap 63: no element)
+                    g[u] = u64x2{0ull, 0ull};
+                    if (live[u]) g[u] = ld_gran2(base + win_rel[u]);
+                }
+                unsigned spins = 0;
+                for (;;) {   // these positions were coded at least two steps ago: the tags match at once
+                    bool all = true;
+#pragma unroll
+                    for (int u = 0; u < kWinU; ++u)
+                        if (live[u] && !tags_are(g[u], static_cast<uint32_t>(q + win_toff[u] + 1))) { g[u] = ld_gran2(base + win_rel[u]); all = false; }
+                    if (all) break;
+                    if (++spins > kSpinLimit) { __hip_atomic_store(a.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = false; break; }
+                }
+#pragma unroll
+                for (int u = 0; u < kWinU; ++u)
+                    if (win_tap[u] != 63) *reinterpret_cast<f2 *>(dst + win_dst[u]) = values_of(g[u]);   // zeros outside the image
             }
+        } else if (piece == 1) {
+            dots(part_e, L[0].dbase, 0, early_units);
         } else {
-            for (int it = tid; it < n_it0; it += kThreads) early[it] = sum_partials(0.f, part_e + it, n_it0, early_blk);
+            if (tid < n_it0) early[tid] = sum_partials(0.f, part_e + tid, n_it0, early_blk);
         }
-        return true;
+        return ok;
     };
-    auto early_pieces_from = [&](int first, int q) -> bool {   // pieces first..2, barriers in between
+    auto early_pieces_from = [&](int first, int q) {   // pieces first..2, barriers in between
         for (int piece = first; piece < 3; ++piece) {
             if (piece > first) lds_barrier();
             if (!early_piece(piece, q)) *s_flag = 1;
         }
-        return true;
     };
 
     if (rw0 > 0) {
@@ -792,48 +849,48 @@ __global__ __launch_bounds__(kThreads) void scanline_pipelined_kernel(const Scan
         lds_barrier();
         if (*s_flag) return;
     }
+    // encoder: pointers of this thread's channel of the Gaussian step, advanced by one position per step
+    const bool codes = tid < B * pairs;
+    const float *y_ptr = a.y ? a.y + (static_cast<int64_t>(my_b) * C + my_c) * HW : nullptr;
+    float *ybuf_ptr = a.ybuf + (static_cast<int64_t>(my_b) * C + my_c) * HW;
+    int32_t *sym_ptr = a.sym + static_cast<int64_t>(my_b) * C * HW + my_c, *idx_ptr = a.idx + static_cast<int64_t>(my_b) * C * HW + my_c;
+    uint64_t *yT_ptr = a.yT + static_cast<int64_t>(my_b) * HW * C + my_c;
+
     const long long loop_c0 = a.prof ? clock64() : 0, loop_t0 = a.prof ? wall_clock64() : 0;
+    int px = 0;
+    bool dead = false;
     for (int p = 0; p < HW; ++p) {
-        const int py = p / a.W, px = p - py * a.W;
         const uint32_t tag = static_cast<uint32_t>(p + 1);
         long long t0 = a.prof ? wall_clock64() : 0;
-        // encoder: this thread's latent of the Gaussian step, requested a whole step before it is needed
-        const int pairs = rows_w[last] >> 1, c_first = (wg * a.rpw[last]) >> 1;
         float y_pre = 0.f;
-        if (!DECODE && tid < B * pairs) {
-            const int bi = tid / pairs, j = tid - bi * pairs;
-            y_pre = a.y[(static_cast<int64_t>(bi) * C + c_first + j) * HW + p];
-        }
+        if (!DECODE && codes) y_pre = y_ptr[p];   // requested a whole step before it is needed
         if (rw0 > 0) {
-            // ---------- context layer, late half: the left neighbour's blocks, the bias, the activation
-            bool ok = stage_window(std::integral_constant<int, 2>{}, p, a.ntaps - 1, a.ntaps);
-            if (p > 0 && px == 0) {
-                // a row's first position has no left neighbour, but the overwrite argument of the exchange buffers (header
-                // comment) needs this workgroup's step p to start after position p - 1 is coded: wait for it, unused
-                for (int e = tid; e < B * C; e += kThreads) {
-                    const int bi = e / C, c = e - bi * C;
-                    const uint64_t *src = a.yT + ((static_cast<int64_t>(bi) * HW + p - 1) * C + c);
-                    uint64_t g = ld_gran(src);
-                    ok = wait_gran(a, src, static_cast<uint32_t>(p), g) && ok;
-                }
+            // ---------- context layer, late half: the left neighbour's blocks, the bias, the activation.  A row's first
+            // position has no left neighbour (zeros), but the overwrite argument of the exchange buffers (header comment)
+            // needs this workgroup's step p to start after position p - 1 is coded: its granules are waited for all the same.
+            bool ok = true;
+            for (int bi = 0; bi < B; ++bi) {
+                float *dst = x0 + bi * K0 + late_off;
+                if (p > 0) ok = stage_pairs(a, a.yT + (static_cast<int64_t>(bi) * HW + p - 1) * C, C >> 1, static_cast<uint32_t>(p), dst) && ok;
+                if (px == 0)
+                    for (int i = tid; i < (C >> 1); i += kThreads) *reinterpret_cast<f2 *>(dst + 2 * i) = f2{0.f, 0.f};
             }
             if (!ok) *s_flag = 1;
             lds_barrier();
             if (*s_flag) return;
             const long long t1 = a.prof ? wall_clock64() : 0;
-            dots(0, early_units, units[0]);
+            dots(part, L[0].dbase, early_units, L[0].units);
             lds_barrier();
             const long long t2 = a.prof ? wall_clock64() : 0;
-            for (int it = tid; it < n_it0; it += kThreads) {
-                const int bi = it / rw0, r = it - bi * rw0;
-                float v = sum_partials(early[it], part + early_blk * n_it0 + it, n_it0, nblk[0] - early_blk);
-                v += lds[bias_at[0] + r];
+            if (tid < n_it0) {
+                float v = sum_partials(early[tid], part + early_units + tid, n_it0, L[0].nblk - early_blk);
+                v += L[0].bias0;
                 if (a.act_after[0]) v = v > 0.f ? v : 0.01f * v;   // LeakyReLU(0.01)
-                st_gran(a.act[0] + static_cast<int64_t>(bi) * a.rows[0] + r_first0 + r, v, tag);
+                st_gran(a.act[0] + static_cast<int64_t>(L[0].fin_bi) * a.rows[0] + L[0].r_first + L[0].fin_r, v, tag);
             }
             const long long t3 = a.prof ? wall_clock64() : 0;
             // ---------- early half for the next position: first piece here, in the shadow of this layer's exchange (a poisoned
-            // wait shows in the flag at the next layer's barrier; with a single dense layer all three pieces run here)
+            // wait shows in the flag at the next layer's barrier; with fewer than three dense layers all pieces run here)
             if (p + 1 < HW) {
                 if (last >= 3) { if (!early_piece(0, p + 1)) *s_flag = 1; }
                 else early_pieces_from(0, p + 1);
@@ -842,66 +899,68 @@ __global__ __launch_bounds__(kThreads) void scanline_pipelined_kernel(const Scan
                 a.prof[0] += t1 - t0; a.prof[1] += t2 - t1; a.prof[2] += t3 - t2; a.prof[3] += wall_clock64() - t3;
             }
         }
-        for (int l = 1; l <= last; ++l) {
-            const int rw = rows_w[l];
+        static_for<1, kMaxLayers>([&](auto lc) {
+            constexpr int l = decltype(lc)::value;
+            if (l > last) return;
+            const LayerRegs &R = L[l];
             const bool piece_due = rw0 > 0 && p + 1 < HW && last >= 3 && l <= 2;   // see early_piece
-            if (rw == 0) {   // nothing to produce here -- and nothing to wait for
+            if (dead) return;
+            if (R.rw == 0) {   // nothing to produce here -- and nothing to wait for
                 if (piece_due) { lds_barrier(); early_piece(l, p + 1); }
-                continue;
+                return;
             }
-            t0 = a.prof ? wall_clock64() : 0;
-            const int K = a.kdim[l], prev = a.rows[l - 1], n_it = B * rw, r_first = wg * a.rpw[l];
-            const bool ok = stage_granules<4>(a, B * K, [&](int e, const uint64_t *&src, uint32_t &want, float *&dst, float &plain) {
-                const int bi = e / K, kk = e - bi * K;
-                dst = xs + e;
-                if (kk < prev) { src = a.act[l - 1] + static_cast<int64_t>(bi) * prev + kk; want = tag; }
-                else if (a.priorT) plain = a.priorT[(static_cast<int64_t>(bi) * HW + p) * a.P + (kk - prev)];   // cat(ctx, prior): an input of the launch
-            });
+            const long long t0 = a.prof ? wall_clock64() : 0;
+            bool ok = true;
+            for (int bi = 0; bi < B; ++bi) {
+                float *dst = xs + bi * R.K;
+                if (R.K > R.prev && a.priorT) {   // cat(ctx, prior): the prior is an input of the launch
+                    const f4 *src = reinterpret_cast<const f4 *>(a.priorT + (static_cast<int64_t>(bi) * HW + p) * a.P);
+                    for (int i = tid; i < ((R.K - R.prev) >> 2); i += kThreads) *reinterpret_cast<f4 *>(dst + R.prev + 4 * i) = src[i];
+                }
+                ok = stage_pairs(a, a.act[l - 1] + static_cast<int64_t>(bi) * R.prev, R.prev >> 1, tag, dst) && ok;
+            }
             if (!ok) *s_flag = 1;
             lds_barrier();
-            if (*s_flag) return;
+            // a poisoned launch (some wait gave up; every later wait then fails fast) is left once per step, after a barrier:
+            // at the context layer's, or here by the workgroups without context rows
+            if (l == 1 && rw0 == 0 && *s_flag) { dead = true; return; }
             const long long t1 = a.prof ? wall_clock64() : 0;
-            dots(l, 0, units[l]);
+            dots(part, R.dbase, 0, R.units);
             lds_barrier();
             const long long t2 = a.prof ? wall_clock64() : 0;
             if (l < last) {
-                for (int it = tid; it < n_it; it += kThreads) {
-                    const int bi = it / rw, r = it - bi * rw;
-                    float v = sum_partials(0.f, part + it, n_it, nblk[l]);
-                    v += lds[bias_at[l] + r];
+                if (tid < R.n_it) {
+                    float v = sum_partials(0.f, part + tid, R.n_it, R.nblk);
+                    v += R.bias0;
                     if (a.act_after[l]) v = v > 0.f ? v : 0.01f * v;
-                    st_gran(a.act[l] + static_cast<int64_t>(bi) * a.rows[l] + r_first + r, v, tag);
+                    st_gran(a.act[l] + static_cast<int64_t>(R.fin_bi) * a.rows[l] + R.r_first + R.fin_r, v, tag);
                 }
                 // the context layer's early half for the next position, second / third piece (see early_piece)
                 if (piece_due) early_piece(l, p + 1);
-            } else {
+            } else if (codes) {
                 // ---- (mean, scale) = rows 2j, 2j + 1 ("split_interleave") summed by ONE thread, which then codes the channel
-                for (int it = tid; it < B * pairs; it += kThreads) {
-                    const int bi = it / pairs, j = it - bi * pairs;
-                    const int i0 = bi * rw + 2 * j;
-                    float mu = sum_partials(0.f, part + i0, n_it, nblk[l]), sg = sum_partials(0.f, part + i0 + 1, n_it, nblk[l]);
-                    mu += lds[bias_at[l] + 2 * j]; sg += lds[bias_at[l] + 2 * j + 1];
-                    if (a.act_after[l]) { mu = mu > 0.f ? mu : 0.01f * mu; sg = sg > 0.f ? sg : 0.01f * sg; }
-                    const int c = c_first + j;
-                    const int row = nearest_scale(sg, tab, a.table_len, tab_sorted);
-                    if (DECODE) {
-                        st_gran(a.idx_step + static_cast<int64_t>(bi) * C + c, static_cast<uint32_t>(row), tag);
-                        st_gran(a.mu + static_cast<int64_t>(bi) * C + c, mu, tag);
-                    } else {
-                        const int64_t e = (static_cast<int64_t>(bi) * C + c) * HW + p;
-                        const int64_t o = static_cast<int64_t>(bi) * C * HW + static_cast<int64_t>(p) * C + c;
-                        const float q = rintf((it == tid ? y_pre : a.y[e]) - mu);          // torch.round: half to even
-                        st_gran(a.yT + (static_cast<int64_t>(bi) * HW + p) * C + c, q + mu, tag);   // first: every workgroup's next step waits for it
-                        a.idx[o] = row;
-                        a.sym[o] = static_cast<int32_t>(q);
-                        a.ybuf[e] = q + mu;
-                    }
+                const int i0 = R.fin_bi * R.rw + 2 * R.fin_r;
+                float mu = sum_partials(0.f, part + i0, R.n_it, R.nblk), sg = sum_partials(0.f, part + i0 + 1, R.n_it, R.nblk);
+                mu += R.bias0; sg += R.bias1;
+                if (a.act_after[l]) { mu = mu > 0.f ? mu : 0.01f * mu; sg = sg > 0.f ? sg : 0.01f * sg; }
+                const int row = nearest_scale(sg, tab, a.table_len, tab_sorted);
+                if (DECODE) {
+                    st_gran(a.idx_step + static_cast<int64_t>(my_b) * C + my_c, static_cast<uint32_t>(row), tag);
+                    st_gran(a.mu + static_cast<int64_t>(my_b) * C + my_c, mu, tag);
+                } else {
+                    const float q = rintf(y_pre - mu);          // torch.round: half to even
+                    st_gran(yT_ptr + static_cast<int64_t>(p) * C, q + mu, tag);   // first: every workgroup's next step waits for it
+                    idx_ptr[static_cast<int64_t>(p) * C] = row;
+                    sym_ptr[static_cast<int64_t>(p) * C] = static_cast<int32_t>(q);
+                    ybuf_ptr[p] = q + mu;
                 }
             }
             if (a.prof && wg == 0 && tid == 0) {
                 a.prof[4 * l] += t1 - t0; a.prof[4 * l + 1] += t2 - t1; a.prof[4 * l + 2] += wall_clock64() - t2;
             }
-        }
+        });
+        if (dead) return;
+        if (++px == a.W) px = 0;
     }
     if (a.prof && wg == 0 && tid == 0) {
         a.prof[4 * kMaxLayers] = clock64() - loop_c0;
@@ -1202,7 +1261,8 @@ int fill_args(basic_scanline_plan *p, ScanArgs &a, int batch, int h, int w, cons
         const size_t desc_off = early_off + align4(static_cast<size_t>(batch) * p->rpw[0]) +
                                 align4(static_cast<size_t>(batch) * p->rpw[0] * (p->kdim[0] / p->kgroup[0]) * p->bpg[0]);   // early sums + the early blocks' partials
         const size_t flag_off = desc_off + align4(2 * static_cast<size_t>(units_total));
-        bool fits = flag_off + 4 <= static_cast<size_t>(total_floats);
+        bool fits = flag_off + 4 <= static_cast<size_t>(total_floats) && p->vec4 && (p->ntaps - 1) * (p->C / 2) <= kWinU * kThreads;
+        for (int l = 0; l < p->nlayers; ++l) fits = fits && batch * p->rpw[l] <= kThreads;   // one finishing item per thread
         const char *e = getenv("BASIC_SCAN_KERNEL");
         if (e && !strcmp(e, "generic")) fits = false;
         if (e && !strcmp(e, "pipelined")) BASIC_REQUIRE(fits, "scanline: BASIC_SCAN_KERNEL=pipelined, but this batch does not fit the LDS");

@@ -29,3 +29,14 @@ for s, e, n, st in ev:
             print(f"{(s - t0) / 1e6:9.3f} {(e - s) / 1e3:9.0f} {(s - last[st]) / 1e3 if last[st] else 0:9.0f} {st:>3s} {n[:64]}")
     last[st] = max(last[st], e)
 print(f"kernels in window: {acc}")
+
+# persistent launches: how many are in flight when each starts, and every kernel that ran > 5 ms (possibly stalled)
+pers = [(s, e, n, st) for s, e, n, st in ev if "scanline_p" in n]
+print("\npersistent launches (start ms, duration ms, stream, in flight at start incl. itself) and other kernels > 5 ms:")
+base = ev[0][0]
+for s, e, n, st in ev:
+    if "scanline_p" in n:
+        inflight = sum(1 for s2, e2, _, _ in pers if s2 <= s < e2)
+        print(f"{(s - base) / 1e6:10.2f} {(e - s) / 1e6:8.2f} {st:>3s} {inflight:2d}  {n[:50]}")
+    elif e - s > 5000000:
+        print(f"{(s - base) / 1e6:10.2f} {(e - s) / 1e6:8.2f} {st:>3s}     {n[:50]}")

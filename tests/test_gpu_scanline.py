@@ -58,7 +58,7 @@ def test_persistent_encode_equals_per_step_path(kind, C, B, H, W):
             try:
                 s1, i1, y1, _ = coder._run_encode(y, prior)
             except (RuntimeError, ValueError) as e:
-                assert kernel == "pipelined" and "does not fit" in str(e) and B > 2, e
+                assert kernel == "pipelined" and "does not fit" in str(e), e   # batch too large, or a layer size that is not a multiple of 4
                 continue
             coder._layers["scanline"][0].check()
             ms, mi = int((s0 != s1).sum()), int((i0 != i1).sum())
@@ -74,7 +74,7 @@ def test_persistent_encode_equals_per_step_path(kind, C, B, H, W):
             ran.append(kernel)
         finally:
             os.environ.pop("BASIC_SCAN_KERNEL", None)
-    assert "generic" in ran and (B > 2 or "pipelined" in ran)
+    assert "generic" in ran and ("pipelined" in ran or not (C in (48, 192) and B <= 2))
     coder.use_persistent_scanline = False
     assert coder.encode(y, prior=prior) == data
     assert torch.equal(coder.decode(data, prior=prior), y1)
