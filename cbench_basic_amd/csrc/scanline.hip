@@ -424,8 +424,10 @@ __device__ __forceinline__ void decoder_workgroup(const ScanArgs &a, float *lds)
         for (int c0 = 0; c0 < a.C; c0 += 64) {
             const int c = c0 + lane;
             bool ok = true;
+            const long long tw0 = a.prof ? wall_clock64() : 0;
             if (c < a.C) ok = wait_gran(a, pi0 + c, tag, gi) && wait_gran(a, pm0 + c, tag, gm);
             if (__ballot(!ok) != 0ull) return;   // poisoned launch: wave-uniform exit
+            const long long tw1 = a.prof ? wall_clock64() : 0;
             int32_t row = static_cast<int32_t>(static_cast<uint32_t>(gi));
             const float mu = __uint_as_float(static_cast<uint32_t>(gm));
             gi = 0ull; gm = 0ull;
@@ -441,6 +443,10 @@ __device__ __forceinline__ void decoder_workgroup(const ScanArgs &a, float *lds)
                 a.sym[static_cast<int64_t>(b) * a.C * HW + static_cast<int64_t>(p) * a.C + c] = value;
                 a.idx[static_cast<int64_t>(b) * a.C * HW + static_cast<int64_t>(p) * a.C + c] = row;
                 a.ybuf[(static_cast<int64_t>(b) * a.C + c) * HW + p] = v;
+            }
+            if (a.prof && b == 0 && lane == 0) {   // first stream: ticks waiting for the step's parameters / decoding and publishing
+                a.prof[4 * kMaxLayers + 2] += tw1 - tw0;
+                a.prof[4 * kMaxLayers + 3] += wall_clock64() - tw1;
             }
         }
     }
@@ -1284,7 +1290,7 @@ int fill_args(basic_scanline_plan *p, ScanArgs &a, int batch, int h, int w, cons
 
 // BASIC_SCAN_PROFILE=1 (debugging aid): where does workgroup 0 spend a coding step?  Synchronises the stream.
 struct ScanProfile {
-    static constexpr int kSlots = 4 * kMaxLayers + 2;
+    static constexpr int kSlots = 4 * kMaxLayers + 4;
     long long *d = nullptr;
     int begin(ScanArgs &a, hipStream_t st)
     {
@@ -1306,8 +1312,10 @@ struct ScanProfile {
         fprintf(stderr, "scan-line %s profile (workgroup 0; 10 ns ticks per coding step: stage+wait / dots / finish / gauss): ", what);
         for (int l = 0; l < a.nlayers; ++l)
             fprintf(stderr, "L%d %.1f / %.1f / %.1f / %.1f | ", l, h[4 * l] / steps, h[4 * l + 1] / steps, h[4 * l + 2] / steps, h[4 * l + 3] / steps);
-        fprintf(stderr, "loop %.1f ticks per step, %.2f shader clocks per tick\n", h[4 * kMaxLayers + 1] / steps,
+        fprintf(stderr, "loop %.1f ticks per step, %.2f shader clocks per tick", h[4 * kMaxLayers + 1] / steps,
                 h[4 * kMaxLayers + 1] ? static_cast<double>(h[4 * kMaxLayers]) / h[4 * kMaxLayers + 1] : 0.0);
+        if (h[4 * kMaxLayers + 3]) fprintf(stderr, " | decoder wave of stream 0: waiting %.1f, decoding %.1f", h[4 * kMaxLayers + 2] / steps, h[4 * kMaxLayers + 3] / steps);
+        fprintf(stderr, "\n");
     }
 };
 

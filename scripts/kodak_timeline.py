@@ -10,7 +10,7 @@ f = glob.glob(d + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 def nm(r):
     return r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
-ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), nm(r), r.get("Stream_Id", "?")) for r in rows)
+ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), nm(r), r.get("Stream_Id", "?") + "/q" + r.get("Queue_Id", "?")) for r in rows)
 t_end = max(e[1] for e in ev)
 tot = defaultdict(lambda: [0, 0, 0])
 for s, e, n, st in ev:
@@ -26,7 +26,7 @@ for s, e, n, st in ev:
     if s >= t0:
         acc += 1
         if e - s > 50000 or (last[st] and s - last[st] > 300000):
-            print(f"{(s - t0) / 1e6:9.3f} {(e - s) / 1e3:9.0f} {(s - last[st]) / 1e3 if last[st] else 0:9.0f} {st:>3s} {n[:64]}")
+            print(f"{(s - t0) / 1e6:9.3f} {(e - s) / 1e3:9.0f} {(s - last[st]) / 1e3 if last[st] else 0:9.0f} {st:>6s} {n[:64]}")
     last[st] = max(last[st], e)
 print(f"kernels in window: {acc}")
 
@@ -37,6 +37,6 @@ base = ev[0][0]
 for s, e, n, st in ev:
     if "scanline_p" in n:
         inflight = sum(1 for s2, e2, _, _ in pers if s2 <= s < e2)
-        print(f"{(s - base) / 1e6:10.2f} {(e - s) / 1e6:8.2f} {st:>3s} {inflight:2d}  {n[:50]}")
+        print(f"{(s - base) / 1e6:10.2f} {(e - s) / 1e6:8.2f} {st:>6s} {inflight:2d}  {n[:50]}")
     elif e - s > 5000000:
-        print(f"{(s - base) / 1e6:10.2f} {(e - s) / 1e6:8.2f} {st:>3s}     {n[:50]}")
+        print(f"{(s - base) / 1e6:10.2f} {(e - s) / 1e6:8.2f} {st:>6s}     {n[:50]}")

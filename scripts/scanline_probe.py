@@ -20,7 +20,7 @@ for B, H, W in shapes:
     y = (torch.randn(B, C, H, W, generator=g) * 2).cuda()
     prior = torch.stack([torch.randn(B, C, H, W, generator=g), torch.rand(B, C, H, W, generator=g) * 3 + 0.1], 2).reshape(B, 2 * C, H, W).cuda()
     res = {}
-    for mode in (False, True):
+    for mode in ((True,) if os.environ.get("PROBE_PERSISTENT_ONLY") else (False, True)):
         c.use_persistent_scanline = mode
         c.persistent_scanline_max_batch = 1024
         for what in ("enc", "dec"):
@@ -37,5 +37,6 @@ for B, H, W in shapes:
                 out = fn()
             torch.cuda.synchronize()
             res[(mode, what)] = (time.time() - t0) / n * 1e3
+    res.setdefault((False, 'enc'), float('nan')); res.setdefault((False, 'dec'), float('nan'))
     print(f"B={B:3d} {H}x{W}: per-step enc {res[(False, 'enc')]:8.2f} ms dec {res[(False, 'dec')]:8.2f} ms | persistent enc {res[(True, 'enc')]:8.2f} ms dec {res[(True, 'dec')]:8.2f} ms"
           f"   ({H * W} steps: {res[(True, 'enc')] / (H * W) * 1e3:.1f} us/step enc)", flush=True)
