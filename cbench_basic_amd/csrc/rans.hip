@@ -130,8 +130,11 @@ int upload_tables(basic_rans_tables *t)
         if (size > 4096) { t->fast_ok = false; break; }
         t->meta[r] = static_cast<uint32_t>(t->image.size() * 4);  // byte offset
         if (size <= 64) {
-            // lane l: { entry l (search key), start and frequency of symbol l - 1, pad }
-            for (int l = 0; l < 64; ++l) {
+            // lane l: { entry l (search key), start and frequency of symbol l - 1, pad }.  Only the row's `size` lanes are
+            // stored: the lanes past them read whatever follows (the next row, the pad behind the last one), and are never
+            // selected -- the first lane whose key exceeds the coded value lies inside the row, whose last key is the total
+            // 2^precision.  A set of many short rows (a factorised prior: one row per channel) then still fits the LDS.
+            for (int l = 0; l < size; ++l) {
                 uint32_t key = 0x7FFFFFFFu, st = 0, fq = 0;
                 if (l < size) key = static_cast<uint32_t>(row[l]);
                 if (l >= 1 && l < size) {
