@@ -1104,8 +1104,12 @@ extern "C" int basic_scanline_plan_create(const float *ctx_weight, const float *
         // row = its groups' channels + kBlockPad floats after every block, + one more pad so that consecutive rows shift banks
         p->kpad[l] = (p->kdim[l] / p->kgroup[l]) * (p->kgroup[l] + kBlockPad * p->bpg[l]) + (p->vec4 ? 4 : 1);
     }
-    // workgroups: the fewest (<= 192: the decoder adds its own) whose weight slices fit ~112 KB of LDS; every layer in whole rows per workgroup, the
+    // workgroups: the fewest (<= 192: the decoder adds its own) whose weight slices fit ~126 KB of LDS (BaSIC, C = 192: 64 --
+    // three launches of concurrent stream workers then hold 195 of the 256 compute units and leave the rest to the transforms;
+    // with 112 KB it was 77 and the workers' transforms queued behind the persistent launches); every layer in whole rows per workgroup, the
     // last one in whole (mean, scale) pairs
+    const char *wk = getenv("BASIC_SCAN_WEIGHT_KB");   // experiments: LDS budget of a workgroup's weight slices
+    const size_t weight_kb = wk && atoi(wk) >= 16 && atoi(wk) <= 150 ? static_cast<size_t>(atoi(wk)) : 126;
     int nwg = 1;
     for (;; ++nwg) {
         int floats = 0;
@@ -1114,7 +1118,7 @@ extern "C" int basic_scanline_plan_create(const float *ctx_weight, const float *
             if (l == p->nlayers - 1) rpw = (rpw + 1) & ~1;
             floats += rpw * p->kpad[l];
         }
-        if (floats * sizeof(float) <= 112 * 1024 || nwg >= 192) { p->weight_floats = floats; break; }
+        if (floats * sizeof(float) <= weight_kb * 1024 || nwg >= 192) { p->weight_floats = floats; break; }
     }
     if (p->weight_floats * sizeof(float) > 150 * 1024) {
         delete p;
