@@ -13,6 +13,7 @@
 // clamp / bypass split, the symbol's two transform words: one coalesced gather), the chain itself runs on wave-uniform
 // values; the state-dependent lookups hit the table set in L2 (a set of R rows is R x 2^L x 2 bytes for the encoder,
 // R x 2^L x 4 bytes for the decoder).
+#include <type_traits>
 #include "common.h"
 
 #include <algorithm>
@@ -295,10 +296,15 @@ struct BitSink {
     uint64_t acc;        // pending bits, low `fill` valid
     uint32_t fill;
     int64_t total_bits;  // set by finish()
-    __device__ __forceinline__ void put(uint32_t value, uint32_t nbits, int lane)
+    // append a field without flushing: the caller flushes before fill + nbits could pass 64 (fill < 32 after flush32, fields <= 16 bits:
+    // two fields per flush)
+    __device__ __forceinline__ void add(uint32_t value, uint32_t nbits)
     {
         acc |= static_cast<uint64_t>(value & ((1u << nbits) - 1u)) << fill;   // nbits <= 16
         fill += nbits;
+    }
+    __device__ __forceinline__ void flush32(int lane)
+    {
         if (fill >= 32u) {
             if (lane == 0 && nwords < cap_words) words[nwords] = static_cast<uint32_t>(acc);
             ++nwords;
@@ -306,6 +312,7 @@ struct BitSink {
             fill -= 32u;
         }
     }
+    __device__ __forceinline__ void put(uint32_t value, uint32_t nbits, int lane) { add(value, nbits); flush32(lane); }
     __device__ __forceinline__ void finish(int lane)
     {
         total_bits = nwords * 32 + fill;
@@ -316,33 +323,59 @@ struct BitSink {
     }
 };
 
+// The state-dependent images, from the workgroup's LDS copy (LDS: a ds_read with a 32-bit address -- through a generic pointer
+// it would be a flat load with 64-bit address arithmetic on the chain) or from L2
+extern __shared__ uint32_t tans_lds[];
+template <bool LDS> __device__ __forceinline__ uint32_t enc_next(const TansDev &T, uint32_t i)
+{
+    return LDS ? reinterpret_cast<const uint16_t *>(tans_lds)[i] : T.next[i];
+}
+template <bool LDS> __device__ __forceinline__ uint32_t dec_entry(const TansDev &T, uint32_t i) { return LDS ? tans_lds[i] : T.dec[i]; }
+
 // tbase = (row << log) + the symbol's group start - its count: the lookup index is tbase + (state >> nb), inside the row's 2^log
 // entries for every state in [2^log, 2^(log+1)) by the tables' construction (symbols without mass point at entry 1).
-__device__ __forceinline__ void tans_step(const TansDev &T, BitSink &sink, uint32_t &state, uint32_t dbits, uint32_t tbase, int lane)
+template <bool LDS> __device__ __forceinline__ void tans_step(const TansDev &T, BitSink &sink, uint32_t &state, uint32_t dbits, uint32_t tbase, int lane)
 {   // Tans_encodeSymbol, tans.cpp:245-252
     const uint32_t nb = (state + dbits) >> 16;
     sink.put(state, nb, lane);
-    state = T.next[tbase + (state >> nb)];
+    state = enc_next<LDS>(T, tbase + (state >> nb));
     state = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(state)));
 }
 
-__device__ __forceinline__ void tans_step_bypass(const TansDev &T, BitSink &sink, uint32_t &state, uint32_t v, int lane)
+// the same step, the flush test left to the caller (BitSink::add)
+template <bool LDS> __device__ __forceinline__ void tans_step_add(const TansDev &T, BitSink &sink, uint32_t &state, uint32_t dbits, uint32_t tbase)
+{
+    const uint32_t nb = (state + dbits) >> 16;
+    sink.add(state, nb);
+    state = enc_next<LDS>(T, tbase + (state >> nb));
+    state = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(state)));
+}
+
+template <int kFrom, int kTo, class F> __device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (kFrom < kTo) {
+        f(std::integral_constant<int, kFrom>{});
+        static_for<kFrom + 1, kTo>(f);
+    }
+}
+
+template <bool LDS> __device__ __forceinline__ void tans_step_bypass(const TansDev &T, BitSink &sink, uint32_t &state, uint32_t v, int lane)
 {
     const uint2 e = T.sym[static_cast<size_t>(T.rows) * T.max_nsym + v];
-    tans_step(T, sink, state, e.x, (static_cast<uint32_t>(T.rows) << T.log) + e.y, lane);
+    tans_step<LDS>(T, sink, state, e.x, (static_cast<uint32_t>(T.rows) << T.log) + e.y, lane);
 }
 
 // One wavefront per stream.  out_info[stream] = { total bits incl. final state and end mark, coded symbols incl. bypass }.
+template <bool LDS>
 __global__ __launch_bounds__(64) void tans_encode_kernel(TansDev T, const int32_t *__restrict__ symbols, const int32_t *__restrict__ indexes,
                                                          const int64_t *__restrict__ seg, uint32_t *out_words, int64_t slot_words,
                                                          int64_t *out_info)
 {
-    extern __shared__ uint32_t tans_lds[];
-    if (T.lds_words > 0) {   // a lookup that depends on the previous state then costs an LDS access instead of an L2 round trip
+    __builtin_amdgcn_s_setprio(3);   // a serial chain: never lose the issue arbitration (see rans_encode_fast_kernel)
+    if (LDS) {   // a lookup that depends on the previous state then costs an LDS access instead of an L2 round trip
         const uint32_t *src = reinterpret_cast<const uint32_t *>(T.next);
         for (int e = threadIdx.x; e < T.lds_words; e += 64) tans_lds[e] = src[e];
         __syncthreads();
-        T.next = reinterpret_cast<const uint16_t *>(tans_lds);
     }
     const int stream = blockIdx.x, lane = threadIdx.x;
     const int64_t beg = seg[stream], n = seg[stream + 1] - beg;
@@ -351,11 +384,13 @@ __global__ __launch_bounds__(64) void tans_encode_kernel(TansDev T, const int32_
     uint32_t state = 1u << T.log;
     int64_t coded = 0;
     const uint32_t bprec = static_cast<uint32_t>(T.bypass_precision), maxbv = (1u << bprec) - 1u;
-    for (int64_t hi = n; hi > 0; hi -= 64) {
-        const int64_t i = hi - 64 + lane;   // lane 63 holds the chunk's last symbol
-        uint32_t dbits = 0, tbase = 0, raw = 0;
-        bool is_bypass = false;
-        if (i >= 0) {
+    // per chunk of 64 symbols (lane 63 holds the chunk's last symbol): row, offset, clamp / bypass split, the symbol's transform
+    // pair -- three dependent gathers, so chunk k + 1 is prepared while chunk k runs through the chain
+    struct Prepared { uint32_t dbits, tbase, raw; bool is_bypass; };
+    auto prepare = [&](int64_t hi) -> Prepared {
+        Prepared q{0u, 0u, 0u, false};
+        const int64_t i = hi - 64 + lane;
+        if (hi > 0 && i >= 0) {
             int32_t row = idx[i];
             if (T.ar_tab) {
                 const int64_t g = beg + i;
@@ -373,27 +408,55 @@ __global__ __launch_bounds__(64) void tans_encode_kernel(TansDev T, const int32_
             const int2 ri = T.rowinfo[row];
             const int32_t max_value = ri.y;
             int32_t value = sym[i] - ri.x;
-            if (value < 0) { raw = static_cast<uint32_t>(-2 * value - 1); value = max_value; }
-            else if (value >= max_value) { raw = static_cast<uint32_t>(2 * (value - max_value)); value = max_value; }
-            is_bypass = T.bypass && value == max_value;
+            if (value < 0) { q.raw = static_cast<uint32_t>(-2 * value - 1); value = max_value; }
+            else if (value >= max_value) { q.raw = static_cast<uint32_t>(2 * (value - max_value)); value = max_value; }
+            q.is_bypass = T.bypass && value == max_value;
             const uint2 e = T.sym[static_cast<size_t>(row) * T.max_nsym + value];
-            dbits = e.x; tbase = (static_cast<uint32_t>(row) << T.log) + e.y;   // e.y is an int32 offset: unsigned wrap-around adds it
+            q.dbits = e.x; q.tbase = (static_cast<uint32_t>(row) << T.log) + e.y;   // e.y is an int32 offset: unsigned wrap-around adds it
         }
+        return q;
+    };
+    Prepared nxt = prepare(n);
+    for (int64_t hi = n; hi > 0; hi -= 64) {
+        const Prepared cur = nxt;
+        nxt = prepare(hi - 64);
+        const uint32_t dbits = cur.dbits, tbase = cur.tbase, raw = cur.raw;
+        const bool is_bypass = cur.is_bypass;
         const uint64_t bypass_mask = __ballot(is_bypass);
         const int j_lo = hi >= 64 ? 0 : static_cast<int>(64 - hi);
-        for (int j = 63; j >= j_lo; --j) {
+        auto slow_symbol = [&](int j) {
             if ((bypass_mask >> j) & 1ull) {
                 // decode order: sentinel, digit count (unary in units of maxbv), digits low first  =>  coded reversed
                 const uint32_t r = bcast(raw, j);
                 int nb = 0;
                 while (nb * bprec < 32u && (r >> (nb * bprec)) != 0u) ++nb;
-                for (int k = nb - 1; k >= 0; --k) tans_step_bypass(T, sink, state, (r >> (k * bprec)) & maxbv, lane);
-                tans_step_bypass(T, sink, state, static_cast<uint32_t>(nb) % maxbv, lane);
-                for (uint32_t k = 0; k < static_cast<uint32_t>(nb) / maxbv; ++k) tans_step_bypass(T, sink, state, maxbv, lane);
+                for (int k = nb - 1; k >= 0; --k) tans_step_bypass<LDS>(T, sink, state, (r >> (k * bprec)) & maxbv, lane);
+                tans_step_bypass<LDS>(T, sink, state, static_cast<uint32_t>(nb) % maxbv, lane);
+                for (uint32_t k = 0; k < static_cast<uint32_t>(nb) / maxbv; ++k) tans_step_bypass<LDS>(T, sink, state, maxbv, lane);
                 coded += nb + 1 + static_cast<int>(static_cast<uint32_t>(nb) / maxbv);
             }
-            tans_step(T, sink, state, bcast(dbits, j), bcast(tbase, j), lane);
-            ++coded;
+            tans_step<LDS>(T, sink, state, bcast(dbits, j), bcast(tbase, j), lane);
+        };
+        if (j_lo == 0) {
+            // a full chunk, eight symbols at a time (lane 63 first): a group without a bypass symbol runs unrolled -- lane ids
+            // as immediates, two bit fields per flush test; the chain is ~15 instructions + one table lookup per symbol
+            static_for<0, 8>([&](auto gc) {
+                constexpr int G = 7 - decltype(gc)::value;
+                if (((bypass_mask >> (8 * G)) & 0xFFull) == 0ull) {
+                    static_for<0, 4>([&](auto pc) {
+                        constexpr int J = 8 * G + 7 - 2 * decltype(pc)::value;
+                        tans_step_add<LDS>(T, sink, state, bcast(dbits, J), bcast(tbase, J));
+                        tans_step_add<LDS>(T, sink, state, bcast(dbits, J - 1), bcast(tbase, J - 1));
+                        sink.flush32(lane);
+                    });
+                } else {
+                    for (int j = 8 * G + 7; j >= 8 * G; --j) slow_symbol(j);
+                }
+            });
+            coded += 64;
+        } else {
+            for (int j = 63; j >= j_lo; --j) slow_symbol(j);
+            coded += 64 - j_lo;
         }
     }
     sink.put(state, static_cast<uint32_t>(T.log), lane);   // Tans_flushCState, tans.cpp:254-258
@@ -405,31 +468,60 @@ __global__ __launch_bounds__(64) void tans_encode_kernel(TansDev T, const int32_
     }
 }
 
-// Bit source of one stream: fields come off the top, below the end mark.  `c` holds the unread bits [lo, lo + have) with
-// lo a multiple of 8; below the stream's first byte it supplies zeros (the reference's behaviour there is undefined).
+// Bit source of one stream: fields come off the top, below the end mark.  The stream is cut into 32-bit words counted from
+// its first byte; `c` holds the unread bits [lo, lo + have) with lo a multiple of 32; below the stream's first byte it
+// supplies zeros (the reference's behaviour there is undefined).  64 words live in a register window (lane k = word
+// wbase + k) and are handed out by lane broadcast: no memory access on the coder's serial chain except one window load
+// per 2,048 bits.
 struct BitSource {
     const uint8_t *bytes;
-    int64_t lo;          // bit index of the lowest bit held
+    int64_t len;         // bytes in the stream
+    int64_t lo;          // bit index of the lowest bit held (multiple of 32)
     uint64_t c;
     uint32_t have;
-    __device__ __forceinline__ void refill()
+    int64_t wbase;       // first word of the window (multiple of 64)
+    uint32_t window;     // lane k: word wbase + k (bytes past the stream read as 0)
+    __device__ __forceinline__ uint32_t load_word(int64_t k) const
     {
-        while (have < 32u) {
-            if (lo >= 32) {
-                const int64_t b = (lo >> 3) - 4;
-                const uint32_t w = static_cast<uint32_t>(bytes[b]) | (static_cast<uint32_t>(bytes[b + 1]) << 8) |
-                                   (static_cast<uint32_t>(bytes[b + 2]) << 16) | (static_cast<uint32_t>(bytes[b + 3]) << 24);
-                c = (c << 32) | w;
+        const int64_t b = 4 * k;
+        uint32_t w = 0;
+        if (b + 3 < len) {
+            w = static_cast<uint32_t>(bytes[b]) | (static_cast<uint32_t>(bytes[b + 1]) << 8) | (static_cast<uint32_t>(bytes[b + 2]) << 16) |
+                (static_cast<uint32_t>(bytes[b + 3]) << 24);
+        } else {
+            for (int i = 0; i < 4; ++i)
+                if (b + i < len) w |= static_cast<uint32_t>(bytes[b + i]) << (8 * i);
+        }
+        return w;
+    }
+    __device__ __forceinline__ void fill_window(int64_t k, int lane)   // window that holds word k
+    {
+        wbase = k & ~int64_t{63};
+        window = load_word(wbase + lane);
+    }
+    // data_bits = bits below the end mark
+    __device__ __forceinline__ void init(const uint8_t *p, int64_t nbytes, int64_t data_bits, int lane)
+    {
+        bytes = p; len = nbytes;
+        const int64_t wtop = data_bits > 0 ? (data_bits - 1) >> 5 : 0;
+        fill_window(wtop, lane);
+        lo = wtop * 32;
+        have = static_cast<uint32_t>(data_bits - lo);   // 0..32
+        const uint32_t w = bcast(window, static_cast<int>(wtop - wbase));
+        c = have >= 32u ? w : (w & ((1u << have) - 1u));
+    }
+    __device__ __forceinline__ void refill(int lane)
+    {
+        if (have < 32u) {
+            uint32_t w = 0;
+            if (lo > 0) {
+                const int64_t k = (lo >> 5) - 1;
+                if (k < wbase) fill_window(k, lane);
+                w = bcast(window, static_cast<int>(k - wbase));
                 lo -= 32;
-                have += 32u;
-            } else if (lo > 0) {
-                c = (c << 8) | bytes[(lo >> 3) - 1];
-                lo -= 8;
-                have += 8u;
-            } else {
-                c <<= 24;
-                have += 24u;
             }
+            c = (c << 32) | w;
+            have += 32u;
         }
     }
     __device__ __forceinline__ uint32_t take(uint32_t nbits)   // nbits <= 16, have >= nbits
@@ -439,25 +531,25 @@ struct BitSource {
     }
 };
 
-__device__ __forceinline__ uint32_t tans_unstep(const TansDev &T, BitSource &src, uint32_t &state, uint32_t row)
+template <bool LDS> __device__ __forceinline__ uint32_t tans_unstep(const TansDev &T, BitSource &src, uint32_t &state, uint32_t row)
 {   // Tans_decodeSymbol, tans.cpp:338-364
-    uint32_t e = T.dec[(static_cast<size_t>(row) << T.log) + (state & ((1u << T.log) - 1u))];
+    uint32_t e = dec_entry<LDS>(T, (row << T.log) + (state & ((1u << T.log) - 1u)));
     e = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(e)));
-    src.refill();
+    src.refill(static_cast<int>(threadIdx.x));
     state = (e & 0xFFFu) + src.take((e >> 12) & 0xFu);
     return e >> 16;
 }
 
 // One wavefront per stream: stream s = bytes[byte_off[s] .. byte_off[s+1]).  status[s]: 0 ok, 1 empty stream / no end mark.
+template <bool LDS>
 __global__ __launch_bounds__(64) void tans_decode_kernel(TansDev T, const uint8_t *__restrict__ bytes_all, const int64_t *__restrict__ byte_off,
                                                          const int32_t *__restrict__ indexes, const int64_t *__restrict__ seg,
                                                          int32_t *out_symbols, int32_t *status)
 {
-    extern __shared__ uint32_t tans_lds[];
-    if (T.lds_words > 0) {
+    __builtin_amdgcn_s_setprio(3);   // a serial chain: never lose the issue arbitration (see rans_encode_fast_kernel)
+    if (LDS) {
         for (int e = threadIdx.x; e < T.lds_words; e += 64) tans_lds[e] = T.dec[e];
         __syncthreads();
-        T.dec = tans_lds;
     }
     const int stream = blockIdx.x, lane = threadIdx.x;
     const int64_t beg = seg[stream], n = seg[stream + 1] - beg;
@@ -470,21 +562,63 @@ __global__ __launch_bounds__(64) void tans_decode_kernel(TansDev T, const uint8_
         if (lane == 0) status[stream] = 1;
         return;
     }
-    const uint32_t top = 31u - static_cast<uint32_t>(__builtin_clz(last));
-    BitSource src{bytes, (len - 1) * 8, last & ((1u << top) - 1u), top};
-    src.refill();
+    const uint32_t top = 31u - static_cast<uint32_t>(__builtin_clz(last));   // the end mark's bit in the last byte
+    BitSource src;
+    src.init(bytes, len, (len - 1) * 8 + top, lane);
+    src.refill(lane);
     uint32_t state = src.take(static_cast<uint32_t>(T.log));   // Tans_initDState, tans.cpp:330-335
     const uint32_t bprec = static_cast<uint32_t>(T.bypass_precision), maxbv = (1u << bprec) - 1u;
+    // a chunk's rows and row info are two dependent gathers: requested one chunk ahead
+    struct Rows { uint32_t row; int2 ri; };
+    auto rows_of = [&](int64_t c0) -> Rows {
+        Rows r{0u, make_int2(0, 1)};
+        const int64_t i = c0 + lane;
+        if (i < n) {
+            r.row = static_cast<uint32_t>(T.ar_tab ? idx[i] : clampi(idx[i], 0, T.rows - 1));
+            if (!T.ar_tab) r.ri = T.rowinfo[r.row];
+        }
+        return r;
+    };
+    Rows nxt = rows_of(0);
     for (int64_t c0 = 0; c0 < n; c0 += 64) {
         const int64_t i = c0 + lane;
-        uint32_t row_l = 0;
-        int2 ri_l = make_int2(0, 1);
-        if (i < n) {
-            row_l = static_cast<uint32_t>(T.ar_tab ? idx[i] : clampi(idx[i], 0, T.rows - 1));
-            if (!T.ar_tab) ri_l = T.rowinfo[row_l];
-        }
+        const Rows cur = nxt;
+        nxt = rows_of(c0 + 64);
+        const uint32_t row_l = cur.row;
+        const int2 ri_l = cur.ri;
         int32_t result = 0;
         const int cnt = (n - c0) < 64 ? static_cast<int>(n - c0) : 64;
+        if (!T.ar_tab && cnt == 64) {
+            // a full chunk without AR remap, unrolled: lane ids as immediates, the row's table base prepared per lane, the
+            // offset added lane-parallel after the chunk -- what stays per symbol is the lookup, the refill test, the field
+            // and the bypass test
+            const uint32_t base_l = row_l << T.log, esc_l = T.bypass ? static_cast<uint32_t>(ri_l.y) : 0xFFFFFFFFu;
+            const uint32_t smask = (1u << T.log) - 1u;
+            static_for<0, 64>([&](auto jc) {
+                constexpr int J = decltype(jc)::value;
+                int32_t &res = result;   // (generic lambda: the asm operand below needs an odr-use to capture it)
+                uint32_t e = dec_entry<LDS>(T, bcast(base_l, J) + (state & smask));
+                e = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(e)));
+                src.refill(lane);
+                state = (e & 0xFFFu) + src.take((e >> 12) & 0xFu);
+                int32_t value = static_cast<int32_t>(e >> 16);
+                if (__builtin_expect(static_cast<uint32_t>(value) == bcast(esc_l, J), 0)) {
+                    const int32_t max_value = value;
+                    uint32_t v = tans_unstep<LDS>(T, src, state, static_cast<uint32_t>(T.rows)), nb = v;
+                    while (v == maxbv && nb < 64u * maxbv) { v = tans_unstep<LDS>(T, src, state, static_cast<uint32_t>(T.rows)); nb += v; }
+                    uint32_t raw = 0;
+                    for (uint32_t k = 0; k < nb; ++k) {
+                        const uint32_t d = tans_unstep<LDS>(T, src, state, static_cast<uint32_t>(T.rows));
+                        if (k * bprec < 32u) raw |= d << (k * bprec);
+                    }
+                    value = static_cast<int32_t>(raw >> 1);
+                    if (raw & 1u) value = -value - 1; else value += max_value;
+                }
+                asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(res) : "s"(value), "n"(J));
+            });
+            out[i] = result + ri_l.x;
+            continue;
+        }
         for (int j = 0; j < cnt; ++j) {
             int32_t row = static_cast<int32_t>(bcast(row_l, j));
             int32_t offset, max_value;
@@ -506,13 +640,13 @@ __global__ __launch_bounds__(64) void tans_decode_kernel(TansDev T, const uint8_
                 offset = static_cast<int32_t>(bcast(static_cast<uint32_t>(ri_l.x), j));
                 max_value = static_cast<int32_t>(bcast(static_cast<uint32_t>(ri_l.y), j));
             }
-            int32_t value = static_cast<int32_t>(tans_unstep(T, src, state, static_cast<uint32_t>(row)));
+            int32_t value = static_cast<int32_t>(tans_unstep<LDS>(T, src, state, static_cast<uint32_t>(row)));
             if (T.bypass && value == max_value) {
-                uint32_t v = tans_unstep(T, src, state, static_cast<uint32_t>(T.rows)), nb = v;
-                while (v == maxbv && nb < 64u * maxbv) { v = tans_unstep(T, src, state, static_cast<uint32_t>(T.rows)); nb += v; }
+                uint32_t v = tans_unstep<LDS>(T, src, state, static_cast<uint32_t>(T.rows)), nb = v;
+                while (v == maxbv && nb < 64u * maxbv) { v = tans_unstep<LDS>(T, src, state, static_cast<uint32_t>(T.rows)); nb += v; }
                 uint32_t raw = 0;
                 for (uint32_t k = 0; k < nb; ++k) {
-                    const uint32_t d = tans_unstep(T, src, state, static_cast<uint32_t>(T.rows));
+                    const uint32_t d = tans_unstep<LDS>(T, src, state, static_cast<uint32_t>(T.rows));
                     if (k * bprec < 32u) raw |= d << (k * bprec);
                 }
                 value = static_cast<int32_t>(raw >> 1);
@@ -565,9 +699,11 @@ extern "C" int basic_tans_encode_batch_dev(const basic_tans_tables *t, const int
     TansDev T = dev_view(t);
     const size_t lds = tans_lds_bytes(t, false);
     T.lds_words = static_cast<int>(lds / 4);
-    if (lds > 48 * 1024) BASIC_HIP_TRY(ensure_max_lds(reinterpret_cast<const void *>(tans_encode_kernel)));
-    hipLaunchKernelGGL(tans_encode_kernel, dim3(nstreams), dim3(64), lds, as_stream(hip_stream), T, d_symbols, d_indexes, d_seg,
-                       d_out_words, slot_words, d_out_info);
+    if (lds > 48 * 1024) BASIC_HIP_TRY(ensure_max_lds(reinterpret_cast<const void *>(tans_encode_kernel<true>)));
+    if (lds) hipLaunchKernelGGL(tans_encode_kernel<true>, dim3(nstreams), dim3(64), lds, as_stream(hip_stream), T, d_symbols, d_indexes, d_seg,
+                                d_out_words, slot_words, d_out_info);
+    else hipLaunchKernelGGL(tans_encode_kernel<false>, dim3(nstreams), dim3(64), 0, as_stream(hip_stream), T, d_symbols, d_indexes, d_seg,
+                            d_out_words, slot_words, d_out_info);
     BASIC_HIP_TRY(hipGetLastError());
     return BASIC_OK;
 }
@@ -583,9 +719,11 @@ extern "C" int basic_tans_decode_batch_dev(const basic_tans_tables *t, const uin
     TansDev T = dev_view(t);
     const size_t lds = tans_lds_bytes(t, true);
     T.lds_words = static_cast<int>(lds / 4);
-    if (lds > 48 * 1024) BASIC_HIP_TRY(ensure_max_lds(reinterpret_cast<const void *>(tans_decode_kernel)));
-    hipLaunchKernelGGL(tans_decode_kernel, dim3(nstreams), dim3(64), lds, as_stream(hip_stream), T, d_bytes, d_byte_off, d_indexes,
-                       d_seg, d_out_symbols, d_status);
+    if (lds > 48 * 1024) BASIC_HIP_TRY(ensure_max_lds(reinterpret_cast<const void *>(tans_decode_kernel<true>)));
+    if (lds) hipLaunchKernelGGL(tans_decode_kernel<true>, dim3(nstreams), dim3(64), lds, as_stream(hip_stream), T, d_bytes, d_byte_off, d_indexes,
+                                d_seg, d_out_symbols, d_status);
+    else hipLaunchKernelGGL(tans_decode_kernel<false>, dim3(nstreams), dim3(64), 0, as_stream(hip_stream), T, d_bytes, d_byte_off, d_indexes,
+                            d_seg, d_out_symbols, d_status);
     BASIC_HIP_TRY(hipGetLastError());
     return BASIC_OK;
 }
@@ -652,9 +790,11 @@ extern "C" int basic_tans_encode_host(const basic_tans_tables *t, const int32_t 
     if (rc) return rc;
     const size_t lds = n >= 2048 ? tans_lds_bytes(t, false) : 0;   // short streams: the copy would cost more than it saves
     T.lds_words = static_cast<int>(lds / 4);
-    if (lds > 48 * 1024) BASIC_HIP_TRY(ensure_max_lds(reinterpret_cast<const void *>(tans_encode_kernel)));
-    hipLaunchKernelGGL(tans_encode_kernel, dim3(1), dim3(64), lds, nullptr, T, b_sym.as<int32_t>(), b_idx.as<int32_t>(), b_seg.as<int64_t>(),
-                       b_out.as<uint32_t>(), slot_words, b_info.as<int64_t>());
+    if (lds > 48 * 1024) BASIC_HIP_TRY(ensure_max_lds(reinterpret_cast<const void *>(tans_encode_kernel<true>)));
+    if (lds) hipLaunchKernelGGL(tans_encode_kernel<true>, dim3(1), dim3(64), lds, nullptr, T, b_sym.as<int32_t>(), b_idx.as<int32_t>(), b_seg.as<int64_t>(),
+                                b_out.as<uint32_t>(), slot_words, b_info.as<int64_t>());
+    else hipLaunchKernelGGL(tans_encode_kernel<false>, dim3(1), dim3(64), 0, nullptr, T, b_sym.as<int32_t>(), b_idx.as<int32_t>(), b_seg.as<int64_t>(),
+                            b_out.as<uint32_t>(), slot_words, b_info.as<int64_t>());
     BASIC_HIP_TRY(hipGetLastError());
     int64_t info[2] = {0, 0};
     BASIC_HIP_TRY(hipMemcpy(info, b_info.p, sizeof(info), hipMemcpyDeviceToHost));
@@ -695,9 +835,11 @@ extern "C" int basic_tans_decode_host(const basic_tans_tables *t, const uint8_t 
     if (rc) return rc;
     const size_t lds = n >= 2048 ? tans_lds_bytes(t, true) : 0;
     T.lds_words = static_cast<int>(lds / 4);
-    if (lds > 48 * 1024) BASIC_HIP_TRY(ensure_max_lds(reinterpret_cast<const void *>(tans_decode_kernel)));
-    hipLaunchKernelGGL(tans_decode_kernel, dim3(1), dim3(64), lds, nullptr, T, b_bytes.as<uint8_t>(), b_boff.as<int64_t>(), b_idx.as<int32_t>(),
-                       b_seg.as<int64_t>(), b_out.as<int32_t>(), b_status.as<int32_t>());
+    if (lds > 48 * 1024) BASIC_HIP_TRY(ensure_max_lds(reinterpret_cast<const void *>(tans_decode_kernel<true>)));
+    if (lds) hipLaunchKernelGGL(tans_decode_kernel<true>, dim3(1), dim3(64), lds, nullptr, T, b_bytes.as<uint8_t>(), b_boff.as<int64_t>(), b_idx.as<int32_t>(),
+                                b_seg.as<int64_t>(), b_out.as<int32_t>(), b_status.as<int32_t>());
+    else hipLaunchKernelGGL(tans_decode_kernel<false>, dim3(1), dim3(64), 0, nullptr, T, b_bytes.as<uint8_t>(), b_boff.as<int64_t>(), b_idx.as<int32_t>(),
+                            b_seg.as<int64_t>(), b_out.as<int32_t>(), b_status.as<int32_t>());
     BASIC_HIP_TRY(hipGetLastError());
     int32_t status = 0;
     BASIC_HIP_TRY(hipMemcpy(&status, b_status.p, sizeof(status), hipMemcpyDeviceToHost));
