@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--total", type=int, default=256, help="images per step over ALL GPUs in the strong-scaling leg (cfg-5)")
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--workers", type=int, default=None,
-                    help="concurrent stream workers per GPU (1 = plain sequential calls); default 3 for the headline, 4 for --workload checkerboard, "
+                    help="concurrent stream workers per GPU (1 = plain sequential calls); default 3 for the headline, 6 for --workload checkerboard, "
                          "3 for --workload basic")
     ap.add_argument("--shard-by", default="steps", choices=["steps", "images"],
                     help="how the K steps are spread over the workers: steps = every worker codes WHOLE batches, step k on worker k mod W "
@@ -232,9 +232,10 @@ def masked_conv_flops(plan_cin, plan_cout, k, topo_in, topo_out, allow_same, pos
 def run_ar_workload(args):
     """Extra bench lines for the AR parity configurations: one codec, one stream (module path), HIP-event time of every
     masked-convolution launch of one measured encode + decode pass for the roofline of masked_conv_pos_kernel."""
-    # measured (profiles/r02_ar_codecs.txt): checkerboard 359 / 385 / 430 / 451 / 454 Mpix/s with 1 / 2 / 3 / 4 / 5 workers; scan-line
+    # measured (profiles/r02_ar_codecs.txt): checkerboard 359 / 385 / 430 / 451 / 454 Mpix/s with 1 / 2 / 3 / 4 / 5 workers; round 3 (LDS-DMA
+    # masked convolution): 474 / 483 / 492-500 with 4 / 5 / 6; BaSIC at 64 images per step: 94 / 58 / 73 with 3 / 4 / 6; scan-line
     # BaSIC 61 / 92 / 109 / 62 with 1 / 2 / 3 / 4 (four graph-replaying streams fall back to the one-stream rate)
-    workers = max(1, args.workers if args.workers is not None else (4 if args.workload == "checkerboard" else 3))
+    workers = max(1, args.workers if args.workers is not None else (6 if args.workload == "checkerboard" else 3))
     if workers > 1:   # before HIP initialises: one hardware queue per stream; 8 image streams per rANS workgroup (CUs left to the others)
         os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
         os.environ.setdefault("BASIC_RANS_WPB", str(args.rans_waves if args.rans_waves > 0 else 8))
