@@ -33,13 +33,33 @@ __global__ void gc_quantize_index_kernel(const float *__restrict__ y, const floa
                                          float *__restrict__ yhat)
 {
     extern __shared__ float s_table[];
+    __shared__ int s_unsorted;
+    if (threadIdx.x == 0) s_unsorted = 0;
     for (int i = threadIdx.x; i < table_len; i += blockDim.x) s_table[i] = table[i];
     __syncthreads();
+    for (int i = threadIdx.x; i + 1 < table_len; i += blockDim.x)
+        if (!(s_table[i] <= s_table[i + 1])) s_unsorted = 1;
+    __syncthreads();
+    // build_indexes (compressai GaussianConditional): idx = (len - 1) - #{ j < len - 1 : s <= table[j] }.  On a non-decreasing
+    // table (the scale table is: checked above) that count is the number of entries from the first one >= s on, so idx is
+    // that entry's position, found in log2(len) probes instead of len - 1 compares per element (the kernel was VALU-bound at
+    // ten times its HBM time).  NaN and unsorted tables take the counting loop.
+    const bool sorted = s_unsorted == 0;
     for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n;
          i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
         const float s = fmaxf(scales[i], bound);  // LowerBound
-        int idx = table_len - 1;
-        for (int j = 0; j < table_len - 1; ++j) idx -= (s <= s_table[j]) ? 1 : 0;
+        int idx;
+        if (sorted && s == s) {
+            int lo = 0, hi = table_len - 1;   // first j in [0, len - 1) with table[j] >= s, len - 1 if none
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (s_table[mid] < s) lo = mid + 1; else hi = mid;
+            }
+            idx = lo;
+        } else {
+            idx = table_len - 1;
+            for (int j = 0; j < table_len - 1; ++j) idx -= (s <= s_table[j]) ? 1 : 0;
+        }
         const float q = round_even(y[i]);
         symbols[i] = static_cast<int32_t>(q);
         indexes[i] = idx;

@@ -349,6 +349,15 @@ def test_entropy_param_kernels():
     assert torch.equal(idx.cpu(), ref_idx)
     assert torch.equal(sym.cpu(), torch.round(y).int())
     assert torch.equal(yhat.cpu(), torch.round(y))
+    # the index search is a bisection on non-decreasing tables and the reference's counting loop otherwise: table entries hit
+    # exactly, repeated entries, values outside the table, an unsorted table, NaN scales
+    for tab in (table, torch.tensor([0.2, 0.5, 0.5, 0.5, 1.0, 3.0]), torch.tensor([1.0, 0.3, 2.0, 0.7]), torch.tensor([0.8])):
+        s2 = torch.cat([tab, tab * 0.999, tab * 1.001, torch.tensor([0.0, 1e9, float("nan"), 0.11]), s.flatten()[:50]])
+        _, i2, _ = K.gc_quantize_index(torch.zeros_like(s2).cuda(), s2.cuda(), tab.cuda())
+        sb = torch.maximum(s2, torch.tensor(0.11))   # LowerBound (NaN stays NaN in torch; fmaxf drops it)
+        sb = torch.where(torch.isnan(s2), torch.tensor(0.11), sb)
+        want = (len(tab) - 1) - (sb.unsqueeze(1) <= tab[:-1]).sum(1)
+        assert torch.equal(i2.cpu(), want.int()), tab
     z = torch.randn(3, 128, 4, 4, generator=g) * 3
     med = torch.randn(128, generator=g)
     sym, idx, zhat = K.eb_quantize_index(z.cuda(), med.cuda())
