@@ -1070,7 +1070,11 @@ __global__ __launch_bounds__(64 * WPB) void rans_decode_fast_kernel(TablesDev T,
             }
             // result[lane j] = first (one scalar operand per VALU instruction on gfx9: a run-time lane select goes through m0)
             if constexpr (std::is_integral<decltype(jc)>::value)
-                asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(res) : "s"(first), "s"(j) : "m0");
+            {   // m0 is saved and restored inside the statement (a reserved register on a clobber list is not honoured reliably)
+                    uint32_t m0_save;
+                    asm volatile("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1"
+                                 : "+v"(res), "=&s"(m0_save) : "s"(first), "s"(j));
+                }
             else
                 asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(res) : "s"(first), "n"(decltype(jc)::value));
         };

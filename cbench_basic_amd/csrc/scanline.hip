@@ -364,7 +364,11 @@ struct WaveDecoder {
             if (__builtin_expect(x < kRansLow, 0))
                 first = slow_path(e, first, bc32(meta_l, j), static_cast<int32_t>(bc32(static_cast<uint32_t>(size_l), j)), cf, t, lane);
             if constexpr (std::is_integral<decltype(jc)>::value)
-                asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(res) : "s"(first), "s"(j) : "m0");
+            {   // m0 is saved and restored inside the statement (a reserved register on a clobber list is not honoured reliably)
+                    uint32_t m0_save;
+                    asm volatile("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1"
+                                 : "+v"(res), "=&s"(m0_save) : "s"(first), "s"(j));
+                }
             else
                 asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(res) : "s"(first), "n"(decltype(jc)::value));
         };
@@ -456,7 +460,7 @@ template <bool DECODE>
 __global__ __launch_bounds__(kThreads) void scanline_persistent_kernel(const ScanArgs a)
 {
     extern __shared__ float lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tid = threadIdx.x;
     const int wg = blockIdx.x;
     const int HW = a.H * a.W;
     const int last = a.nlayers - 1;
