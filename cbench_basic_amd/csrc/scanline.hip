@@ -598,7 +598,9 @@ __global__ __launch_bounds__(kThreads) void scanline_persistent_kernel(const Sca
 //     coded during the previous step; the other taps' blocks (the first (ntaps - 1) * blocks-per-tap of the canonical
 //     order) are summed one step AHEAD, right after this workgroup has published its context rows and while the next
 //     layer's inputs are still in flight.  On the critical path stay C granules, blocks-per-tap dot products per row
-//     and a short sum, instead of ntaps * C granules and the whole layer;
+//     and a short sum, instead of ntaps * C granules and the whole layer.  (Needs a latent at least ksize / 2 + 2 columns
+//     wide: in a narrower one the tap up and to the right of position p + 1 IS position p or later; the host then takes the
+//     generic kernel);
 //   * a (block, image, row) unit's addresses are computed once per launch (descriptor table in LDS), not with four
 //     integer divisions per unit and step -- a workgroup is four lone waves, each issuing one instruction per ~8-10
 //     clocks, so instruction count IS the latency;
@@ -1275,7 +1277,10 @@ int fill_args(basic_scanline_plan *p, ScanArgs &a, int batch, int h, int w, cons
         const size_t desc_off = early_off + align4(static_cast<size_t>(batch) * p->rpw[0]) +
                                 align4(static_cast<size_t>(batch) * p->rpw[0] * (p->kdim[0] / p->kgroup[0]) * p->bpg[0]);   // early sums + the early blocks' partials
         const size_t flag_off = desc_off + align4(2 * static_cast<size_t>(units_total));
-        bool fits = flag_off + 4 <= static_cast<size_t>(total_floats) && p->vec4 && (p->ntaps - 1) * (p->C / 2) <= kWinU * kThreads;
+        // (the early half of a position's context window must be coded two steps before it: the tap up and to the right by
+        // ksize / 2 columns is w - ksize / 2 positions back, so the latent must be at least ksize / 2 + 2 columns wide)
+        bool fits = flag_off + 4 <= static_cast<size_t>(total_floats) && p->vec4 && (p->ntaps - 1) * (p->C / 2) <= kWinU * kThreads &&
+                    w >= p->ksize / 2 + 2;
         for (int l = 0; l < p->nlayers; ++l) fits = fits && batch * p->rpw[l] <= kThreads;   // one finishing item per thread
         const char *e = getenv("BASIC_SCAN_KERNEL");
         if (e && !strcmp(e, "generic")) fits = false;

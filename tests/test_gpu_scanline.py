@@ -33,7 +33,8 @@ def _coder(kind, C):
 
 @pytest.mark.parametrize("kind,C,B,H,W", [("ctxmodel", 32, 1, 6, 5), ("ctxmodel", 32, 3, 4, 7), ("ctxmodel", 192, 2, 5, 6), ("merger", 32, 2, 5, 5),
                                            ("merger-expand", 16, 1, 4, 4), ("joint", 32, 2, 3, 6), ("ctxmodel", 192, 11, 3, 4), ("ctxmodel", 48, 1, 1, 1),
-                                           ("ctxmodel", 192, 1, 7, 9), ("merger", 192, 2, 4, 5), ("joint", 64, 1, 5, 4), ("ctxmodel", 30, 2, 3, 5)])
+                                           ("ctxmodel", 192, 1, 7, 9), ("merger", 192, 2, 4, 5), ("joint", 64, 1, 5, 4), ("ctxmodel", 30, 2, 3, 5),
+                                           ("ctxmodel", 192, 1, 5, 1), ("ctxmodel", 192, 2, 3, 2), ("ctxmodel", 48, 2, 1, 6)])
 def test_persistent_encode_equals_per_step_path(kind, C, B, H, W):
     coder = _coder(kind, C)
     g = torch.Generator().manual_seed(B * 100 + H * 10 + W)
@@ -58,7 +59,7 @@ def test_persistent_encode_equals_per_step_path(kind, C, B, H, W):
             try:
                 s1, i1, y1, _ = coder._run_encode(y, prior)
             except (RuntimeError, ValueError) as e:
-                assert kernel == "pipelined" and "does not fit" in str(e), e   # batch too large, or a layer size that is not a multiple of 4
+                assert kernel == "pipelined" and "does not fit" in str(e), e   # batch too large, a layer size that is not a multiple of 4, a latent under 4 columns
                 continue
             coder._layers["scanline"][0].check()
             ms, mi = int((s0 != s1).sum()), int((i0 != i1).sum())
@@ -74,7 +75,7 @@ def test_persistent_encode_equals_per_step_path(kind, C, B, H, W):
             ran.append(kernel)
         finally:
             os.environ.pop("BASIC_SCAN_KERNEL", None)
-    assert "generic" in ran and ("pipelined" in ran or not (C in (48, 192) and B <= 2))
+    assert "generic" in ran and ("pipelined" in ran or not (C in (48, 192) and B <= 2 and W >= 4))
     coder.use_persistent_scanline = False
     assert coder.encode(y, prior=prior) == data
     assert torch.equal(coder.decode(data, prior=prior), y1)
