@@ -14,8 +14,9 @@ pytestmark = pytest.mark.gpu
 def _coder(kind, C):
     from cbench_basic_amd.modules.prior_model.prior_coder.pgm_coder import (GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder as Coder,
                                                                             TopoGroupDynamicMaskConv2dContextModel as Ctx)
-    if kind == "ctxmodel":
-        c = Coder(in_channels=C, default_topo_group_method="scanline", topo_group_context_model=Ctx(in_channels=C, out_channels=2 * C))
+    if kind.startswith("ctxmodel"):   # "ctxmodel", or "ctxmodel-k3" for a 3x3 context window (the masked-convolution plans stop at 5x5)
+        ks = int(kind.split("-k")[1]) if "-k" in kind else 5
+        c = Coder(in_channels=C, default_topo_group_method="scanline", topo_group_context_model=Ctx(in_channels=C, out_channels=2 * C, kernel_size=ks))
     elif kind == "merger":
         c = Coder(in_channels=C, default_topo_group_method="scanline")
     elif kind == "merger-expand":
@@ -34,7 +35,8 @@ def _coder(kind, C):
 @pytest.mark.parametrize("kind,C,B,H,W", [("ctxmodel", 32, 1, 6, 5), ("ctxmodel", 32, 3, 4, 7), ("ctxmodel", 192, 2, 5, 6), ("merger", 32, 2, 5, 5),
                                            ("merger-expand", 16, 1, 4, 4), ("joint", 32, 2, 3, 6), ("ctxmodel", 192, 11, 3, 4), ("ctxmodel", 48, 1, 1, 1),
                                            ("ctxmodel", 192, 1, 7, 9), ("merger", 192, 2, 4, 5), ("joint", 64, 1, 5, 4), ("ctxmodel", 30, 2, 3, 5),
-                                           ("ctxmodel", 192, 1, 5, 1), ("ctxmodel", 192, 2, 3, 2), ("ctxmodel", 48, 2, 1, 6)])
+                                           ("ctxmodel", 192, 1, 5, 1), ("ctxmodel", 192, 2, 3, 2), ("ctxmodel", 48, 2, 1, 6),
+                                           ("ctxmodel-k3", 192, 1, 4, 3), ("ctxmodel-k3", 48, 2, 5, 6)])
 def test_persistent_encode_equals_per_step_path(kind, C, B, H, W):
     coder = _coder(kind, C)
     g = torch.Generator().manual_seed(B * 100 + H * 10 + W)
@@ -75,7 +77,8 @@ def test_persistent_encode_equals_per_step_path(kind, C, B, H, W):
             ran.append(kernel)
         finally:
             os.environ.pop("BASIC_SCAN_KERNEL", None)
-    assert "generic" in ran and ("pipelined" in ran or not (C in (48, 192) and B <= 2 and W >= 4))
+    ks = int(kind.split("-k")[1]) if "-k" in kind else 5
+    assert "generic" in ran and ("pipelined" in ran or not (C in (48, 192) and B <= 2 and W >= ks // 2 + 2 and ks <= 5))
     coder.use_persistent_scanline = False
     assert coder.encode(y, prior=prior) == data
     assert torch.equal(coder.decode(data, prior=prior), y1)
