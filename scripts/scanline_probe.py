@@ -14,6 +14,8 @@ with torch.no_grad():
 c = c.eval().cuda()
 c.update_state()
 shapes = ((1, 32, 48), (8, 16, 16), (64, 16, 16), (24, 32, 48))
+if os.environ.get("PROBE_SMALL_BATCHES"):   # where does the per-step path take over?
+    shapes = ((2, 32, 48), (3, 32, 48), (4, 32, 48), (6, 32, 48))
 if os.environ.get("PROBE_SHAPES"):   # ablation runs (BASIC_SCAN_DEBUG: wrong results, timing only): the batch-1 Kodak shape
     shapes = shapes[:int(os.environ["PROBE_SHAPES"])]
 for B, H, W in shapes:
