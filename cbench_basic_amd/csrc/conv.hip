@@ -77,6 +77,7 @@ struct TapLaunch {
     const float *in;
     float *out;
     const float *wpack;   // [gridDim.y][cin_pad/CK][ntaps][CK][32][MTP]  (MTP = mtile_pitch(coutp / 32))
+    const float *wrow;    // first-layer row slab [ky * 16 + kx * 3 + c][32][4] (conv5x5_cin4_gdn_persistent_kernel<true>), or nullptr
     const float *bias;    // [gridDim.y][coutp] (zero padded) or nullptr
     int64_t split_wstride;  // floats between the weight packs of consecutive blockIdx.y output-channel slices
     const float *gammaT;  // [coutp(k)][32][MTP]: gamma[i = 32 m + col][k] at [k][col][m], zero padded
@@ -482,11 +483,17 @@ constexpr int kFirstSlots = 10;  // patch elements per thread (512 threads): <= 
 // static stride (tile += gridDim.x, what runs when sched == nullptr) makes the launch as slow as its LAST workgroup to
 // start: with rANS workgroups of another HIP stream holding the LDS of some compute units for milliseconds, the workgroups
 // meant for those units start late with their full share of tiles still to do (measured 1.07 -> 2.05 ms at 128 images).
+// ROWS (<= 3 input channels: the codec's RGB layer): the reduction runs kernel row by kernel row over (kx, channel) pairs --
+// 15 real products + 1 zero-weight pad per row = 80 instead of 25 taps x 4 padded channels = 100, i.e. 40 MFMA steps per
+// tile instead of 50 (of 114 with the GDN) -- and the patch is staged pixel-interleaved ([py][px][c], 3 floats per pixel, no
+// padding channel: 25 % fewer DMA instructions), so that a row's 16 operands are 16 consecutive floats: every step's B
+// read keeps an immediate offset.  Weights come as a second slab [ky * 16 + kx * 3 + c][32][4] (wrow).
+template <bool ROWS>
 __global__ __launch_bounds__(512, 1) void conv5x5_cin4_gdn_persistent_kernel(const TapLaunch g, int ntiles, int *sched)
 {
     extern __shared__ float lds[];
-    constexpr int MT = 4, kCK = 4, KW = 5, kSteps = 25 * 2;
-    constexpr int kWFloats = 25 * kCK * 32 * 4;  // 12800
+    constexpr int MT = 4, kCK = ROWS ? 3 : 4, KW = 5, kSteps = ROWS ? 5 * 8 : 25 * 2;
+    constexpr int kWFloats = ROWS ? 80 * 32 * 4 : 25 * 4 * 32 * 4;  // 10240 / 12800
     constexpr int kGFloats = 128 * 32 * 4;       // 16384
     float *wl = lds;
     float *gl = lds + kWFloats;
@@ -496,7 +503,7 @@ __global__ __launch_bounds__(512, 1) void conv5x5_cin4_gdn_persistent_kernel(con
     const int khalf = lane >> 5, col = lane & 31;
     const int TB = 1 << g.tb_log, TH = 1 << g.th_log, TW = 1 << g.tw_log;
     const int chan_stride = g.ph * g.pwp;
-    const int patch_elems = TB * kCK * chan_stride;
+    const int patch_elems = TB * kCK * chan_stride;   // (ROWS: kCK = 3 floats per pixel)
     const int patch_pad = (patch_elems + 511) / 512 * 512;
     const int n_pslots = patch_pad / 512;
     float *pbuf = gl + kGFloats;  // two patch buffers of patch_pad floats
@@ -509,12 +516,12 @@ __global__ __launch_bounds__(512, 1) void conv5x5_cin4_gdn_persistent_kernel(con
 
     // resident operands: weight slab (6 whole 8 KB pieces + 2 KB) and gamma (8 pieces)
     {
-        const float *srcw = g.wpack + tid * 4;
+        const float *srcw = (ROWS ? g.wrow : g.wpack) + tid * 4;
 #pragma unroll
-        for (int sl = 0; sl < 6; ++sl)
+        for (int sl = 0; sl < kWFloats / 2048; ++sl)
             __builtin_amdgcn_global_load_lds((glb_cvoid *)(srcw + sl * 2048), (lds_void *)(wl + sl * 2048 + wave * 256), 16, 0, 0);
-        if (wave < 2)
-            __builtin_amdgcn_global_load_lds((glb_cvoid *)(srcw + 6 * 2048), (lds_void *)(wl + 6 * 2048 + wave * 256), 16, 0, 0);
+        if (kWFloats % 2048 && wave < (kWFloats % 2048) / 256)
+            __builtin_amdgcn_global_load_lds((glb_cvoid *)(srcw + (kWFloats / 2048) * 2048), (lds_void *)(wl + (kWFloats / 2048) * 2048 + wave * 256), 16, 0, 0);
         const float *srcg = g.gammaT + tid * 4;
 #pragma unroll
         for (int sl = 0; sl < 8; ++sl)
@@ -528,7 +535,9 @@ __global__ __launch_bounds__(512, 1) void conv5x5_cin4_gdn_persistent_kernel(con
     const int tb_raw = q >> (g.tw_log + g.th_log);
     const bool lane_live = tb_raw < TB;
     const int tb = lane_live ? tb_raw : 0;
-    const int lane_b_base = ((tb * kCK + khalf) * g.ph + ty * g.s_in) * g.pwp + tx * g.s_in;
+    const int row_pitch = ROWS ? 3 * g.pwp : g.pwp;   // floats per patch row
+    const int lane_b_base = ROWS ? ((tb * g.ph + ty * g.s_in) * g.pwp + tx * g.s_in) * 3 + khalf
+                                 : ((tb * kCK + khalf) * g.ph + ty * g.s_in) * g.pwp + tx * g.s_in;
     const int lane_a_base = (khalf * 32 + col) * 4;
 
     // tile-independent part of the gather descriptors: patch element tid + 512 s sits at (pb, ci, py, px)
@@ -540,10 +549,18 @@ __global__ __launch_bounds__(512, 1) void conv5x5_cin4_gdn_persistent_kernel(con
         int r = tid + sl * 512;
         int off = 0, code = -1;
         if (r < patch_elems) {
-            const int px = r % g.pwp; r /= g.pwp;
-            const int py = r % g.ph; r /= g.ph;
-            const int ci = r % kCK;
-            const int pb = r / kCK;
+            int px, py, ci, pb;
+            if (ROWS) {   // [pb][py][px][c]
+                ci = r % 3; r /= 3;
+                px = r % g.pwp; r /= g.pwp;
+                py = r % g.ph;
+                pb = r / g.ph;
+            } else {      // [pb][c][py][px]
+                px = r % g.pwp; r /= g.pwp;
+                py = r % g.ph; r /= g.ph;
+                ci = r % kCK;
+                pb = r / kCK;
+            }
             if (px < g.pw && ci < g.cin) {
                 off = static_cast<int>(pb * in_img + ci * in_plane + py * g.in_w + px);
                 code = (pb << 24) | (py << 12) | px;
@@ -599,15 +616,24 @@ __global__ __launch_bounds__(512, 1) void conv5x5_cin4_gdn_persistent_kernel(con
             float fa[2][4], fb[2];
             const float *a_lane = wl + lane_a_base;
             const float *b_lane = patch + lane_b_base;
+            const float *b_row[KW];   // ROWS: this lane's 16 operands of kernel row ky start at b_row[ky] (its khalf folded in)
+#pragma unroll
+            for (int ky = 0; ky < KW; ++ky) b_row[ky] = b_lane + ky * row_pitch;
             fb[0] = b_lane[0];
             load_a<4>(a_lane, fa[0]);
 #pragma unroll
             for (int st = 0; st < kSteps; ++st) {
                 const int cur = st & 1, nxt = cur ^ 1;
                 const int sn = (st + 1 < kSteps) ? st + 1 : st;
+                if constexpr (ROWS) {   // step = (kernel row, pair of its 16 operands)
+                    fb[nxt] = b_row[sn / 8][2 * (sn % 8)];
+                    if (sn % 8 == 7 && khalf) fb[nxt] = 0.f;   // the row's 16th operand is the pad: whatever sits there (the next pixel) stays out, non-finite or not
+                    load_a<4>(a_lane + (sn / 8 * 16 + 2 * (sn % 8)) * 32 * 4, fa[nxt]);
+                } else {
                 const int tn = sn / 2, cpn = sn % 2;
                 fb[nxt] = b_lane[(tn / KW) * g.pwp + cpn * 2 * chan_stride + (tn % KW)];
                 load_a<4>(a_lane + (tn * kCK + cpn * 2) * 32 * 4, fa[nxt]);
+                }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
@@ -937,6 +963,7 @@ struct Phase {
     int waves = 4;                  // wavefronts per workgroup of this launch (32 positions each)
     signed char dy[kMaxTaps], dx[kMaxTaps];
     float *d_wpack = nullptr;
+    float *d_wrow = nullptr;    // see TapLaunch::wrow
     int64_t split_wstride = 0;  // floats per output-channel slice of d_wpack
 };
 
@@ -965,8 +992,10 @@ extern "C" void basic_conv_plan_destroy(basic_conv_plan *p)
     if (!p) return;
     for (auto *list : {&p->chunks, &p->split})
         for (auto &ch : *list) {
-            for (auto &ph : ch.phases)
+            for (auto &ph : ch.phases) {
                 if (ph.d_wpack) (void)hipFree(ph.d_wpack);
+                if (ph.d_wrow) (void)hipFree(ph.d_wrow);
+            }
             for (auto &ph : ch.fused)
                 if (ph.d_wpack) (void)hipFree(ph.d_wpack);
             if (ch.d_bias) (void)hipFree(ch.d_bias);
@@ -1065,7 +1094,21 @@ int build_chunks(basic_conv_plan *p, const float *weight, const float *bias, int
                         }
                     }
                 wp.resize(wp.size() + 2048, 0.f);  // the DMA copies whole 4 / 8 KB pieces and may read past the last stage
-                const int rc = upload(wp, &ph.d_wpack);
+                int rc = upload(wp, &ph.d_wpack);
+                // the first analysis layer's row slab (conv5x5_cin4_gdn_persistent_kernel<true>): [ky * 16 + kx * 3 + c][32][4]
+                if (!rc && !transposed && ph.kh == 5 && ph.kw == 5 && ci_n <= 3 && ch.cout == 128 && ch.mt == 4 && ch.nsplit == 1) {
+                    std::vector<float> wr(static_cast<size_t>(80) * 32 * 4 + 2048, 0.f);
+                    for (int c = 0; c < ci_n; ++c)
+                        for (int t = 0; t < ph.ntaps; ++t) {
+                            const int ky = taps[t].first, kx = taps[t].second;
+                            if (ky < 0) continue;
+                            const int k = (t / ph.kw) * 16 + (t % ph.kw) * 3 + c;   // patch row t / kw, patch column t % kw
+                            for (int o = 0; o < ch.cout; ++o)
+                                wr[(static_cast<size_t>(k) * 32 + o % 32) * 4 + o / 32] =
+                                    weight[((static_cast<size_t>(co0 + o) * cin + c) * ksize + ky) * ksize + kx];
+                        }
+                    rc = upload(wr, &ph.d_wrow);
+                }
                 ch.phases.push_back(ph);
                 if (rc) { out->push_back(ch); return rc; }
             }
@@ -1349,7 +1392,7 @@ extern "C" int basic_conv_forward_dev(const basic_conv_plan *p, const float *d_i
     for (const Chunk &ch : (use_split ? p->split : p->chunks))
     for (const Phase &ph : ((fuse_ok && !ch.fused.empty()) ? ch.fused : ch.phases)) {
         TapLaunch g{};
-        g.in = d_in; g.out = d_out; g.wpack = ph.d_wpack; g.split_wstride = ph.split_wstride; g.bias = ch.d_bias; g.gammaT = p->d_gammaT; g.beta = p->d_beta;
+        g.in = d_in; g.out = d_out; g.wpack = ph.d_wpack; g.wrow = ph.d_wrow; g.split_wstride = ph.split_wstride; g.bias = ch.d_bias; g.gammaT = p->d_gammaT; g.beta = p->d_beta;
         g.batch = batch; g.cin = p->cin; g.cin_pad = ph.ntaps ? ph.cin_pad : 0; g.cout = ch.cout; g.coutp = ch.coutp; g.out_ctotal = p->cout; g.co_base = ch.co0;
         g.in_h = in_h; g.in_w = in_w; g.out_h = oh; g.out_w = ow;
         g.s_in = p->s_in; g.s_out = p->s_out; g.oy0 = ph.oy0; g.ox0 = ph.ox0;
@@ -1398,11 +1441,14 @@ extern "C" int basic_conv_forward_dev(const basic_conv_plan *p, const float *d_i
         BASIC_REQUIRE(lds_bytes <= 160 * 1024, "conv_forward: LDS budget exceeded");
         hipStream_t st = as_stream(hip_stream);
         if (first_layer_path) {
-            // single-stage GDN layer (the first analysis layer): persistent workgroups with resident weights and gamma
-            const int patch_pad1 = (tb * kCK * g.ph * g.pwp + 511) / 512 * 512;
-            const size_t lds1 = sizeof(float) * (12800 + 16384 + 2 * static_cast<size_t>(patch_pad1) + 256 + 4);
+            // single-stage GDN layer (the first analysis layer): persistent workgroups with resident weights and gamma;
+            // <= 3 input channels: the row-interleaved reduction (BASIC_CONV_DEBUG & 1024 keeps the padded-channel one)
+            const bool rows = ph.d_wrow != nullptr && !(dbg & 1024);
+            const int patch_pad1 = (tb * (rows ? 3 : kCK) * g.ph * g.pwp + 511) / 512 * 512;
+            const size_t lds1 = sizeof(float) * ((rows ? 10240 : 12800) + 16384 + 2 * static_cast<size_t>(patch_pad1) + 256 + 4);
             if (lds1 <= 160 * 1024 && patch_pad1 <= kFirstSlots * 512) {
-                BASIC_HIP_TRY(ensure_max_lds(reinterpret_cast<const void *>(conv5x5_cin4_gdn_persistent_kernel)));
+                BASIC_HIP_TRY(ensure_max_lds(reinterpret_cast<const void *>(conv5x5_cin4_gdn_persistent_kernel<false>)));
+                BASIC_HIP_TRY(ensure_max_lds(reinterpret_cast<const void *>(conv5x5_cin4_gdn_persistent_kernel<true>)));
                 int dev = 0, cus = 256;
                 (void)hipGetDevice(&dev);
                 (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -1416,7 +1462,8 @@ extern "C" int basic_conv_forward_dev(const basic_conv_plan *p, const float *d_i
                     BASIC_HIP_TRY(hipMemsetAsync(pm->d_sched, 0, sizeof(int), st));
                     sched = pm->d_sched;
                 }
-                hipLaunchKernelGGL(conv5x5_cin4_gdn_persistent_kernel, dim3(grid), dim3(512), lds1, st, g, blocks, sched);
+                if (rows) hipLaunchKernelGGL(conv5x5_cin4_gdn_persistent_kernel<true>, dim3(grid), dim3(512), lds1, st, g, blocks, sched);
+                else hipLaunchKernelGGL(conv5x5_cin4_gdn_persistent_kernel<false>, dim3(grid), dim3(512), lds1, st, g, blocks, sched);
                 BASIC_HIP_TRY(hipGetLastError());
                 continue;
             }
