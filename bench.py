@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--total", type=int, default=256, help="images per step over ALL GPUs in the strong-scaling leg (cfg-5)")
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--workers", type=int, default=None,
-                    help="concurrent stream workers per GPU (1 = plain sequential calls); default 3 for the headline, 6 for --workload checkerboard, "
+                    help="concurrent stream workers per GPU (1 = plain sequential calls); default 6 for the headline and for --workload checkerboard, "
                          "3 for --workload basic")
     ap.add_argument("--shard-by", default="steps", choices=["steps", "images"],
                     help="how the K steps are spread over the workers: steps = every worker codes WHOLE batches, step k on worker k mod W "
@@ -445,7 +445,9 @@ def main():
                          f"(or run `python bench.py --gpus {args.gpus}` without a launcher)")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    workers = max(1, args.workers if args.workers is not None else 3)
+    # measured at 256 images per step (scripts/r03_session/r03_call53-55.sh): 3 workers / 1 token lane 671-675 Mpix/s, 4 / 3 676-689,
+    # 6 / 4 683-695 (also at 5 timed steps); under-filled tails of one session's launches are filled by another session's
+    workers = max(1, args.workers if args.workers is not None else 6)
     if workers > 1:  # one hardware queue per worker stream (+ its entropy side stream); HIP's default 4 make streams share
         os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
@@ -475,7 +477,7 @@ def main():
     # packing more image streams into one rANS workgroup frees compute units for the other workers' transforms at the
     # price of a longer chain (+2 % at 4, +10 % at 8, x2 at 16): with whole batches in flight the chain has slack
     waves = args.rans_waves if args.rans_waves >= 0 else (8 if by_steps else 4 if workers > 1 else 0)
-    token_lanes = args.token_lanes if args.token_lanes is not None else (1 if args.batch >= 128 else 4)
+    token_lanes = args.token_lanes if args.token_lanes is not None else (4 if (args.batch < 128 or workers >= 5) else 3 if workers == 4 else 1)
 
     def make_codec():
         c = seed_synthetic_weights(hyperprior_codec(), seed=0).eval().to(dev)   # every replica: the same seeded weights
