@@ -83,6 +83,7 @@ _SIGNATURES = {
     "basic_scanline_encode_dev": (_I, [_P, _P, _P, _I, _I, _I, _P, _I, _P, _P, _P, _P]),
     "basic_scanline_decode_dev": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _I, _P, _P, _P, _P]),
     "basic_scanline_can_decode": (_I, [_P, _P, _I, _P]),
+    "basic_scanline_batched_max": (_I, [_P, _I, _I, _P]),
     "basic_scanline_status": (_I, [_P, _P, _P]),
     "basic_scanline_plan_destroy": (None, [_P]),
     "basic_mse_per_image_dev": (_I, [_P, _P, _I, _L, _P, _P]),

@@ -84,6 +84,14 @@ struct ScanArgs {
     RansFastView tv;
     const uint32_t *words; // all streams back to back
     const int64_t *word_off;   // [B + 1]
+    // batched kernel only (scanline_batched_kernel; nbt == 0 for the other two): the batch is the fastest dimension of every
+    // exchanged array -- yT [HW][C][nbt], act[l] [rows_l][nbt], priorT [HW][P][nbt]; mu / idx_step stay [image][C]
+    int nbt;               // columns of the exchange arrays: 32 * column tiles (a column tile = 32 images = the N of an MFMA tile)
+    int nw, nd;            // compute workgroups per column tile; the first nd of them hold the dense layers' row tiles
+    int bpt;               // canonical blocks per context tap = C / 64
+    int nblk[kMaxLayers], rt[kMaxLayers];   // canonical blocks of a layer's K axis; its 32-row tiles
+    int ctx_blocks;        // blocks of the first dense layer fed by the context layer (the rest: the prior)
+    int tile_off[kMaxLayers];   // dense-role workgroups: LDS float offset of a layer's partial tiles
 };
 
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -443,7 +451,7 @@ __device__ __forceinline__ void decoder_workgroup(const ScanArgs &a, float *lds)
             if (c < a.C) {
                 const int32_t value = mine + static_cast<int32_t>(rt[2]);
                 const float v = static_cast<float>(value) + mu;           // pgm_coder.py:973-978
-                st_gran(a.yT + (static_cast<int64_t>(b) * HW + p) * a.C + c, v, tag);   // first: the compute workgroups wait for it
+                st_gran(a.yT + (a.nbt ? (static_cast<int64_t>(p) * a.C + c) * a.nbt + b : (static_cast<int64_t>(b) * HW + p) * a.C + c), v, tag);   // first: the compute workgroups wait for it
                 a.sym[static_cast<int64_t>(b) * a.C * HW + static_cast<int64_t>(p) * a.C + c] = value;
                 a.idx[static_cast<int64_t>(b) * a.C * HW + static_cast<int64_t>(p) * a.C + c] = row;
                 a.ybuf[(static_cast<int64_t>(b) * a.C + c) * HW + p] = v;
@@ -980,6 +988,458 @@ __global__ __launch_bounds__(kThreads) void scanline_pipelined_kernel(const Scan
     }
 }
 
+// ================================================================================================================
+// Batched variant (round 4): batches of 3 .. 64 images on the matrix core.
+//
+// The two kernels above give a thread one (block, image, row) FMA chain: right for one or two images, 0.6 ms per coding step
+// at 64.  Here the BATCH is the N dimension of v_mfma_f32_32x32x2_f32 tiles and the weights never move:
+//   * a column tile = 32 images; the launch runs one independent set of `nw` compute workgroups per column tile (64 images =
+//     two sets), one workgroup per compute unit;
+//   * a workgroup owns ONE 32-row tile of a layer with its whole K axis, as MFMA A fragments IN REGISTERS: a wave keeps up
+//     to nine 32-row x 64-channel blocks (288 VGPRs of the 512 a lone wave per SIMD may use) -- 1.9 M weights = 928 blocks
+//     fit the register files of 32 compute units, and the LDS stays free for partial tiles.  Roles: the first `nd`
+//     workgroups hold row tile j of EVERY dense layer that has one (layers run one after the other, so their tiles share
+//     the unit), the others one row tile of the context layer (ntaps * C / 64 blocks);
+//   * a canonical block's partial tile (32 rows x 32 images) is one 32-step MFMA chain from zero -- exactly the masked
+//     convolution's block (mconv.hip), so the integers agree with every other path bit for bit -- written to LDS; after a
+//     workgroup barrier the 256 threads add the tile's blocks in block order (16-byte LDS reads, four outputs per thread),
+//     bias, activation.  Splitting a row tile's K over workgroups would need a second exchange per layer; keeping it in one
+//     compute unit costs up to three MFMA rounds per layer instead;
+//   * B fragments are loaded straight from the exchange arrays into registers (lane = (k parity, image): two 256-byte runs per
+//     load), validated by their tags, and fed to the chain -- no LDS staging.  All exchanged arrays are batch-minor;
+//   * context layer: the taps coded at least two steps ago (all but the left neighbour) are multiplied one step AHEAD, in the
+//     shadow of the dense layers; on the critical path stay C / 64 blocks and their sum.  Dense layer 1: the blocks fed by the
+//     prior (an input of the launch) run before the context layer's output is waited for.
+// Exchange protocol, tags, overwrite argument and bounded spins: as in the header comment (a row tile's workgroup consumes ALL
+// inputs of its layer, so "produced" still implies "every input consumed").
+// ================================================================================================================
+constexpr int kBSlots = 9;        // weight blocks a wave keeps in registers
+constexpr int kBLateSlot = 8;     // context role, waves 1 .. bpt: the left neighbour's block
+constexpr int kBDenseSlots = 3;   // blocks per dense layer and wave (a layer's K axis has at most 12)
+constexpr int kBTile = 1024;      // floats of a 32 x 32 partial tile
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ uint32_t gran_tag(uint64_t g) { return static_cast<uint32_t>(g >> 32); }
+__device__ __forceinline__ float gran_val(uint64_t g) { return __uint_as_float(static_cast<uint32_t>(g)); }
+
+// this lane's 32 B-fragment granules of a block: base + i * stride + voff, i = 0 .. 31 (channel 2 i + lane / 32 of the block, image
+// lane % 32).  `base` and `stride` (bytes) are wave-uniform, `voff` is the lane's byte offset inside a (channel pair, column tile)
+// slab and never changes: every load is `global_load_dwordx2 v, v_off, s[base]` -- one VGPR of addressing for the whole kernel
+// instead of a 64-bit address per load in flight
+struct BSrc {
+    const char *base;
+    int stride;
+    uint32_t want;
+};
+
+__device__ __forceinline__ uint64_t ld_gran_at(const char *ubase, uint32_t voff)
+{
+    return __hip_atomic_load(reinterpret_cast<uint64_t *>(const_cast<char *>(ubase) + voff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// (the lane offset goes through an empty asm: hipcc would otherwise hoist the 32 addresses of every block of every layer out of
+// the coding loop -- they do not change from step to step -- and spill hundreds of 64-bit values)
+__device__ __forceinline__ void b_issue(const BSrc &s, uint32_t voff, bool on, uint64_t (&g)[32])
+{
+#pragma unroll
+    for (int i = 0; i < 32; ++i) g[i] = 0ull;
+    if (on) {
+        uint32_t vo = voff;
+        asm volatile("" : "+v"(vo));
+#pragma unroll
+        for (int i = 0; i < 32; ++i) g[i] = ld_gran_at(s.base, vo + static_cast<uint32_t>(i * s.stride));
+    }
+}
+
+// re-loads whatever does not carry the tag yet; wave-uniform result, false = poisoned launch
+__device__ __forceinline__ bool b_validate(const ScanArgs &a, const BSrc &s, uint32_t voff, bool on, uint64_t (&g)[32])
+{
+    bool ok = true;
+    if (on) {
+        unsigned spins = 0;
+        for (;;) {
+            bool all = true;
+            uint32_t vo = voff;
+            asm volatile("" : "+v"(vo));
+#pragma unroll
+            for (int i = 0; i < 32; ++i)
+                if (gran_tag(g[i]) != s.want) { g[i] = ld_gran_at(s.base, vo + static_cast<uint32_t>(i * s.stride)); all = false; }
+            if (all) break;
+            if (++spins > kSpinLimit || (spins % 1024u == 0u && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                __hip_atomic_store(a.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = false;
+                break;
+            }
+        }
+    }
+    return __ballot(!ok) == 0ull;
+}
+
+// one granule polled alone before a block's 32 loads are issued: while the producers are still computing, a waiting wave
+// keeps one load in flight instead of thirty-two
+__device__ __forceinline__ bool b_sentinel(const ScanArgs &a, const uint64_t *p, uint32_t want, bool on)
+{
+    bool ok = true;
+    if (on) {
+        uint64_t g = ld_gran(p);
+        ok = wait_gran(a, p, want, g);
+    }
+    return __ballot(!ok) == 0ull;
+}
+
+// the canonical block: one MFMA chain from zero over the block's 32 channel pairs, in ascending order
+template <class BF> __device__ __forceinline__ f32x16 b_chain(const float (&wr)[32], BF &&bf)
+{
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[i], bf(i), acc, 0, 0, 0);
+    return acc;
+}
+
+// Weight slots 0 .. 7 live in the ACCUMULATOR half of the register file, a[32 k .. 32 k + 31], for the whole launch (an MFMA
+// takes its A operand from there directly); hipcc would spill a 288-register array that is live across the whole kernel, so
+// these 256 registers are named literally: written once (b_put_weights), read only by the MFMAs of b_chain_acc, reserved by
+// the clobber list of b_reserve_acc -- and the build is audited for a spill count of zero and for no compiler v_accvgpr_*
+// (cdna_hip_programming.md 5.7 item 4).  Nothing inside an asm string is padded by the compiler: every MFMA is preceded by the
+// two wait states a just-written B operand needs, and the chain ends with the 19 states a 16-pass MFMA's result needs
+// before anything but the next MFMA of the chain touches it.
+#define BASIC_A16(n) "a" #n "0", "a" #n "1", "a" #n "2", "a" #n "3", "a" #n "4", "a" #n "5", "a" #n "6", "a" #n "7", "a" #n "8", "a" #n "9"
+__device__ __forceinline__ void b_reserve_acc()
+{
+    asm volatile("" ::: "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", BASIC_A16(1), BASIC_A16(2), BASIC_A16(3), BASIC_A16(4),
+                 BASIC_A16(5), BASIC_A16(6), BASIC_A16(7), BASIC_A16(8), BASIC_A16(9), BASIC_A16(10), BASIC_A16(11), BASIC_A16(12), BASIC_A16(13),
+                 BASIC_A16(14), BASIC_A16(15), BASIC_A16(16), BASIC_A16(17), BASIC_A16(18), BASIC_A16(19), BASIC_A16(20), BASIC_A16(21),
+                 BASIC_A16(22), BASIC_A16(23), BASIC_A16(24), "a250", "a251", "a252", "a253", "a254", "a255");
+}
+#undef BASIC_A16
+
+template <int K> __device__ __forceinline__ void b_put_weights(const float *src)   // src == nullptr: an unused slot (zeros)
+{
+    static_for<0, 32>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        const float x = src ? src[2 * i] : 0.f;
+        asm volatile("v_accvgpr_write_b32 a[%c1], %0" ::"v"(x), "n"(K * 32 + i));
+    });
+}
+
+template <int K, int I, class BF> __device__ __forceinline__ void b_chain_acc_step(f32x16 &acc, BF &bf)
+{
+    if constexpr (I < 32) {
+        const float b = bf(I);
+        asm volatile("s_nop 1\n\tv_mfma_f32_32x32x2_f32 %0, a[%c2], %1, %0" : "+v"(acc) : "v"(b), "n"(K * 32 + I));
+        b_chain_acc_step<K, I + 1>(acc, bf);
+    }
+}
+
+template <int K, class BF> __device__ __forceinline__ f32x16 b_chain_acc(BF &&bf)
+{
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    b_chain_acc_step<K, 0>(acc, bf);
+    asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc));
+    return acc;
+}
+
+// slot K of this wave: accumulator-file slots below 8, the wave's VGPR array for the ninth
+template <int K, class BF> __device__ __forceinline__ f32x16 b_chain_slot(const float (&w8)[32], BF &&bf)
+{
+    if constexpr (K < 8) return b_chain_acc<K>(bf);
+    else return b_chain(w8, bf);
+}
+
+// accumulator layout of the 32 x 32 tile: lane holds image lane % 32, rows 8 q + 4 (lane / 32) + j for register 4 q + j; the
+// tile goes to LDS as [q][lane] 16-byte pieces, and thread (q, lane) of the workgroup later owns exactly those four outputs
+__device__ __forceinline__ void b_store_tile(float *tile, int lane, const f32x16 &acc)
+{
+#pragma unroll
+    for (int q = 0; q < 4; ++q) *reinterpret_cast<f4 *>(tile + (q * 64 + lane) * 4) = f4{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+}
+
+// v + tile 0 + tile 1 + ... (n tiles, in that order), this thread's four outputs
+__device__ __forceinline__ f4 b_sum_tiles(f4 v, const float *tiles, int n, int tid)
+{
+    const float *p = tiles + tid * 4;
+    int b = 0;
+    for (; b + 4 <= n; b += 4) {
+        const f4 t0 = *reinterpret_cast<const f4 *>(p + b * kBTile), t1 = *reinterpret_cast<const f4 *>(p + (b + 1) * kBTile);
+        const f4 t2 = *reinterpret_cast<const f4 *>(p + (b + 2) * kBTile), t3 = *reinterpret_cast<const f4 *>(p + (b + 3) * kBTile);
+        v += t0; v += t1; v += t2; v += t3;
+    }
+    for (; b < n; ++b) v += *reinterpret_cast<const f4 *>(p + b * kBTile);
+    return v;
+}
+
+__device__ __forceinline__ f4 b_leaky(f4 v)
+{
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = v[i] > 0.f ? v[i] : 0.01f * v[i];   // LeakyReLU(0.01)
+    return v;
+}
+
+template <bool DECODE>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))) void scanline_batched_kernel(const ScanArgs a)
+{
+    extern __shared__ float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wg = blockIdx.x;
+    if (DECODE && wg >= a.ncompute) { decoder_workgroup(a, lds); return; }
+    const int HW = a.H * a.W, C = a.C, NBT = a.nbt, T = NBT >> 5;
+    const int t = wg % T, j = wg / T;                  // column tile; role index inside the tile's set of workgroups
+    const int h = lane >> 5, n = lane & 31, col = t * 32 + n;
+    const bool img = col < a.B;                        // columns beyond the batch: nothing loaded, nothing published
+    const bool dense = j < a.nd;
+    const int r0 = dense ? j : j - a.nd;               // this workgroup's row tile (dense role: of every layer that has one)
+    const int early = (a.ntaps - 1) * a.bpt;           // context blocks of the taps coded at least two steps ago
+    const int frow = 8 * wave + 4 * h;                 // first of this thread's four finishing rows inside the tile
+    // the lane's place inside a (channel pair, column tile) slab of a batch-minor array: granule arrays / float arrays (bytes)
+    const uint32_t voff8 = static_cast<uint32_t>(h * NBT + col) * 8u, voff4 = static_cast<uint32_t>(h * NBT + col) * 4u;
+    const int gstride = 2 * NBT * 8;                   // bytes between consecutive channel pairs of a granule array
+    const uint32_t soff = static_cast<uint32_t>(frow * NBT + col);   // granule index of this thread's first finishing row inside its tile's rows
+
+    // LDS: [scale table][flags][biases of this workgroup's row tiles: 3 x 32][partial tiles]
+    float *tab = lds;
+    int *s_flag = reinterpret_cast<int *>(lds + ((a.table_len + 3) & ~3));
+    float *bias_s = lds + ((a.table_len + 3) & ~3) + 4;
+    float *part = bias_s + 96;
+    for (int e = tid; e < a.table_len; e += kThreads) tab[e] = a.table[e];
+    if (tid < 96) {
+        const int li = tid >> 5, l = dense ? 1 + li : 0;
+        const float *bias = (l < a.nlayers && (dense || li == 0) && r0 < a.rt[l]) ? a.bias[l] : nullptr;
+        bias_s[tid] = bias ? bias[r0 * 32 + (tid & 31)] : 0.f;
+    }
+    if (tid == 0) s_flag[1] = 1;
+    __syncthreads();
+    for (int e = tid; e + 1 < a.table_len; e += kThreads)
+        if (!(tab[e] < tab[e + 1])) s_flag[1] = 0;   // not strictly increasing: nearest_scale scans
+    __syncthreads();
+    const bool tab_sorted = s_flag[1] != 0;
+
+    // ---- this wave's weight blocks: A fragments, lane = (row lane % 32 of the tile, channel parity lane / 32)
+    float wreg[kBSlots][32];
+    static_for<0, kBSlots>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        const float *src = nullptr;
+        if (dense) {
+            constexpr int l = 1 + k / kBDenseSlots;
+            const int b = wave + 4 * (k % kBDenseSlots);
+            if (l < a.nlayers && r0 < a.rt[l] && b < a.nblk[l]) src = a.w[l] + static_cast<int64_t>(r0 * 32 + n) * a.kdim[l] + 64 * b + h;
+        } else {
+            const int e = (k == kBLateSlot && wave != 0) ? early + wave - 1 : wave + 4 * k;
+            const bool v = (k == kBLateSlot && wave != 0) ? wave <= a.bpt : e < early;
+            if (v) src = a.w[0] + static_cast<int64_t>(r0 * 32 + n) * a.kdim[0] + 64 * e + h;
+        }
+#pragma unroll
+        for (int i = 0; i < 32; ++i) wreg[k][i] = src ? src[2 * i] : 0.f;
+    });
+    const f4 zero4 = f4{0.f, 0.f, 0.f, 0.f};
+    f32x16 zero16;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) zero16[i] = 0.f;
+    uint64_t gA[32], gB[32];
+
+    if (!dense) {
+        // ================= context role: row tile r0 of the masked context convolution =================
+        const char *yT8 = reinterpret_cast<const char *>(a.yT);
+        f4 esum = zero4;   // position 0 has no causal neighbour: its early sum is zero
+        int px = 0;
+        for (int p = 0; p < HW; ++p) {
+            const uint32_t tag = static_cast<uint32_t>(p + 1);
+            // ---------- late half: the left neighbour's blocks.  A row's first position has none (zeros), but the overwrite
+            // argument of the exchange arrays needs this step to start after position p - 1 is coded: its granules are waited
+            // for all the same
+            if (wave >= 1 && wave <= a.bpt) {
+                f32x16 acc = zero16;
+                if (p > 0) {
+                    const BSrc s{yT8 + (static_cast<int64_t>(p - 1) * C + 64 * (wave - 1)) * NBT * 8, gstride, static_cast<uint32_t>(p)};
+                    bool ok = b_sentinel(a, reinterpret_cast<const uint64_t *>(s.base + static_cast<int64_t>(31) * s.stride + voff8), s.want, img);
+                    b_issue(s, voff8, img, gA);
+                    ok = b_validate(a, s, voff8, img, gA) && ok;
+                    if (!ok) return;
+                    if (px > 0) acc = b_chain(wreg[kBLateSlot], [&](int i) { return gran_val(gA[i]); });
+                }
+                b_store_tile(part + (early + wave - 1) * kBTile, lane, acc);
+            }
+            lds_barrier();
+            {
+                f4 v = b_sum_tiles(esum, part + early * kBTile, a.bpt, tid);
+                v += *reinterpret_cast<const f4 *>(bias_s + frow);
+                if (a.act_after[0]) v = b_leaky(v);
+                if (img) {
+                    uint32_t so = soff;
+                    asm volatile("" : "+v"(so));   // (or the four addresses are hoisted out of the coding loop and spilled)
+                    uint64_t *dst = a.act[0] + static_cast<int64_t>(r0 * 32) * NBT;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) st_gran(dst + (so + static_cast<uint32_t>(i * NBT)), v[i], tag);
+                }
+            }
+            if (++px == a.W) px = 0;
+            if (p + 1 == HW) break;
+            // ---------- early half for the next position q = p + 1, in the shadow of the dense layers: partial tiles of the blocks
+            // of the taps coded at least two steps ago, then their sum in block order.  Every granule read here was validated by
+            // this workgroup's late waves in an earlier step (the newest, position p - 1, in this step's late half, before the
+            // barrier above), so only the value halves are loaded: 32 registers per block in flight instead of 64, and the
+            // loads of TWO blocks ahead are in flight under a block's chain (a wave has 63 outstanding loads at most; a block's
+            // loads take ~1.5 us to land, its chain 0.85)
+            const int q = p + 1, qy = q / a.W, qx = px;
+            float eb0[32], eb1[32], eb2[32];
+            auto issue_early = [&](int e, float (&dst)[32]) -> bool {   // false: the tap lies outside the image (zeros)
+                const int tp = e / a.bpt, cb = e - tp * a.bpt;
+                const int ny = qy + a.tap_dy[tp], nx = qx + a.tap_dx[tp];
+                if (!(ny >= 0 && nx >= 0 && nx < a.W)) return false;
+                const char *base = yT8 + (static_cast<int64_t>(q + a.tap_off[tp]) * C + 64 * cb) * NBT * 8;
+#pragma unroll
+                for (int i = 0; i < 32; ++i) dst[i] = 0.f;
+                if (img) {
+                    uint32_t vo = voff8;
+                    asm volatile("" : "+v"(vo));
+#pragma unroll
+                    for (int i = 0; i < 32; ++i)
+                        dst[i] = __uint_as_float(__hip_atomic_load(reinterpret_cast<uint32_t *>(const_cast<char *>(base) + (vo + static_cast<uint32_t>(i * gstride))),
+                                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                }
+                return true;
+            };
+            auto early_valid = [&](int kk) { return wave + 4 * kk < early && !(kk == kBLateSlot && wave != 0); };
+            bool in_a = early_valid(0) && issue_early(wave, eb0);
+            bool in_b = early_valid(1) && issue_early(wave + 4, eb1);
+            bool in_c = false;
+            static_for<0, kBSlots>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                if (!early_valid(k)) return;
+                float(&cur)[32] = *((k % 3 == 0) ? &eb0 : (k % 3 == 1) ? &eb1 : &eb2);
+                float(&nxt)[32] = *((k % 3 == 0) ? &eb2 : (k % 3 == 1) ? &eb0 : &eb1);   // buffer of block k + 2
+                bool &in_cur = (k % 3 == 0) ? in_a : (k % 3 == 1) ? in_b : in_c;
+                bool &in_nxt = (k % 3 == 0) ? in_c : (k % 3 == 1) ? in_a : in_b;
+                const bool have = in_cur;
+                f32x16 acc = zero16;
+                if (have) acc = b_chain(wreg[k], [&](int i) { return cur[i]; });   // (a tap outside the image enters as zeros: the block's partial is zero)
+                if (k + 2 < kBSlots) in_nxt = early_valid(k + 2) && issue_early(wave + 4 * (k + 2), nxt);
+                b_store_tile(part + (wave + 4 * k) * kBTile, lane, acc);
+            });
+            lds_barrier();
+            esum = b_sum_tiles(zero4, part, early, tid);
+        }
+        return;
+    }
+
+    // ================= dense role: row tile r0 of every dense layer that has one =================
+    const int last = a.nlayers - 1;
+    const bool codes = r0 < a.rt[last] && img;     // this thread finishes two (mean, scale) pairs of image `col`
+    const int c0 = (r0 * 32 + frow) >> 1;          // its channels c0, c0 + 1  (rows 2c = mean, 2c + 1 = scale: "split_interleave")
+    // element offsets of (image col, channel c0) in y / ybuf [B][C][HW], sym / idx [B][HW * C], yT [HW][C][nbt], mu / idx_step [nbt][C]
+    const uint32_t yoff = static_cast<uint32_t>((col * C + c0) * HW), ooff = static_cast<uint32_t>(col * C * HW + c0);
+    const uint32_t toff = static_cast<uint32_t>(c0 * NBT + col), moff = static_cast<uint32_t>(col * C + c0);
+    for (int p = 0; p < HW; ++p) {
+        const uint32_t tag = static_cast<uint32_t>(p + 1);
+        // (per-thread element offsets stay 32-bit and opaque: as 64-bit addresses hoisted out of the loop they would be spilled)
+        float y_pre0 = 0.f, y_pre1 = 0.f;
+        if (!DECODE && codes) {   // requested a whole step before they are needed
+            uint32_t yo = yoff;
+            asm volatile("" : "+v"(yo));
+            y_pre0 = (a.y + p)[yo];
+            y_pre1 = (a.y + p)[yo + static_cast<uint32_t>(HW)];
+        }
+        bool alive = true;
+        static_for<1, 4>([&](auto lc) {
+            constexpr int l = decltype(lc)::value;
+            if (l > last || r0 >= a.rt[l] || !alive) return;
+            float *tiles = part + a.tile_off[l];
+            const int fed = l == 1 ? a.ctx_blocks : a.nblk[l];   // blocks fed by the previous layer; the rest (layer 1): the prior
+            // (1) the prior's blocks: inputs of the launch, nothing to wait for
+            if (l == 1) {
+                static_for<0, kBDenseSlots>([&](auto kc) {
+                    constexpr int k = decltype(kc)::value;
+                    const int b = wave + 4 * k;
+                    if (b < fed || b >= a.nblk[1]) return;
+                    const char *src = reinterpret_cast<const char *>(a.priorT) + (static_cast<int64_t>(p) * a.P + 64 * (b - fed)) * NBT * 4;
+                    float bv[32];
+#pragma unroll
+                    for (int i = 0; i < 32; ++i) bv[i] = 0.f;
+                    if (img) {
+                        uint32_t vo = voff4;
+                        asm volatile("" : "+v"(vo));
+#pragma unroll
+                        for (int i = 0; i < 32; ++i) bv[i] = *reinterpret_cast<const float *>(src + (vo + static_cast<uint32_t>(i * (2 * NBT * 4))));
+                    }
+                    const f32x16 acc = b_chain(wreg[k], [&](int i) { return bv[i]; });
+                    b_store_tile(tiles + b * kBTile, lane, acc);
+                });
+            }
+            // (2) the blocks fed by layer l - 1: one granule polled alone, then the wave's blocks double-buffered
+            const char *xin = reinterpret_cast<const char *>(a.act[l - 1]);
+            if (wave < fed)
+                alive = b_sentinel(a, reinterpret_cast<const uint64_t *>(xin + static_cast<int64_t>(64 * wave + 62) * NBT * 8 + voff8), tag, img) && alive;
+            static_for<0, kBDenseSlots>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                const int b = wave + 4 * k;
+                if (b >= fed) return;
+                uint64_t(&gc)[32] = *((k & 1) ? &gB : &gA);
+                uint64_t(&gn)[32] = *((k & 1) ? &gA : &gB);
+                const BSrc s{xin + static_cast<int64_t>(64 * b) * NBT * 8, gstride, tag};
+                if (k == 0) b_issue(s, voff8, img, gc);
+                if (k + 1 < kBDenseSlots && b + 4 < fed) {
+                    const BSrc s1{xin + static_cast<int64_t>(64 * (b + 4)) * NBT * 8, gstride, tag};
+                    b_issue(s1, voff8, img, gn);
+                }
+                alive = b_validate(a, s, voff8, img, gc) && alive;
+                const f32x16 acc = b_chain(wreg[(l - 1) * kBDenseSlots + k], [&](int i) { return gran_val(gc[i]); });
+                b_store_tile(tiles + b * kBTile, lane, acc);
+            });
+            if (!alive) return;
+            lds_barrier();
+            f4 v = b_sum_tiles(zero4, tiles, a.nblk[l], tid);
+            v += *reinterpret_cast<const f4 *>(bias_s + (l - 1) * 32 + frow);
+            if (a.act_after[l]) v = b_leaky(v);
+            if (l < last) {
+                if (img) {
+                    uint32_t so = soff;
+                    asm volatile("" : "+v"(so));
+                    uint64_t *dst = a.act[l] + static_cast<int64_t>(r0 * 32) * NBT;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) st_gran(dst + (so + static_cast<uint32_t>(i * NBT)), v[i], tag);
+                }
+            } else if (img) {
+                // ---- Gaussian step: this thread's two (mean, scale) pairs
+                uint32_t yo = yoff, oo = ooff, to = toff, mo = moff;
+                asm volatile("" : "+v"(yo), "+v"(oo), "+v"(to), "+v"(mo));
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const float mu = v[2 * i], sg = v[2 * i + 1];
+                    const int row = nearest_scale(sg, tab, a.table_len, tab_sorted);
+                    if (DECODE) {
+                        st_gran(a.idx_step + (mo + i), static_cast<uint32_t>(row), tag);
+                        st_gran(a.mu + (mo + i), mu, tag);
+                    } else {
+                        const float q = rintf((i ? y_pre1 : y_pre0) - mu);          // torch.round: half to even
+                        st_gran(a.yT + static_cast<int64_t>(p) * C * NBT + (to + static_cast<uint32_t>(i * NBT)), q + mu, tag);   // first: the context workgroups wait for it
+                        (a.idx + static_cast<int64_t>(p) * C)[oo + i] = row;
+                        (a.sym + static_cast<int64_t>(p) * C)[oo + i] = static_cast<int32_t>(q);
+                        (a.ybuf + p)[yo + static_cast<uint32_t>(i * HW)] = q + mu;
+                    }
+                }
+            }
+        });
+        if (!alive) return;
+        lds_barrier();   // a layer's partial tiles are rewritten in the next step (a workgroup with one layer has no other barrier in between)
+    }
+}
+
+// prior [B][P][HW] -> priorT [HW][P][nbt]  (batch-minor: a B fragment of the batched kernel is two 128-byte runs)
+__global__ void transpose_prior_batched_kernel(const float *__restrict__ in, float *__restrict__ out, int B, int P, int HW, int nbt, int64_t total)
+{
+    for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < total; i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        const int b = static_cast<int>(i % nbt);
+        const int64_t r = i / nbt;
+        const int c = static_cast<int>(r % P);
+        const int p = static_cast<int>(r / P);
+        out[i] = b < B ? in[(static_cast<int64_t>(b) * P + c) * HW + p] : 0.f;
+    }
+}
+
 // prior [B][P][HW] -> priorT [B][HW][P]
 __global__ void transpose_prior_kernel(const float *__restrict__ in, float *__restrict__ out, int P, int HW, int64_t total)
 {
@@ -1006,6 +1466,11 @@ struct basic_scanline_plan {
     size_t scratch_cap = 0;
     unsigned *d_bar = nullptr;   // [0] barrier counter, [1] error flag
     hipEvent_t done = nullptr;   // completion of this plan's last launch (see ScanChain)
+    // batched kernel (scanline_batched_kernel): whether the layers have its shape, and the split of a column tile's workgroups
+    bool batched = false;
+    int b_nw = 0, b_nd = 0, b_bpt = 0, b_ctx_blocks = 0;
+    int b_nblk[kMaxLayers] = {}, b_rt[kMaxLayers] = {}, b_tile_off[kMaxLayers] = {};
+    int b_tiles = 0;             // partial tiles (4 KB each) the larger role keeps in LDS
 };
 
 namespace {
@@ -1173,6 +1638,35 @@ extern "C" int basic_scanline_plan_create(const float *ctx_weight, const float *
         if (e != hipSuccess) rc = hip_fail(e, "scanline_plan_create", __FILE__, __LINE__);
     }
     if (rc) { basic_scanline_plan_destroy(p); return rc; }
+    // batched kernel: every layer in whole 32-row tiles and whole 64-channel canonical blocks (no short block, none across a
+    // K group or the ctx | prior seam); a context row tile's blocks in the nine register slots of four waves (the late blocks
+    // on waves 1 .. bpt, slot 8); at most three blocks per dense layer and wave; at most three dense layers
+    {
+        bool ok = p->nlayers >= 2 && p->nlayers <= 4 && channels % kKB == 0 && channels / kKB <= 3 && p->rows[0] % kKB == 0;
+        const int bpt = channels / kKB, early = (p->ntaps - 1) * bpt;
+        for (int w = 1; w <= 3 && ok; ++w) ok = w + 4 * kBLateSlot >= early;   // slot 8 of waves 1 .. 3 is not an early block
+        ok = ok && early <= 4 * kBSlots - 3;
+        for (int l = 0; l < p->nlayers && ok; ++l) {
+            ok = p->rows[l] % 32 == 0 && p->kdim[l] % kKB == 0 && p->kgroup[l] % kKB == 0;
+            p->b_nblk[l] = p->kdim[l] / kKB;
+            p->b_rt[l] = p->rows[l] / 32;
+            if (l > 0) ok = ok && p->b_nblk[l] <= 4 * kBDenseSlots;
+        }
+        if (ok) {
+            p->b_bpt = bpt;
+            p->b_ctx_blocks = p->rows[0] / kKB;
+            int tiles = 0;
+            for (int l = 1; l < p->nlayers; ++l) {
+                p->b_nd = std::max(p->b_nd, p->b_rt[l]);
+                p->b_tile_off[l] = tiles * kBTile;
+                tiles += p->b_nblk[l];
+            }
+            p->b_nw = p->b_nd + p->b_rt[0];
+            p->b_tiles = std::max(tiles, p->b_nblk[0]);
+            ok = static_cast<size_t>(p->b_tiles) * kBTile * sizeof(float) + 8192 <= 160 * 1024;
+        }
+        p->batched = ok;
+    }
     *out = p;
     return BASIC_OK;
 }
@@ -1301,6 +1795,88 @@ int fill_args(basic_scanline_plan *p, ScanArgs &a, int batch, int h, int w, cons
     return BASIC_OK;
 }
 
+// ---- batched kernel: when it serves a call, and its launch arguments
+constexpr int kBatchedMaxTiles = 2;   // column tiles of 32 images per launch
+
+// whether the batched kernel can serve `batch` images of a latent `w` columns wide (the context window's early half must be coded
+// two steps before it is used: w >= ksize / 2 + 2); grid = column tiles x workgroups per tile (+ decoder workgroups)
+bool batched_fits(const basic_scanline_plan *p, int batch, int w, int ndec, int cus)
+{
+    if (!p->batched || batch < 1 || batch > 32 * kBatchedMaxTiles || w < p->ksize / 2 + 2) return false;
+    const int tiles = (batch + 31) / 32;
+    return tiles * p->b_nw + ndec <= cus;
+}
+
+// 0 = generic / pipelined kernels, 1 = batched.  BASIC_SCAN_KERNEL=batched|generic|pipelined forces one (identical results)
+int choose_batched(const basic_scanline_plan *p, int batch, int w, int ndec, int cus, bool *batched)
+{
+    const bool fits = batched_fits(p, batch, w, ndec, cus);
+    const char *e = getenv("BASIC_SCAN_KERNEL");
+    if (e && !strcmp(e, "batched")) BASIC_REQUIRE(fits, "scanline: BASIC_SCAN_KERNEL=batched, but this call does not fit the batched kernel");
+    if (e && (!strcmp(e, "generic") || !strcmp(e, "pipelined"))) { *batched = false; return BASIC_OK; }
+    const char *m = getenv("BASIC_SCAN_BATCHED_FROM");   // smallest batch the batched kernel takes by default
+    const int from = m && atoi(m) >= 1 ? atoi(m) : 3;
+    *batched = fits && (batch >= from || (e && !strcmp(e, "batched")));
+    return BASIC_OK;
+}
+
+int fill_args_batched(basic_scanline_plan *p, ScanArgs &a, int batch, int h, int w, const float *d_prior, const float *d_table, int table_len,
+                      size_t *lds_bytes, hipStream_t st)
+{
+    const int64_t HW = static_cast<int64_t>(h) * w;
+    const int tiles = (batch + 31) / 32, nbt = 32 * tiles;
+    a.B = batch; a.C = p->C; a.H = h; a.W = w; a.P = p->P;
+    a.nlayers = p->nlayers; a.ntaps = p->ntaps; a.vec4 = p->vec4;
+    a.table = d_table; a.table_len = table_len;
+    a.nbt = nbt; a.nw = p->b_nw; a.nd = p->b_nd; a.bpt = p->b_bpt; a.ctx_blocks = p->b_ctx_blocks;
+    // scratch: [granule regions: layer exchange arrays [rows][nbt], coded latent [HW][C][nbt], step means / rows [nbt][C]][prior [HW][P][nbt]]
+    size_t floats = 0;
+    for (int l = 0; l + 1 < p->nlayers; ++l) floats += align4(2 * static_cast<size_t>(nbt) * p->rows[l]);
+    const size_t yT_off = floats;     floats += align4(2 * static_cast<size_t>(nbt) * HW * p->C);
+    const size_t mu_off = floats;     floats += align4(2 * static_cast<size_t>(nbt) * p->C);
+    const size_t is_off = floats;     floats += align4(2 * static_cast<size_t>(nbt) * p->C);
+    const size_t gran_floats = floats;
+    const size_t pT_off = floats;     floats += align4(static_cast<size_t>(nbt) * HW * p->P);
+    if (floats > p->scratch_cap) {
+        if (p->d_scratch) (void)hipFree(p->d_scratch);
+        p->d_scratch = nullptr; p->scratch_cap = 0;
+        BASIC_HIP_TRY(hipMalloc(&p->d_scratch, floats * sizeof(float)));
+        p->scratch_cap = floats;
+    }
+    BASIC_HIP_TRY(hipMemsetAsync(p->d_scratch, 0, gran_floats * sizeof(float), st));   // tag 0 = "not written in this launch"
+    size_t ao = 0;
+    for (int l = 0; l < p->nlayers; ++l) {
+        a.rows[l] = p->rows[l]; a.kdim[l] = p->kdim[l]; a.act_after[l] = p->act_after[l];
+        a.nblk[l] = p->b_nblk[l]; a.rt[l] = p->b_rt[l]; a.tile_off[l] = p->b_tile_off[l];
+        a.w[l] = p->d_w[l]; a.bias[l] = p->d_b[l];
+        a.act[l] = nullptr;
+        if (l + 1 < p->nlayers) {
+            a.act[l] = reinterpret_cast<uint64_t *>(p->d_scratch + ao);
+            ao += align4(2 * static_cast<size_t>(nbt) * p->rows[l]);
+        }
+    }
+    a.yT = reinterpret_cast<uint64_t *>(p->d_scratch + yT_off);
+    a.mu = reinterpret_cast<uint64_t *>(p->d_scratch + mu_off);
+    a.idx_step = reinterpret_cast<uint64_t *>(p->d_scratch + is_off);
+    a.priorT = nullptr;
+    if (p->P > 0) {
+        float *pT = p->d_scratch + pT_off;
+        const int64_t total = static_cast<int64_t>(nbt) * HW * p->P;
+        int64_t g = (total + 255) / 256;
+        hipLaunchKernelGGL(transpose_prior_batched_kernel, dim3(static_cast<unsigned>(g > 8192 ? 8192 : g)), dim3(256), 0, st, d_prior, pT, batch,
+                           p->P, static_cast<int>(HW), nbt, total);
+        BASIC_HIP_TRY(hipGetLastError());
+        a.priorT = pT;
+    }
+    for (int t = 0; t < p->ntaps; ++t) { a.tap_dy[t] = p->tap_dy[t]; a.tap_dx[t] = p->tap_dx[t]; a.tap_off[t] = p->tap_dy[t] * w + p->tap_dx[t]; }
+    *lds_bytes = (align4(table_len) + 4 + 96 + static_cast<size_t>(p->b_tiles) * kBTile) * sizeof(float);   // table, flags, biases, partial tiles
+    a.bar = p->d_bar;
+    a.err = reinterpret_cast<int *>(p->d_bar + 1);
+    a.debug = 0;
+    BASIC_HIP_TRY(hipMemsetAsync(p->d_bar, 0, 2 * sizeof(unsigned), st));
+    return BASIC_OK;
+}
+
 // BASIC_SCAN_PROFILE=1 (debugging aid): where does workgroup 0 spend a coding step?  Synchronises the stream.
 struct ScanProfile {
     static constexpr int kSlots = 4 * kMaxLayers + 4;
@@ -1352,14 +1928,31 @@ extern "C" int basic_scanline_encode_dev(basic_scanline_plan *p, const float *d_
     hipStream_t st = as_stream(hip_stream);
     ScanArgs a{};
     size_t lds_bytes = 0;
-    bool pipelined = false;
-    int rc = fill_args(p, a, batch, h, w, d_prior, d_table, table_len, &lds_bytes, &pipelined, st);
+    bool pipelined = false, batched = false;
+    int cus = 0;
+    int rc = device_cus(&cus);
+    if (rc) return rc;
+    rc = choose_batched(p, batch, w, 0, cus, &batched);
+    if (rc) return rc;
+    if (batched) {
+        rc = fill_args_batched(p, a, batch, h, w, d_prior, d_table, table_len, &lds_bytes, st);
+        if (rc) return rc;
+        a.y = d_y; a.ybuf = d_ybuf; a.sym = d_symbols; a.idx = d_indexes;
+        const int grid = (a.nbt / 32) * p->b_nw;
+        a.ncompute = grid;
+        if (lds_bytes < 96 * 1024) lds_bytes = 96 * 1024;   // one workgroup per compute unit
+        BASIC_HIP_TRY(ensure_max_lds(reinterpret_cast<const void *>(scanline_batched_kernel<false>)));
+        ScanProfile prof;
+        rc = prof.begin(a, st);
+        if (rc) return rc;
+        rc = chained_launch(p, st, grid, cus, [&] { hipLaunchKernelGGL(scanline_batched_kernel<false>, dim3(grid), dim3(kThreads), lds_bytes, st, a); });
+        prof.report(a, st, "encode (batched)");
+        return rc;
+    }
+    rc = fill_args(p, a, batch, h, w, d_prior, d_table, table_len, &lds_bytes, &pipelined, st);
     if (rc) return rc;
     a.y = d_y; a.ybuf = d_ybuf; a.sym = d_symbols; a.idx = d_indexes;
     a.ncompute = p->nwg;
-    int cus = 0;
-    rc = device_cus(&cus);
-    if (rc) return rc;
     BASIC_REQUIRE(p->nwg <= cus, "scanline_encode: more workgroups than compute units (the grid must be resident)");
     // more than half of a compute unit's LDS per workgroup: exactly one workgroup per unit, as the barrier protocol assumes
     if (lds_bytes < 96 * 1024) lds_bytes = 96 * 1024;
@@ -1386,17 +1979,40 @@ extern "C" int basic_scanline_decode_dev(basic_scanline_plan *p, const basic_ran
     hipStream_t st = as_stream(hip_stream);
     ScanArgs a{};
     size_t lds_bytes = 0;
-    bool pipelined = false;
-    int rc = fill_args(p, a, batch, h, w, d_prior, d_table, table_len, &lds_bytes, &pipelined, st);
+    bool pipelined = false, batched = false;
+    const int ndec = (batch + kThreads / 64 - 1) / (kThreads / 64);
+    int cus = 0;
+    int rc = device_cus(&cus);
+    if (rc) return rc;
+    rc = choose_batched(p, batch, w, ndec, cus, &batched);
+    if (rc) return rc;
+    if (batched) {
+        rc = fill_args_batched(p, a, batch, h, w, d_prior, d_table, table_len, &lds_bytes, st);
+        if (rc) return rc;
+        rc = rans_fast_view(tables, &a.tv);
+        if (rc) return rc;
+        a.ybuf = d_ybuf; a.sym = d_symbols; a.idx = d_indexes; a.words = d_words; a.word_off = d_word_off;
+        const int ncompute = (a.nbt / 32) * p->b_nw;
+        a.ncompute = ncompute;
+        const size_t dec_lds_b = (static_cast<size_t>((a.tv.image_words + 3) & ~3) + 4 * static_cast<size_t>(a.tv.rows) + 4) * sizeof(uint32_t);
+        if (dec_lds_b > lds_bytes) lds_bytes = dec_lds_b;
+        if (lds_bytes < 96 * 1024) lds_bytes = 96 * 1024;
+        BASIC_REQUIRE(lds_bytes <= 160 * 1024, "scanline_decode: the search image does not fit the LDS");
+        BASIC_HIP_TRY(ensure_max_lds(reinterpret_cast<const void *>(scanline_batched_kernel<true>)));
+        ScanProfile prof;
+        rc = prof.begin(a, st);
+        if (rc) return rc;
+        rc = chained_launch(p, st, ncompute + ndec, cus,
+                            [&] { hipLaunchKernelGGL(scanline_batched_kernel<true>, dim3(ncompute + ndec), dim3(kThreads), lds_bytes, st, a); });
+        prof.report(a, st, "decode (batched)");
+        return rc;
+    }
+    rc = fill_args(p, a, batch, h, w, d_prior, d_table, table_len, &lds_bytes, &pipelined, st);
     if (rc) return rc;
     rc = rans_fast_view(tables, &a.tv);
     if (rc) return rc;
     a.ybuf = d_ybuf; a.sym = d_symbols; a.idx = d_indexes; a.words = d_words; a.word_off = d_word_off;
     a.ncompute = p->nwg;
-    const int ndec = (batch + kThreads / 64 - 1) / (kThreads / 64);
-    int cus = 0;
-    rc = device_cus(&cus);
-    if (rc) return rc;
     BASIC_REQUIRE(p->nwg + ndec <= cus, "scanline_decode: more workgroups than compute units (the grid must be resident)");
     const size_t dec_lds = (static_cast<size_t>((a.tv.image_words + 3) & ~3) + 4 * static_cast<size_t>(a.tv.rows) + 4) * sizeof(uint32_t);
     if (dec_lds > lds_bytes) lds_bytes = dec_lds;
@@ -1430,6 +2046,23 @@ extern "C" int basic_scanline_can_decode(const basic_scanline_plan *p, const bas
     const int ndec = (batch + kThreads / 64 - 1) / (kThreads / 64);
     const size_t dec_lds = (static_cast<size_t>((tv.image_words + 3) & ~3) + 4 * static_cast<size_t>(tv.rows) + 4) * sizeof(uint32_t);
     *ok = p->nwg + ndec <= cus && dec_lds <= 160 * 1024;
+    return BASIC_OK;
+}
+
+// The largest batch the batched kernel (the batch as the N dimension of MFMA tiles, weights in registers) serves for a latent
+// `w` columns wide on the current device: 0 = never (the layers do not have its shape, or the latent is too narrow);
+// `decode` != 0 counts the decoder workgroups (one wavefront per image stream) too.
+extern "C" int basic_scanline_batched_max(const basic_scanline_plan *p, int w, int decode, int *max_batch)
+{
+    BASIC_REQUIRE(p && max_batch && w >= 1, "scanline_batched_max: bad argument");
+    *max_batch = 0;
+    int cus = 0;
+    int rc = device_cus(&cus);
+    if (rc) return rc;
+    for (int b = 32 * kBatchedMaxTiles; b >= 1; b -= 32) {
+        const int ndec = decode ? (b + kThreads / 64 - 1) / (kThreads / 64) : 0;
+        if (batched_fits(p, b, w, ndec, cus)) { *max_batch = b; break; }
+    }
     return BASIC_OK;
 }
 

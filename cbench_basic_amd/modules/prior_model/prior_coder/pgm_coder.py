@@ -561,16 +561,19 @@ class GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(HotPathModule):
     # matter of speed alone: the encoder and the decoder of a stream need not agree, and nothing about it is recorded in the
     # stream.  The two attributes below are tuning knobs, not part of the format.
     use_persistent_scanline = True
-    persistent_scanline_max_batch = 4    # measured (scripts/scanline_probe.py, C = 192): batch 1 x2.1 in the loop, batch 8 break-even, beyond it the per-step path's batched MFMA launches win
+    # batches up to this one take the lane-per-output persistent kernels (measured, scripts/scanline_probe.py, C = 192: batch 1 x2.1
+    # in the loop, batch 8 break-even with the per-step path); larger ones -- up to ScanlinePlan.batched_max(): 64 images for layers of
+    # BaSIC's shape -- take the batched persistent kernel (round 4: the batch as the N dimension of MFMA tiles, weights in
+    # registers); what neither serves goes to the per-step path
+    persistent_scanline_max_batch = 4
 
-    def _scanline_plan(self, plan, prior, batch=1, decode=False):
+    def _scanline_plan(self, plan, prior, batch=1, decode=False, width=None):
         """The ScanlinePlan serving this call, or None (then the per-step path codes the same integers): the configuration
-        must be the scan-line schedule with dense merger layers that fit the chip's LDS, the batch small enough to pay, and
-        the launch must fit the device (the decoder launch adds one wavefront per image stream and needs the table set's
-        fast search image)."""
+        must be the scan-line schedule with dense merger layers that fit the chip's LDS, the batch one a persistent kernel
+        serves, and the launch must fit the device (the decoder launch adds one wavefront per image stream and needs the
+        table set's fast search image)."""
         if not self.use_persistent_scanline or self.channel_groups != 1 or self.default_topo_group_method != "scanline" \
-                or plan.key != ("default",) or "dense" not in self._layers or batch > self.persistent_scanline_max_batch \
-                or (batch > 1 and not self._per_image(batch)):
+                or plan.key != ("default",) or "dense" not in self._layers or (batch > 1 and not self._per_image(batch)):
             return None
         C2 = self.out_channels
         pc = 0 if prior is None else prior.shape[1]
@@ -586,14 +589,18 @@ class GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(HotPathModule):
                 sp = (None, pc)
             self._layers["scanline"] = sp
         sl = sp[0]
-        if sl is not None and not (sl.can_decode(self._tables, batch) if decode else sl.can_encode(batch)):
+        if sl is None:
+            return None
+        if batch > self.persistent_scanline_max_batch and (width is None or batch > sl.batched_max(width, decode)):
+            return None
+        if not (sl.can_decode(self._tables, batch) if decode else sl.can_encode(batch)):
             return None
         return sl
 
     def _run_encode(self, y, prior, pgm=None):
         self._ready()
         plan = self._plan(y.shape[2], y.shape[3], pgm)
-        sl = self._scanline_plan(plan, prior, y.shape[0])
+        sl = self._scanline_plan(plan, prior, y.shape[0], width=y.shape[3])
         if sl is not None:
             sym, idx, ybuf = sl.encode(y, prior, self._scale_table_dev)
             sl.check()   # a launch whose grid never became resident gave up on its barriers: fail loudly, never code garbage
@@ -767,7 +774,7 @@ class GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(HotPathModule):
         stage = self._tables._stage_in(int(woff[-1]))
         stage.numpy()[:] = np.frombuffer(body, dtype=np.int32, count=int(woff[-1]), offset=payload)
         words_np = stage.numpy()
-        sl = self._scanline_plan(plan, prior, B, decode=True)
+        sl = self._scanline_plan(plan, prior, B, decode=True, width=W)
         if sl is not None:   # persistent scan-line launch (see _run_encode); one stream per image
             d_words = stage.to(dev, non_blocking=True)
             self._tables._pin_in_event = torch.cuda.Event()

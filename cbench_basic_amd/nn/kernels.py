@@ -513,6 +513,16 @@ class ScanlinePlan:
         """The encoder launch needs its workgroups resident: one per compute unit."""
         return self.workgroups <= torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
 
+    def batched_max(self, width, decode=False):
+        """Largest batch the batched persistent kernel serves for a latent `width` columns wide on this device (0: never)."""
+        key = (int(width), bool(decode), torch.cuda.current_device())
+        cache = self.__dict__.setdefault("_batched_max", {})
+        if key not in cache:
+            m = ctypes.c_int()
+            _lib.check(_lib.lib().basic_scanline_batched_max(self._h, int(width), int(bool(decode)), ctypes.byref(m)))
+            cache[key] = m.value
+        return cache[key]
+
     def can_decode(self, tables, batch):
         ok = ctypes.c_int()
         _lib.check(_lib.lib().basic_scanline_can_decode(self._h, tables._h, int(batch), ctypes.byref(ok)))

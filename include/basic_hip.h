@@ -369,6 +369,12 @@ int basic_scanline_decode_dev(basic_scanline_plan *p, const basic_rans_tables *t
  * fits the LDS; compute + decoder workgroups <= compute units); otherwise the caller decodes with the per-step path, which
  * codes the same integers. */
 int basic_scanline_can_decode(const basic_scanline_plan *p, const basic_rans_tables *tables, int batch, int *ok);
+/* Batches of 3 .. 64 images take the BATCHED persistent kernel when the layers have its shape (whole 32-row tiles and 64-channel
+ * canonical blocks, <= 3 dense layers of <= 768 inputs, a context window of <= 36 blocks): the batch is the N dimension of
+ * v_mfma_f32_32x32x2_f32 tiles, a workgroup keeps one row tile of a layer as A fragments in registers, 32 images per set of
+ * workgroups.  *max_batch = the largest batch it serves for a latent `w` columns wide on the current device (0 = never);
+ * decode != 0 counts the decoder workgroups too.  Which kernel serves a call never changes the coded integers. */
+int basic_scanline_batched_max(const basic_scanline_plan *p, int w, int decode, int *max_batch);
 int basic_scanline_status(basic_scanline_plan *p, void *hip_stream, int *poisoned);
 void basic_scanline_plan_destroy(basic_scanline_plan *p);
 

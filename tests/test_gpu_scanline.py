@@ -36,7 +36,10 @@ def _coder(kind, C):
                                            ("merger-expand", 16, 1, 4, 4), ("joint", 32, 2, 3, 6), ("ctxmodel", 192, 11, 3, 4), ("ctxmodel", 48, 1, 1, 1),
                                            ("ctxmodel", 192, 1, 7, 9), ("merger", 192, 2, 4, 5), ("joint", 64, 1, 5, 4), ("ctxmodel", 30, 2, 3, 5),
                                            ("ctxmodel", 192, 1, 5, 1), ("ctxmodel", 192, 2, 3, 2), ("ctxmodel", 48, 2, 1, 6),
-                                           ("ctxmodel-k3", 192, 1, 4, 3), ("ctxmodel-k3", 48, 2, 5, 6)])
+                                           ("ctxmodel-k3", 192, 1, 4, 3), ("ctxmodel-k3", 48, 2, 5, 6),
+                                           # the batched kernel (the batch as the N dimension of MFMA tiles): one and two column tiles, full and ragged
+                                           ("ctxmodel", 192, 8, 3, 5), ("ctxmodel", 192, 24, 4, 4), ("ctxmodel", 192, 64, 3, 4), ("ctxmodel", 192, 33, 2, 6),
+                                           ("ctxmodel", 192, 3, 5, 7), ("ctxmodel", 192, 5, 1, 4), ("ctxmodel-k3", 192, 40, 3, 3)])
 def test_persistent_encode_equals_per_step_path(kind, C, B, H, W):
     coder = _coder(kind, C)
     g = torch.Generator().manual_seed(B * 100 + H * 10 + W)
@@ -50,9 +53,10 @@ def test_persistent_encode_equals_per_step_path(kind, C, B, H, W):
     coder.use_persistent_scanline = True
     coder.persistent_scanline_max_batch = 64
     assert coder._scanline_plan(plan, prior, B) is not None
-    # both persistent kernels: the generic one (any batch) and the pipelined one (batches whose working set fits the LDS)
+    # the persistent kernels: the generic one (any batch), the pipelined one (batches whose working set fits the LDS) and the
+    # batched one (layers of its shape, up to 64 images)
     ran = []
-    for kernel in ("generic", "pipelined", None):
+    for kernel in ("generic", "pipelined", "batched", None):
         if kernel is None:
             os.environ.pop("BASIC_SCAN_KERNEL", None)
         else:
@@ -61,7 +65,7 @@ def test_persistent_encode_equals_per_step_path(kind, C, B, H, W):
             try:
                 s1, i1, y1, _ = coder._run_encode(y, prior)
             except (RuntimeError, ValueError) as e:
-                assert kernel == "pipelined" and "does not fit" in str(e), e   # batch too large, a layer size that is not a multiple of 4, a latent under 4 columns
+                assert kernel in ("pipelined", "batched") and "does not fit" in str(e), e   # batch too large, a layer size that is not a multiple of 4 (batched: of 32 / 64), a narrow latent
                 continue
             coder._layers["scanline"][0].check()
             ms, mi = int((s0 != s1).sum()), int((i0 != i1).sum())
@@ -79,6 +83,7 @@ def test_persistent_encode_equals_per_step_path(kind, C, B, H, W):
             os.environ.pop("BASIC_SCAN_KERNEL", None)
     ks = int(kind.split("-k")[1]) if "-k" in kind else 5
     assert "generic" in ran and ("pipelined" in ran or not (C in (48, 192) and B <= 2 and W >= ks // 2 + 2 and ks <= 5))
+    assert "batched" in ran or not (kind.startswith("ctxmodel") and C == 192 and W >= ks // 2 + 2)   # (other widths: merger layers that are not whole 32-row tiles)
     coder.use_persistent_scanline = False
     assert coder.encode(y, prior=prior) == data
     assert torch.equal(coder.decode(data, prior=prior), y1)
