@@ -92,9 +92,11 @@ struct ScanArgs {
     int nblk[kMaxLayers], rt[kMaxLayers];   // canonical blocks of a layer's K axis; its 32-row tiles
     int ctx_blocks;        // blocks of the first dense layer fed by the context layer (the rest: the prior)
     int tile_off[kMaxLayers];   // dense-role workgroups: LDS float offset of a layer's partial tiles
+    float *wlate;          // [compute workgroups][256 threads][32]: a context workgroup's late blocks as A fragments (written by the launch itself)
 };
 
 typedef float f4 __attribute__((ext_vector_type(4)));
+__host__ __device__ __forceinline__ int64_t bm_gran(int c, int col, int nbt);   // batched kernel's exchange layout (defined with it)
 
 __device__ __forceinline__ uint64_t ld_gran(const uint64_t *p)
 {
@@ -451,7 +453,7 @@ __device__ __forceinline__ void decoder_workgroup(const ScanArgs &a, float *lds)
             if (c < a.C) {
                 const int32_t value = mine + static_cast<int32_t>(rt[2]);
                 const float v = static_cast<float>(value) + mu;           // pgm_coder.py:973-978
-                st_gran(a.yT + (a.nbt ? (static_cast<int64_t>(p) * a.C + c) * a.nbt + b : (static_cast<int64_t>(b) * HW + p) * a.C + c), v, tag);   // first: the compute workgroups wait for it
+                st_gran(a.yT + (a.nbt ? static_cast<int64_t>(p) * a.C * a.nbt + bm_gran(c, b, a.nbt) : (static_cast<int64_t>(b) * HW + p) * a.C + c), v, tag);   // first: the compute workgroups wait for it
                 a.sym[static_cast<int64_t>(b) * a.C * HW + static_cast<int64_t>(p) * a.C + c] = value;
                 a.idx[static_cast<int64_t>(b) * a.C * HW + static_cast<int64_t>(p) * a.C + c] = row;
                 a.ybuf[(static_cast<int64_t>(b) * a.C + c) * HW + p] = v;
@@ -995,9 +997,10 @@ __global__ __launch_bounds__(kThreads) void scanline_pipelined_kernel(const Scan
 // at 64.  Here the BATCH is the N dimension of v_mfma_f32_32x32x2_f32 tiles and the weights never move:
 //   * a column tile = 32 images; the launch runs one independent set of `nw` compute workgroups per column tile (64 images =
 //     two sets), one workgroup per compute unit;
-//   * a workgroup owns ONE 32-row tile of a layer with its whole K axis, as MFMA A fragments IN REGISTERS: a wave keeps up
-//     to nine 32-row x 64-channel blocks (288 VGPRs of the 512 a lone wave per SIMD may use) -- 1.9 M weights = 928 blocks
-//     fit the register files of 32 compute units, and the LDS stays free for partial tiles.  Roles: the first `nd`
+//   * a workgroup owns ONE 32-row tile of a layer with its whole K axis, as MFMA A fragments IN REGISTERS: a wave keeps
+//     eight 32-row x 64-channel blocks (256 of the 512 registers a lone wave per SIMD may use; a context tile's 36 blocks are
+//     4 x 8 resident + four "late" blocks whose fragments are re-fetched each step while the wave waits anyway) -- 1.9 M
+//     weights = 928 blocks fit the register files of 32 compute units, and the LDS stays free for partial tiles.  Roles: the first `nd`
 //     workgroups hold row tile j of EVERY dense layer that has one (layers run one after the other, so their tiles share
 //     the unit), the others one row tile of the context layer (ntaps * C / 64 blocks);
 //   * a canonical block's partial tile (32 rows x 32 images) is one 32-step MFMA chain from zero -- exactly the masked
@@ -1013,142 +1016,191 @@ __global__ __launch_bounds__(kThreads) void scanline_pipelined_kernel(const Scan
 // Exchange protocol, tags, overwrite argument and bounded spins: as in the header comment (a row tile's workgroup consumes ALL
 // inputs of its layer, so "produced" still implies "every input consumed").
 // ================================================================================================================
-constexpr int kBSlots = 9;        // weight blocks a wave keeps in registers
-constexpr int kBLateSlot = 8;     // context role, waves 1 .. bpt: the left neighbour's block
-constexpr int kBDenseSlots = 3;   // blocks per dense layer and wave (a layer's K axis has at most 12)
+constexpr int kBSlots = 8;        // weight blocks a wave keeps in registers for the whole launch (256 registers: the accumulator half of the file)
+constexpr int kBLate = 4;         // context role: the LAST four blocks of the K axis (the left neighbour's among them) run in the late half, one per
+                                  // wave, with weights re-fetched every step from the workgroup's fragment copy (a ninth resident block spills)
+constexpr int kBDenseSlots = 3;   // blocks per dense layer and wave (a layer's K axis has at most 12; the last layer's at most 8: slots 6, 7)
 constexpr int kBTile = 1024;      // floats of a 32 x 32 partial tile
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-__device__ __forceinline__ uint32_t gran_tag(uint64_t g) { return static_cast<uint32_t>(g >> 32); }
-__device__ __forceinline__ float gran_val(uint64_t g) { return __uint_as_float(static_cast<uint32_t>(g)); }
-
-// this lane's 32 B-fragment granules of a block: base + i * stride + voff, i = 0 .. 31 (channel 2 i + lane / 32 of the block, image
-// lane % 32).  `base` and `stride` (bytes) are wave-uniform, `voff` is the lane's byte offset inside a (channel pair, column tile)
-// slab and never changes: every load is `global_load_dwordx2 v, v_off, s[base]` -- one VGPR of addressing for the whole kernel
-// instead of a 64-bit address per load in flight
-struct BSrc {
-    const char *base;
-    int stride;
-    uint32_t want;
-};
-
-__device__ __forceinline__ uint64_t ld_gran_at(const char *ubase, uint32_t voff)
+// ---- batch-minor exchange arrays.  A [channels][nbt] slab of granules is stored in 16-byte pieces that hold the granules of
+//      channels 4 m + h and 4 m + 2 + h of one column: the B operands of two consecutive MFMA steps of lane (h, column % 32), so
+//      a lane fetches a block's 32 operands with sixteen 16-byte loads (each 8-byte half still validates itself by its tag).
+//      Granule index of (channel c, column col):
+__host__ __device__ __forceinline__ int64_t bm_gran(int c, int col, int nbt)
 {
-    return __hip_atomic_load(reinterpret_cast<uint64_t *>(const_cast<char *>(ubase) + voff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return (static_cast<int64_t>((c >> 2) * 2 + (c & 1)) * nbt + col) * 2 + ((c >> 1) & 1);
+}
+//      The prior (plain floats, an input of the launch) likewise in 16-byte pieces of channels 8 m + 2 j + h, j = 0 .. 3: four steps
+//      per load.  Float index of (channel c, column col) inside a position's [P][nbt] slab:
+__host__ __device__ __forceinline__ int64_t bm_prior(int c, int col, int nbt)
+{
+    return (static_cast<int64_t>((c >> 3) * 2 + (c & 1)) * nbt + col) * 4 + ((c >> 1) & 3);
 }
 
-// (the lane offset goes through an empty asm: hipcc would otherwise hoist the 32 addresses of every block of every layer out of
-// the coding loop -- they do not change from step to step -- and spill hundreds of 64-bit values)
-__device__ __forceinline__ void b_issue(const BSrc &s, uint32_t voff, bool on, uint64_t (&g)[32])
+// A lone wave per SIMD issues one instruction per ~8-10 clocks, so a block's cost beside its 32 MFMAs (0.85 us) is its
+// instruction count.  Operands are fetched with BUFFER loads: descriptor = the array, soffset (SGPR) = the block's and the piece's
+// wave-uniform byte offset, voffset = the lane's constant 32-bit offset -- no vector ALU work per load, sixteen `buffer_load_dwordx4
+// ... offen sc1` back to back (a `volatile` 16-byte global load would do too, but hipcc follows every volatile access with
+// s_waitcnt vmcnt(0): sixteen serial round trips per block, measured 4.4 us) -- and validated with one min-tree over the 32 tags
+// instead of 32 compare-and-branch pairs.  The lane offset goes through an empty asm: it keeps hipcc from treating the loads of
+// different steps (same address, no store in sight) as one, and from hoisting per-load addresses out of the coding loop.
+typedef __amdgpu_buffer_rsrc_t brsrc;
+__device__ __forceinline__ brsrc b_rsrc(const void *p) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, 0x7FFFFFFF, 0x00020000); }
+constexpr int kSc1 = 16;   // cache-policy bit of the raw buffer builtins: sc1 (agent scope: served at the L2 / memory side, never by this CU's L1)
+
+__device__ __forceinline__ u64x2 b_ld2(brsrc r, uint32_t voff, int soff)
 {
+    return __builtin_bit_cast(u64x2, __builtin_amdgcn_raw_buffer_load_b128(r, static_cast<int>(voff), soff, kSc1));
+}
+
+__device__ __forceinline__ void b_issue(brsrc r, int sbase, int stride, uint32_t voff, u64x2 (&g)[16])
+{
+    uint32_t vo = voff;
+    int sb = sbase;   // (opaque too: the sixteen scalar offsets of every block would otherwise be hoisted out of the coding loop and spilled)
+    asm volatile("" : "+v"(vo), "+s"(sb)::"memory");
 #pragma unroll
-    for (int i = 0; i < 32; ++i) g[i] = 0ull;
-    if (on) {
-        uint32_t vo = voff;
-        asm volatile("" : "+v"(vo));
+    for (int m = 0; m < 16; ++m) g[m] = b_ld2(r, vo, sb + m * stride);
+}
+
+// the smallest of the 32 tags: a stale granule carries an older (smaller) tag or 0, never a newer one (overwrite argument)
+__device__ __forceinline__ uint32_t b_min_tag(const u64x2 (&g)[16])
+{
+    uint32_t mn = 0xFFFFFFFFu;
 #pragma unroll
-        for (int i = 0; i < 32; ++i) g[i] = ld_gran_at(s.base, vo + static_cast<uint32_t>(i * s.stride));
+    for (int m = 0; m < 16; ++m) mn = min(min(mn, static_cast<uint32_t>(g[m][0] >> 32)), static_cast<uint32_t>(g[m][1] >> 32));
+    return mn;
+}
+
+// waits until all 32 granules carry `want` (re-issuing the block's loads while one is missing); false = poisoned launch
+__device__ __forceinline__ bool b_wait(const ScanArgs &a, brsrc r, int sbase, int stride, uint32_t voff, uint32_t want, u64x2 (&g)[16])
+{
+    unsigned spins = 0;
+    while (__ballot(b_min_tag(g) != want) != 0ull) {
+        if (++spins > kSpinLimit || (spins % 256u == 0u && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+            __hip_atomic_store(a.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+        }
+        b_issue(r, sbase, stride, voff, g);
     }
+    return true;
 }
 
-// re-loads whatever does not carry the tag yet; wave-uniform result, false = poisoned launch
-__device__ __forceinline__ bool b_validate(const ScanArgs &a, const BSrc &s, uint32_t voff, bool on, uint64_t (&g)[32])
+// one piece polled alone before a block's loads are issued: a wave that waits LONG (the context role, idle through the dense
+// layers) keeps one load in flight instead of sixteen
+__device__ __forceinline__ bool b_sentinel(const ScanArgs &a, brsrc r, int soff, uint32_t voff, uint32_t want)
 {
-    bool ok = true;
-    if (on) {
-        unsigned spins = 0;
-        for (;;) {
-            bool all = true;
-            uint32_t vo = voff;
-            asm volatile("" : "+v"(vo));
-#pragma unroll
-            for (int i = 0; i < 32; ++i)
-                if (gran_tag(g[i]) != s.want) { g[i] = ld_gran_at(s.base, vo + static_cast<uint32_t>(i * s.stride)); all = false; }
-            if (all) break;
-            if (++spins > kSpinLimit || (spins % 1024u == 0u && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-                __hip_atomic_store(a.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ok = false;
-                break;
-            }
+    unsigned spins = 0;
+    for (;;) {
+        uint32_t vo = voff;
+        asm volatile("" : "+v"(vo)::"memory");
+        const u64x2 g = b_ld2(r, vo, soff);
+        if (__ballot(min(static_cast<uint32_t>(g[0] >> 32), static_cast<uint32_t>(g[1] >> 32)) != want) == 0ull) return true;
+        if (++spins > kSpinLimit || (spins % 256u == 0u && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+            __hip_atomic_store(a.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
         }
     }
-    return __ballot(!ok) == 0ull;
 }
 
-// one granule polled alone before a block's 32 loads are issued: while the producers are still computing, a waiting wave
-// keeps one load in flight instead of thirty-two
-__device__ __forceinline__ bool b_sentinel(const ScanArgs &a, const uint64_t *p, uint32_t want, bool on)
-{
-    bool ok = true;
-    if (on) {
-        uint64_t g = ld_gran(p);
-        ok = wait_gran(a, p, want, g);
-    }
-    return __ballot(!ok) == 0ull;
-}
-
-// the canonical block: one MFMA chain from zero over the block's 32 channel pairs, in ascending order
-template <class BF> __device__ __forceinline__ f32x16 b_chain(const float (&wr)[32], BF &&bf)
-{
-    f32x16 acc;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-#pragma unroll
-    for (int i = 0; i < 32; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[i], bf(i), acc, 0, 0, 0);
-    return acc;
-}
-
-// Weight slots 0 .. 7 live in the ACCUMULATOR half of the register file, a[32 k .. 32 k + 31], for the whole launch (an MFMA
-// takes its A operand from there directly); hipcc would spill a 288-register array that is live across the whole kernel, so
-// these 256 registers are named literally: written once (b_put_weights), read only by the MFMAs of b_chain_acc, reserved by
-// the clobber list of b_reserve_acc -- and the build is audited for a spill count of zero and for no compiler v_accvgpr_*
-// (cdna_hip_programming.md 5.7 item 4).  Nothing inside an asm string is padded by the compiler: every MFMA is preceded by the
-// two wait states a just-written B operand needs, and the chain ends with the 19 states a 16-pass MFMA's result needs
-// before anything but the next MFMA of the chain touches it.
-#define BASIC_A16(n) "a" #n "0", "a" #n "1", "a" #n "2", "a" #n "3", "a" #n "4", "a" #n "5", "a" #n "6", "a" #n "7", "a" #n "8", "a" #n "9"
+// ---- Resident weights.  The eight blocks a wave keeps for the whole launch live in the ACCUMULATOR half of the register file,
+//      a[32 k + i] = A fragment i of slot k (an MFMA takes its A operand from there directly).  As a C++ array hipcc spills part of
+//      it whatever the slack (its allocator treats the unified file as two halves and parks / spills around the long live ranges),
+//      and a spilled weight is re-read inside the chain behind an s_waitcnt vmcnt(0).  So the 256 registers are named literally
+//      (cdna_hip_programming.md 5.7 item 4): written once (b_put_weights), read only by the MFMAs below, reserved by the clobber
+//      list of b_reserve_acc; EVERY MFMA of the kernel is an asm statement with its accumulator in VGPRs, so the compiler itself has
+//      no use for the accumulator file -- `make audit` checks the generated code: no spill, no compiler-issued v_accvgpr_*.
+//      Nothing inside an asm string is padded by the compiler: every MFMA is preceded by the two wait states a just-written B
+//      operand needs, and a chain ends with the 19 states a 16-pass MFMA's result needs before anything but the next MFMA of the
+//      chain touches it.
+#define BASIC_A10(n) "a" #n "0", "a" #n "1", "a" #n "2", "a" #n "3", "a" #n "4", "a" #n "5", "a" #n "6", "a" #n "7", "a" #n "8", "a" #n "9"
 __device__ __forceinline__ void b_reserve_acc()
 {
-    asm volatile("" ::: "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", BASIC_A16(1), BASIC_A16(2), BASIC_A16(3), BASIC_A16(4),
-                 BASIC_A16(5), BASIC_A16(6), BASIC_A16(7), BASIC_A16(8), BASIC_A16(9), BASIC_A16(10), BASIC_A16(11), BASIC_A16(12), BASIC_A16(13),
-                 BASIC_A16(14), BASIC_A16(15), BASIC_A16(16), BASIC_A16(17), BASIC_A16(18), BASIC_A16(19), BASIC_A16(20), BASIC_A16(21),
-                 BASIC_A16(22), BASIC_A16(23), BASIC_A16(24), "a250", "a251", "a252", "a253", "a254", "a255");
+    asm volatile("" ::: "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", BASIC_A10(1), BASIC_A10(2), BASIC_A10(3), BASIC_A10(4),
+                 BASIC_A10(5), BASIC_A10(6), BASIC_A10(7), BASIC_A10(8), BASIC_A10(9), BASIC_A10(10), BASIC_A10(11), BASIC_A10(12), BASIC_A10(13),
+                 BASIC_A10(14), BASIC_A10(15), BASIC_A10(16), BASIC_A10(17), BASIC_A10(18), BASIC_A10(19), BASIC_A10(20), BASIC_A10(21),
+                 BASIC_A10(22), BASIC_A10(23), BASIC_A10(24), "a250", "a251", "a252", "a253", "a254", "a255");
 }
-#undef BASIC_A16
+#undef BASIC_A10
 
-template <int K> __device__ __forceinline__ void b_put_weights(const float *src)   // src == nullptr: an unused slot (zeros)
-{
-    static_for<0, 32>([&](auto ic) {
-        constexpr int i = decltype(ic)::value;
-        const float x = src ? src[2 * i] : 0.f;
-        asm volatile("v_accvgpr_write_b32 a[%c1], %0" ::"v"(x), "n"(K * 32 + i));
-    });
-}
-
-template <int K, int I, class BF> __device__ __forceinline__ void b_chain_acc_step(f32x16 &acc, BF &bf)
+template <int K, int I> __device__ __forceinline__ void b_put_weights_step(const float *src, bool valid)
 {
     if constexpr (I < 32) {
-        const float b = bf(I);
-        asm volatile("s_nop 1\n\tv_mfma_f32_32x32x2_f32 %0, a[%c2], %1, %0" : "+v"(acc) : "v"(b), "n"(K * 32 + I));
-        b_chain_acc_step<K, I + 1>(acc, bf);
+        const float x = valid ? src[2 * I] : 0.f;
+        asm volatile("v_accvgpr_write_b32 a[%c1], %0" ::"v"(x), "n"(K * 32 + I));
+        b_put_weights_step<K, I + 1>(src, valid);
     }
 }
+template <int K> __device__ __forceinline__ void b_put_weights(const float *src, bool valid) { b_put_weights_step<K, 0>(src, valid); }
 
-template <int K, class BF> __device__ __forceinline__ f32x16 b_chain_acc(BF &&bf)
+__device__ __forceinline__ f32x16 b_zero16()
 {
-    f32x16 acc;
+    f32x16 z;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    b_chain_acc_step<K, 0>(acc, bf);
-    asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc));
+    for (int i = 0; i < 16; ++i) z[i] = 0.f;
+    return z;
+}
+
+// acc += A(slot K, fragment I) x b   /   acc += wv x b   (one v_mfma_f32_32x32x2_f32 each)
+template <int K, int I> __device__ __forceinline__ void b_mfma_res(f32x16 &acc, float b)
+{
+    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x2_f32 %0, a[%c2], %1, %0" : "+v"(acc) : "v"(b), "n"(K * 32 + I));
+}
+__device__ __forceinline__ void b_mfma_vgpr(f32x16 &acc, float wv, float b)
+{
+    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x2_f32 %0, %2, %1, %0" : "+v"(acc) : "v"(b), "v"(wv));
+}
+__device__ __forceinline__ void b_chain_end(f32x16 &acc) { asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc)); }
+
+// the canonical block: one MFMA chain from zero over the block's 32 channel pairs, in ascending order, A fragments = resident slot
+// K, B = the block's granules.  With kRefill every piece is re-loaded from `nbase` (the block after next of this wave) as soon as
+// its two MFMAs have read it: two blocks' loads are in flight or landed at any time with 128 registers of buffers
+template <int K, bool kRefill, int M> __device__ __forceinline__ void b_chain_gran_step(f32x16 &acc, u64x2 (&g)[16], brsrc r, int nb, int stride, uint32_t vo)
+{
+    if constexpr (M < 16) {
+        b_mfma_res<K, 2 * M>(acc, __uint_as_float(static_cast<uint32_t>(g[M][0])));
+        b_mfma_res<K, 2 * M + 1>(acc, __uint_as_float(static_cast<uint32_t>(g[M][1])));
+        if constexpr (kRefill) {
+            g[M] = b_ld2(r, vo, nb + M * stride);
+            __builtin_amdgcn_sched_barrier(0);   // (keeps the loads between the MFMAs: issued under the matrix pipe's 64-cycle steps)
+        }
+        b_chain_gran_step<K, kRefill, M + 1>(acc, g, r, nb, stride, vo);
+    }
+}
+template <int K, bool kRefill> __device__ __forceinline__ f32x16 b_chain_gran(u64x2 (&g)[16], brsrc r, int nbase, int stride, uint32_t voff)
+{
+    f32x16 acc = b_zero16();
+    uint32_t vo = voff;
+    int nb = nbase;
+    asm volatile("" : "+v"(vo), "+s"(nb)::"memory");
+    b_chain_gran_step<K, kRefill, 0>(acc, g, r, nb, stride, vo);
+    b_chain_end(acc);
     return acc;
 }
 
-// slot K of this wave: accumulator-file slots below 8, the wave's VGPR array for the ninth
-template <int K, class BF> __device__ __forceinline__ f32x16 b_chain_slot(const float (&w8)[32], BF &&bf)
+// the same chain with A fragments and B operands both in VGPRs (a streamed block; a block fed by the prior)
+template <class AF, class BF> __device__ __forceinline__ f32x16 b_chain_vv(AF &&af, BF &&bf)
 {
-    if constexpr (K < 8) return b_chain_acc<K>(bf);
-    else return b_chain(w8, bf);
+    f32x16 acc = b_zero16();
+#pragma unroll
+    for (int i = 0; i < 32; ++i) b_mfma_vgpr(acc, af(i), bf(i));
+    b_chain_end(acc);
+    return acc;
+}
+template <int K, int I, class BF> __device__ __forceinline__ void b_chain_res_step(f32x16 &acc, BF &bf)
+{
+    if constexpr (I < 32) {
+        b_mfma_res<K, I>(acc, bf(I));
+        b_chain_res_step<K, I + 1>(acc, bf);
+    }
+}
+template <int K, class BF> __device__ __forceinline__ f32x16 b_chain_res(BF &&bf)   // resident slot K, B operands from a callable
+{
+    f32x16 acc = b_zero16();
+    b_chain_res_step<K, 0>(acc, bf);
+    b_chain_end(acc);
+    return acc;
 }
 
 // accumulator layout of the 32 x 32 tile: lane holds image lane % 32, rows 8 q + 4 (lane / 32) + j for register 4 q + j; the
@@ -1190,15 +1242,17 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
     const int HW = a.H * a.W, C = a.C, NBT = a.nbt, T = NBT >> 5;
     const int t = wg % T, j = wg / T;                  // column tile; role index inside the tile's set of workgroups
     const int h = lane >> 5, n = lane & 31, col = t * 32 + n;
-    const bool img = col < a.B;                        // columns beyond the batch: nothing loaded, nothing published
+    const bool img = col < a.B;                        // columns beyond the batch: nothing published (they LOAD the last image's
+    const int colc = img ? col : a.B - 1;              // operands: no predicates, no zero fill in the load paths)
     const bool dense = j < a.nd;
     const int r0 = dense ? j : j - a.nd;               // this workgroup's row tile (dense role: of every layer that has one)
-    const int early = (a.ntaps - 1) * a.bpt;           // context blocks of the taps coded at least two steps ago
+    const int nb0 = a.ntaps * a.bpt;                   // context blocks; the last kBLate run in the late half (the left neighbour's bpt among them),
+    const int early = nb0 - kBLate;                    // the others -- taps coded at least two steps ago -- one step ahead
     const int frow = 8 * wave + 4 * h;                 // first of this thread's four finishing rows inside the tile
-    // the lane's place inside a (channel pair, column tile) slab of a batch-minor array: granule arrays / float arrays (bytes)
-    const uint32_t voff8 = static_cast<uint32_t>(h * NBT + col) * 8u, voff4 = static_cast<uint32_t>(h * NBT + col) * 4u;
-    const int gstride = 2 * NBT * 8;                   // bytes between consecutive channel pairs of a granule array
-    const uint32_t soff = static_cast<uint32_t>(frow * NBT + col);   // granule index of this thread's first finishing row inside its tile's rows
+    const uint32_t voff = static_cast<uint32_t>(h * NBT + colc) * 16u;   // the lane's 16-byte piece inside a (channel quad, column tile) slab
+    const int pstride = 2 * NBT * 16;                  // bytes between consecutive pieces of a lane
+    // granule index of this thread's first finishing row (channel r0 * 32 + frow) relative to its tile's first piece
+    const uint32_t soff = static_cast<uint32_t>(((frow >> 2) * 2 * NBT + col) * 2);
 
     // LDS: [scale table][flags][biases of this workgroup's row tiles: 3 x 32][partial tiles]
     float *tab = lds;
@@ -1218,111 +1272,143 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
     __syncthreads();
     const bool tab_sorted = s_flag[1] != 0;
 
-    // ---- this wave's weight blocks: A fragments, lane = (row lane % 32 of the tile, channel parity lane / 32)
-    float wreg[kBSlots][32];
+    // ---- this wave's resident weight blocks: A fragments (lane = row lane % 32 of the tile, channel parity lane / 32) in the
+    // accumulator file, see b_put_weights
+    b_reserve_acc();
     static_for<0, kBSlots>([&](auto kc) {
         constexpr int k = decltype(kc)::value;
-        const float *src = nullptr;
-        if (dense) {
-            constexpr int l = 1 + k / kBDenseSlots;
-            const int b = wave + 4 * (k % kBDenseSlots);
-            if (l < a.nlayers && r0 < a.rt[l] && b < a.nblk[l]) src = a.w[l] + static_cast<int64_t>(r0 * 32 + n) * a.kdim[l] + 64 * b + h;
-        } else {
-            const int e = (k == kBLateSlot && wave != 0) ? early + wave - 1 : wave + 4 * k;
-            const bool v = (k == kBLateSlot && wave != 0) ? wave <= a.bpt : e < early;
-            if (v) src = a.w[0] + static_cast<int64_t>(r0 * 32 + n) * a.kdim[0] + 64 * e + h;
-        }
-#pragma unroll
-        for (int i = 0; i < 32; ++i) wreg[k][i] = src ? src[2 * i] : 0.f;
+        constexpr int l = 1 + k / kBDenseSlots;                      // dense role: the slot's layer and block
+        const int b = wave + 4 * (k % kBDenseSlots), e = wave + 4 * k;   // context role: its early block
+        const bool v = dense ? (l < a.nlayers && r0 < a.rt[l] && b < a.nblk[l]) : e < early;   // wave-uniform
+        const int li = dense ? (l < a.nlayers ? l : 0) : 0;
+        b_put_weights<k>(a.w[li] + static_cast<int64_t>(r0 * 32 + n) * a.kdim[li] + 64 * (dense ? b : e) + h, v);
     });
+    asm volatile("s_nop 4" ::: "memory");   // (accumulator writes -> the first MFMA that reads them)
     const f4 zero4 = f4{0.f, 0.f, 0.f, 0.f};
-    f32x16 zero16;
+    u64x2 gA[16], gB[16];
+
+    // publishes this thread's four finishing rows of its tile into a [rows][nbt] exchange slab (tile = slab + the tile's first piece)
+    auto publish4 = [&](uint64_t *tile, const f4 &v, uint32_t tag) {
+        if (!img) return;
+        uint32_t so = soff;
+        asm volatile("" : "+v"(so));   // (or the four addresses are hoisted out of the coding loop and spilled)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) zero16[i] = 0.f;
-    uint64_t gA[32], gB[32];
+        for (int i = 0; i < 4; ++i) st_gran(tile + (so + static_cast<uint32_t>((i & 1) * 2 * NBT + (i >> 1))), v[i], tag);
+    };
 
     if (!dense) {
         // ================= context role: row tile r0 of the masked context convolution =================
         const char *yT8 = reinterpret_cast<const char *>(a.yT);
+        const int blk_bytes = 16 * pstride;   // a 64-channel block of a slab
+        uint64_t *out_tile = a.act[0] + static_cast<int64_t>(r0 * 8) * 2 * NBT * 2;
+        const int64_t pos_bytes = static_cast<int64_t>(C) * NBT * 8;   // a position's slab of the coded latent
         f4 esum = zero4;   // position 0 has no causal neighbour: its early sum is zero
-        int px = 0;
+        int px = 0, py = 0;
+        // this wave's late block as A fragments, lane-major (8 x 16 bytes per lane): saved once, re-fetched every step
+        const char *wfrag = reinterpret_cast<const char *>(a.wlate) + static_cast<int64_t>(wg) * (kThreads * 128);
+        {
+            const int e = early + wave;
+            const float *src = a.w[0] + static_cast<int64_t>(r0 * 32 + n) * a.kdim[0] + 64 * e + h;
+            float *dst = reinterpret_cast<float *>(const_cast<char *>(wfrag)) + tid * 32;
+#pragma unroll
+            for (int i = 0; i < 32; ++i) dst[i] = src[2 * i];
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        const bool prof1 = a.prof && wg == a.nd * T && tid == 64, prof0 = a.prof && wg == a.nd * T && tid == 0;   // BASIC_SCAN_PROFILE: first context workgroup, waves 1 / 0
+        const long long loop_t0 = prof0 ? wall_clock64() : 0;
         for (int p = 0; p < HW; ++p) {
             const uint32_t tag = static_cast<uint32_t>(p + 1);
-            // ---------- late half: the left neighbour's blocks.  A row's first position has none (zeros), but the overwrite
-            // argument of the exchange arrays needs this step to start after position p - 1 is coded: its granules are waited
-            // for all the same
-            if (wave >= 1 && wave <= a.bpt) {
-                f32x16 acc = zero16;
-                if (p > 0) {
-                    const BSrc s{yT8 + (static_cast<int64_t>(p - 1) * C + 64 * (wave - 1)) * NBT * 8, gstride, static_cast<uint32_t>(p)};
-                    bool ok = b_sentinel(a, reinterpret_cast<const uint64_t *>(s.base + static_cast<int64_t>(31) * s.stride + voff8), s.want, img);
-                    b_issue(s, voff8, img, gA);
-                    ok = b_validate(a, s, voff8, img, gA) && ok;
-                    if (!ok) return;
-                    if (px > 0) acc = b_chain(wreg[kBLateSlot], [&](int i) { return gran_val(gA[i]); });
+            const long long tp0 = a.prof ? wall_clock64() : 0;
+            long long tp1 = tp0;
+            // ---------- late half: the last four blocks of the K axis, one per wave.  The left neighbour's (the last tap's) need
+            // position p - 1, coded a moment ago: sentinel, then tags.  A row's first position has no left neighbour (zeros), but
+            // the overwrite argument of the exchange arrays needs this step to start after position p - 1 is coded: its granules
+            // are waited for all the same.  The block's weights come from this wave's fragment copy, requested before the wait
+            {
+                const int e = early + wave, tp = e / a.bpt, cb = e - tp * a.bpt;
+                const bool left = tp == a.ntaps - 1;
+                const int ny = py + a.tap_dy[tp], nx = px + a.tap_dx[tp];
+                const bool inside = ny >= 0 && nx >= 0 && nx < a.W;
+                f4 wl4[8];
+                {
+                    uint32_t fo = static_cast<uint32_t>(tid) * 128u;
+                    asm volatile("" : "+v"(fo)::"memory");
+#pragma unroll
+                    for (int m = 0; m < 8; ++m) wl4[m] = *reinterpret_cast<const f4 *>(wfrag + (fo + static_cast<uint32_t>(m * 16)));
                 }
-                b_store_tile(part + (early + wave - 1) * kBTile, lane, acc);
+                f32x16 acc = b_zero16();
+                if (inside || (left && p > 0)) {
+                    const int pos = left ? p - 1 : p + a.tap_off[tp];
+                    const brsrc yr = b_rsrc(yT8 + pos * pos_bytes);
+                    const int sb = cb * blk_bytes;
+                    if (left && !b_sentinel(a, yr, sb + 15 * pstride, voff, static_cast<uint32_t>(pos + 1))) return;
+                    if (a.prof) tp1 = wall_clock64();
+                    b_issue(yr, sb, pstride, voff, gA);
+                    if (!b_wait(a, yr, sb, pstride, voff, static_cast<uint32_t>(pos + 1), gA)) return;
+                    if (inside)
+                        acc = b_chain_vv([&](int i) { return wl4[i >> 2][i & 3]; }, [&](int i) { return __uint_as_float(static_cast<uint32_t>(gA[i >> 1][i & 1])); });
+                }
+                b_store_tile(part + e * kBTile, lane, acc);
             }
+            const long long tp2 = a.prof ? wall_clock64() : 0;
             lds_barrier();
             {
-                f4 v = b_sum_tiles(esum, part + early * kBTile, a.bpt, tid);
+                f4 v = b_sum_tiles(esum, part + early * kBTile, kBLate, tid);
                 v += *reinterpret_cast<const f4 *>(bias_s + frow);
                 if (a.act_after[0]) v = b_leaky(v);
-                if (img) {
-                    uint32_t so = soff;
-                    asm volatile("" : "+v"(so));   // (or the four addresses are hoisted out of the coding loop and spilled)
-                    uint64_t *dst = a.act[0] + static_cast<int64_t>(r0 * 32) * NBT;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) st_gran(dst + (so + static_cast<uint32_t>(i * NBT)), v[i], tag);
-                }
+                publish4(out_tile, v, tag);
             }
-            if (++px == a.W) px = 0;
+            const long long tp3 = a.prof ? wall_clock64() : 0;
+            if (prof1) { a.prof[0] += tp1 - tp0; a.prof[1] += tp2 - tp1; a.prof[2] += tp3 - tp2; }
+            if (++px == a.W) { px = 0; ++py; }
             if (p + 1 == HW) break;
             // ---------- early half for the next position q = p + 1, in the shadow of the dense layers: partial tiles of the blocks
             // of the taps coded at least two steps ago, then their sum in block order.  Every granule read here was validated by
             // this workgroup's late waves in an earlier step (the newest, position p - 1, in this step's late half, before the
-            // barrier above), so only the value halves are loaded: 32 registers per block in flight instead of 64, and the
-            // loads of TWO blocks ahead are in flight under a block's chain (a wave has 63 outstanding loads at most; a block's
-            // loads take ~1.5 us to land, its chain 0.85)
-            const int q = p + 1, qy = q / a.W, qx = px;
-            float eb0[32], eb1[32], eb2[32];
-            auto issue_early = [&](int e, float (&dst)[32]) -> bool {   // false: the tap lies outside the image (zeros)
+            // barrier above), so the tags are not looked at again.  Two buffers: while block k's chain runs, its buffer is
+            // re-filled piece by piece with block k + 2 (the loads sit between the MFMAs, where a lone wave's issue slots are
+            // free), block k + 1 landed during the chain before
+            const int q = p + 1, qy = py, qx = px;
+            auto early_valid = [&](int kk) { return wave + 4 * kk < early; };
+            // block e of this position's early window: false when its tap lies outside the image (zeros); r / sb = where its operands are
+            auto early_src = [&](int e, brsrc &r, int &sb) -> bool {
                 const int tp = e / a.bpt, cb = e - tp * a.bpt;
                 const int ny = qy + a.tap_dy[tp], nx = qx + a.tap_dx[tp];
-                if (!(ny >= 0 && nx >= 0 && nx < a.W)) return false;
-                const char *base = yT8 + (static_cast<int64_t>(q + a.tap_off[tp]) * C + 64 * cb) * NBT * 8;
-#pragma unroll
-                for (int i = 0; i < 32; ++i) dst[i] = 0.f;
-                if (img) {
-                    uint32_t vo = voff8;
-                    asm volatile("" : "+v"(vo));
-#pragma unroll
-                    for (int i = 0; i < 32; ++i)
-                        dst[i] = __uint_as_float(__hip_atomic_load(reinterpret_cast<uint32_t *>(const_cast<char *>(base) + (vo + static_cast<uint32_t>(i * gstride))),
-                                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                }
-                return true;
+                const bool inside = ny >= 0 && nx >= 0 && nx < a.W;
+                r = b_rsrc(yT8 + (inside ? q + a.tap_off[tp] : q - 1) * pos_bytes);   // (outside: any coded position -- loaded into a buffer nobody reads)
+                sb = cb * blk_bytes;
+                return inside;
             };
-            auto early_valid = [&](int kk) { return wave + 4 * kk < early && !(kk == kBLateSlot && wave != 0); };
-            bool in_a = early_valid(0) && issue_early(wave, eb0);
-            bool in_b = early_valid(1) && issue_early(wave + 4, eb1);
-            bool in_c = false;
+            bool have_a = false, have_b = false;   // whether buffer A / B holds (or is receiving) a block that is used
+            {
+                brsrc r; int sb;
+                if (early_valid(0) && (have_a = early_src(wave, r, sb))) b_issue(r, sb, pstride, voff, gA);
+                if (early_valid(1) && (have_b = early_src(wave + 4, r, sb))) b_issue(r, sb, pstride, voff, gB);
+            }
             static_for<0, kBSlots>([&](auto kc) {
                 constexpr int k = decltype(kc)::value;
                 if (!early_valid(k)) return;
-                float(&cur)[32] = *((k % 3 == 0) ? &eb0 : (k % 3 == 1) ? &eb1 : &eb2);
-                float(&nxt)[32] = *((k % 3 == 0) ? &eb2 : (k % 3 == 1) ? &eb0 : &eb1);   // buffer of block k + 2
-                bool &in_cur = (k % 3 == 0) ? in_a : (k % 3 == 1) ? in_b : in_c;
-                bool &in_nxt = (k % 3 == 0) ? in_c : (k % 3 == 1) ? in_a : in_b;
-                const bool have = in_cur;
-                f32x16 acc = zero16;
-                if (have) acc = b_chain(wreg[k], [&](int i) { return cur[i]; });   // (a tap outside the image enters as zeros: the block's partial is zero)
-                if (k + 2 < kBSlots) in_nxt = early_valid(k + 2) && issue_early(wave + 4 * (k + 2), nxt);
+                u64x2(&cur)[16] = *((k & 1) ? &gB : &gA);
+                bool &have_cur = (k & 1) ? have_b : have_a;
+                brsrc r2 = b_rsrc(yT8);
+                int sb2 = 0;
+                const bool next = k + 2 < kBSlots && early_valid(k + 2);
+                const bool have_next = next && early_src(wave + 4 * (k + 2), r2, sb2);
+                f32x16 acc = b_zero16();
+                if (have_cur) {
+                    if (!next) early_src(wave + 4 * k, r2, sb2);   // nothing follows: the refill re-reads this block (no second copy of the chain)
+                    acc = b_chain_gran<k, true>(cur, r2, sb2, pstride, voff);
+                } else if (have_next) {
+                    b_issue(r2, sb2, pstride, voff, cur);   // (a tap outside the image enters as zeros: no chain to hide the loads behind)
+                }
+                have_cur = have_next;
                 b_store_tile(part + (wave + 4 * k) * kBTile, lane, acc);
             });
             lds_barrier();
             esum = b_sum_tiles(zero4, part, early, tid);
+            if (prof0) a.prof[3] += wall_clock64() - tp3;
         }
+        if (prof0) a.prof[4 * kMaxLayers + 2] = wall_clock64() - loop_t0;
         return;
     }
 
@@ -1330,9 +1416,11 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
     const int last = a.nlayers - 1;
     const bool codes = r0 < a.rt[last] && img;     // this thread finishes two (mean, scale) pairs of image `col`
     const int c0 = (r0 * 32 + frow) >> 1;          // its channels c0, c0 + 1  (rows 2c = mean, 2c + 1 = scale: "split_interleave")
-    // element offsets of (image col, channel c0) in y / ybuf [B][C][HW], sym / idx [B][HW * C], yT [HW][C][nbt], mu / idx_step [nbt][C]
+    // element offsets of (image col, channel c0) in y / ybuf [B][C][HW], sym / idx [B][HW * C], the coded latent's slab, mu / idx_step [nbt][C]
     const uint32_t yoff = static_cast<uint32_t>((col * C + c0) * HW), ooff = static_cast<uint32_t>(col * C * HW + c0);
-    const uint32_t toff = static_cast<uint32_t>(c0 * NBT + col), moff = static_cast<uint32_t>(col * C + c0);
+    const uint32_t toff = static_cast<uint32_t>(bm_gran(c0, col, NBT)), moff = static_cast<uint32_t>(col * C + c0);
+    const bool prof = a.prof && wg == 0 && tid == 0;   // BASIC_SCAN_PROFILE: first dense workgroup, wave 0
+    const long long loop_c0 = prof ? clock64() : 0, loop_t0 = prof ? wall_clock64() : 0;
     for (int p = 0; p < HW; ++p) {
         const uint32_t tag = static_cast<uint32_t>(p + 1);
         // (per-thread element offsets stay 32-bit and opaque: as 64-bit addresses hoisted out of the loop they would be spilled)
@@ -1349,94 +1437,105 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1))
             if (l > last || r0 >= a.rt[l] || !alive) return;
             float *tiles = part + a.tile_off[l];
             const int fed = l == 1 ? a.ctx_blocks : a.nblk[l];   // blocks fed by the previous layer; the rest (layer 1): the prior
-            // (1) the prior's blocks: inputs of the launch, nothing to wait for
+            const long long tq0 = a.prof ? wall_clock64() : 0;
+            // (1) the prior's blocks: inputs of the launch, nothing to wait for (16-byte pieces of four steps' operands)
             if (l == 1) {
                 static_for<0, kBDenseSlots>([&](auto kc) {
                     constexpr int k = decltype(kc)::value;
                     const int b = wave + 4 * k;
                     if (b < fed || b >= a.nblk[1]) return;
-                    const char *src = reinterpret_cast<const char *>(a.priorT) + (static_cast<int64_t>(p) * a.P + 64 * (b - fed)) * NBT * 4;
-                    float bv[32];
+                    const brsrc pr = b_rsrc(reinterpret_cast<const char *>(a.priorT) + static_cast<int64_t>(p) * a.P * NBT * 4);
+                    int sb = 8 * (b - fed) * pstride;
+                    f4 pv[8];
+                    uint32_t vo = voff;
+                    asm volatile("" : "+v"(vo), "+s"(sb)::"memory");
 #pragma unroll
-                    for (int i = 0; i < 32; ++i) bv[i] = 0.f;
-                    if (img) {
-                        uint32_t vo = voff4;
-                        asm volatile("" : "+v"(vo));
-#pragma unroll
-                        for (int i = 0; i < 32; ++i) bv[i] = *reinterpret_cast<const float *>(src + (vo + static_cast<uint32_t>(i * (2 * NBT * 4))));
-                    }
-                    const f32x16 acc = b_chain(wreg[k], [&](int i) { return bv[i]; });
+                    for (int m = 0; m < 8; ++m) pv[m] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(pr, static_cast<int>(vo), sb + m * pstride, 0));
+                    const f32x16 acc = b_chain_res<k>([&](int i) { return pv[i >> 2][i & 3]; });
                     b_store_tile(tiles + b * kBTile, lane, acc);
                 });
             }
-            // (2) the blocks fed by layer l - 1: one granule polled alone, then the wave's blocks double-buffered
-            const char *xin = reinterpret_cast<const char *>(a.act[l - 1]);
-            if (wave < fed)
-                alive = b_sentinel(a, reinterpret_cast<const uint64_t *>(xin + static_cast<int64_t>(64 * wave + 62) * NBT * 8 + voff8), tag, img) && alive;
-            static_for<0, kBDenseSlots>([&](auto kc) {
-                constexpr int k = decltype(kc)::value;
-                const int b = wave + 4 * k;
-                if (b >= fed) return;
-                uint64_t(&gc)[32] = *((k & 1) ? &gB : &gA);
-                uint64_t(&gn)[32] = *((k & 1) ? &gA : &gB);
-                const BSrc s{xin + static_cast<int64_t>(64 * b) * NBT * 8, gstride, tag};
-                if (k == 0) b_issue(s, voff8, img, gc);
-                if (k + 1 < kBDenseSlots && b + 4 < fed) {
-                    const BSrc s1{xin + static_cast<int64_t>(64 * (b + 4)) * NBT * 8, gstride, tag};
-                    b_issue(s1, voff8, img, gn);
+            // (2) the blocks fed by layer l - 1: the first two blocks' loads go out together, the third's piece by piece behind the first
+            // chain's MFMAs (no sentinel: the producers are rarely behind, and a second round trip per layer costs more than the polling)
+            const long long tq1 = a.prof ? wall_clock64() : 0;
+            const brsrc xr = b_rsrc(a.act[l - 1]);
+            const int nb = wave < fed ? (fed - wave + 3) >> 2 : 0;   // this wave's blocks wave, wave + 4, wave + 8 below `fed`
+            const int b0 = 16 * wave * pstride, b1 = b0 + 64 * pstride, b2 = b1 + 64 * pstride;   // their byte offsets in the slab
+            if (nb >= 1) b_issue(xr, b0, pstride, voff, gA);
+            if (nb >= 2) b_issue(xr, b1, pstride, voff, gB);
+            if (nb >= 1) {
+                alive = b_wait(a, xr, b0, pstride, voff, tag, gA) && alive;
+                const f32x16 acc = (nb >= 3 && (l - 1) * kBDenseSlots + 2 < kBSlots) ? b_chain_gran<(l - 1) * kBDenseSlots, true>(gA, xr, b2, pstride, voff)
+                                                                                    : b_chain_gran<(l - 1) * kBDenseSlots, false>(gA, xr, 0, 0, 0u);
+                b_store_tile(tiles + wave * kBTile, lane, acc);
+            }
+            if (nb >= 2) {
+                alive = b_wait(a, xr, b1, pstride, voff, tag, gB) && alive;
+                const f32x16 acc = b_chain_gran<(l - 1) * kBDenseSlots + 1, false>(gB, xr, 0, 0, 0u);
+                b_store_tile(tiles + (wave + 4) * kBTile, lane, acc);
+            }
+            if constexpr ((l - 1) * kBDenseSlots + 2 < kBSlots) {   // (the last layer has two register slots per wave)
+                if (nb >= 3) {
+                    alive = b_wait(a, xr, b2, pstride, voff, tag, gA) && alive;
+                    const f32x16 acc = b_chain_gran<(l - 1) * kBDenseSlots + 2, false>(gA, xr, 0, 0, 0u);
+                    b_store_tile(tiles + (wave + 8) * kBTile, lane, acc);
                 }
-                alive = b_validate(a, s, voff8, img, gc) && alive;
-                const f32x16 acc = b_chain(wreg[(l - 1) * kBDenseSlots + k], [&](int i) { return gran_val(gc[i]); });
-                b_store_tile(tiles + b * kBTile, lane, acc);
-            });
+            }
             if (!alive) return;
+            const long long tq2 = a.prof ? wall_clock64() : 0;
             lds_barrier();
             f4 v = b_sum_tiles(zero4, tiles, a.nblk[l], tid);
             v += *reinterpret_cast<const f4 *>(bias_s + (l - 1) * 32 + frow);
             if (a.act_after[l]) v = b_leaky(v);
             if (l < last) {
-                if (img) {
-                    uint32_t so = soff;
-                    asm volatile("" : "+v"(so));
-                    uint64_t *dst = a.act[l] + static_cast<int64_t>(r0 * 32) * NBT;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) st_gran(dst + (so + static_cast<uint32_t>(i * NBT)), v[i], tag);
-                }
+                publish4(a.act[l] + static_cast<int64_t>(r0 * 8) * 2 * NBT * 2, v, tag);
             } else if (img) {
-                // ---- Gaussian step: this thread's two (mean, scale) pairs
+                // ---- Gaussian step: this thread's two (mean, scale) pairs.  What the next step waits for goes out first: the coded
+                // latent (encoder) -- the table search and the plain outputs follow in its shadow
                 uint32_t yo = yoff, oo = ooff, to = toff, mo = moff;
                 asm volatile("" : "+v"(yo), "+v"(oo), "+v"(to), "+v"(mo));
+                if (DECODE) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const float mu = v[2 * i], sg = v[2 * i + 1];
-                    const int row = nearest_scale(sg, tab, a.table_len, tab_sorted);
-                    if (DECODE) {
+                    for (int i = 0; i < 2; ++i) {
+                        const int row = nearest_scale(v[2 * i + 1], tab, a.table_len, tab_sorted);
                         st_gran(a.idx_step + (mo + i), static_cast<uint32_t>(row), tag);
-                        st_gran(a.mu + (mo + i), mu, tag);
-                    } else {
-                        const float q = rintf((i ? y_pre1 : y_pre0) - mu);          // torch.round: half to even
-                        st_gran(a.yT + static_cast<int64_t>(p) * C * NBT + (to + static_cast<uint32_t>(i * NBT)), q + mu, tag);   // first: the context workgroups wait for it
+                        st_gran(a.mu + (mo + i), v[2 * i], tag);
+                    }
+                } else {
+                    const float q0 = rintf(y_pre0 - v[0]), q1 = rintf(y_pre1 - v[2]);          // torch.round: half to even
+                    uint64_t *ypos = a.yT + static_cast<int64_t>(p) * C * NBT;
+                    st_gran(ypos + to, q0 + v[0], tag);
+                    st_gran(ypos + (to + static_cast<uint32_t>(2 * NBT)), q1 + v[2], tag);     // channel c0 + 1: the odd-parity piece of the same quad
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const float mu = v[2 * i], qq = i ? q1 : q0;
+                        const int row = nearest_scale(v[2 * i + 1], tab, a.table_len, tab_sorted);
                         (a.idx + static_cast<int64_t>(p) * C)[oo + i] = row;
-                        (a.sym + static_cast<int64_t>(p) * C)[oo + i] = static_cast<int32_t>(q);
-                        (a.ybuf + p)[yo + static_cast<uint32_t>(i * HW)] = q + mu;
+                        (a.sym + static_cast<int64_t>(p) * C)[oo + i] = static_cast<int32_t>(qq);
+                        (a.ybuf + p)[yo + static_cast<uint32_t>(i * HW)] = qq + mu;
                     }
                 }
             }
+            if (prof) { a.prof[4 * l] += tq1 - tq0; a.prof[4 * l + 1] += tq2 - tq1; a.prof[4 * l + 2] += wall_clock64() - tq2; }
         });
         if (!alive) return;
         lds_barrier();   // a layer's partial tiles are rewritten in the next step (a workgroup with one layer has no other barrier in between)
     }
+    if (prof) {
+        a.prof[4 * kMaxLayers] = clock64() - loop_c0;
+        a.prof[4 * kMaxLayers + 1] = wall_clock64() - loop_t0;
+    }
 }
 
-// prior [B][P][HW] -> priorT [HW][P][nbt]  (batch-minor: a B fragment of the batched kernel is two 128-byte runs)
+// prior [B][P][HW] -> priorT [HW] x slab [P][nbt] in 16-byte pieces of four steps' operands (bm_prior)
 __global__ void transpose_prior_batched_kernel(const float *__restrict__ in, float *__restrict__ out, int B, int P, int HW, int nbt, int64_t total)
 {
     for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < total; i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
-        const int b = static_cast<int>(i % nbt);
-        const int64_t r = i / nbt;
+        const int p = static_cast<int>(i % HW);   // position fastest: coalesced reads
+        const int64_t r = i / HW;
         const int c = static_cast<int>(r % P);
-        const int p = static_cast<int>(r / P);
-        out[i] = b < B ? in[(static_cast<int64_t>(b) * P + c) * HW + p] : 0.f;
+        const int b = static_cast<int>(r / P);
+        out[static_cast<int64_t>(p) * P * nbt + bm_prior(c, b, nbt)] = in[i];
     }
 }
 
@@ -1642,15 +1741,14 @@ extern "C" int basic_scanline_plan_create(const float *ctx_weight, const float *
     // K group or the ctx | prior seam); a context row tile's blocks in the nine register slots of four waves (the late blocks
     // on waves 1 .. bpt, slot 8); at most three blocks per dense layer and wave; at most three dense layers
     {
-        bool ok = p->nlayers >= 2 && p->nlayers <= 4 && channels % kKB == 0 && channels / kKB <= 3 && p->rows[0] % kKB == 0;
-        const int bpt = channels / kKB, early = (p->ntaps - 1) * bpt;
-        for (int w = 1; w <= 3 && ok; ++w) ok = w + 4 * kBLateSlot >= early;   // slot 8 of waves 1 .. 3 is not an early block
-        ok = ok && early <= 4 * kBSlots - 3;
+        bool ok = p->nlayers >= 2 && p->nlayers <= 4 && channels % kKB == 0 && channels / kKB <= kBLate - 1 && p->rows[0] % kKB == 0;
+        const int bpt = channels / kKB, nb0 = p->ntaps * bpt;
+        ok = ok && nb0 >= kBLate && nb0 - kBLate <= 4 * kBSlots;   // four late blocks (all of the left neighbour's among them), 8 resident per wave
         for (int l = 0; l < p->nlayers && ok; ++l) {
             ok = p->rows[l] % 32 == 0 && p->kdim[l] % kKB == 0 && p->kgroup[l] % kKB == 0;
             p->b_nblk[l] = p->kdim[l] / kKB;
             p->b_rt[l] = p->rows[l] / 32;
-            if (l > 0) ok = ok && p->b_nblk[l] <= 4 * kBDenseSlots;
+            if (l > 0) ok = ok && p->b_nblk[l] <= 4 * (l < 3 ? kBDenseSlots : kBSlots - 2 * kBDenseSlots);   // register slots 0-2, 3-5, 6-7
         }
         if (ok) {
             p->b_bpt = bpt;
@@ -1837,6 +1935,7 @@ int fill_args_batched(basic_scanline_plan *p, ScanArgs &a, int batch, int h, int
     const size_t is_off = floats;     floats += align4(2 * static_cast<size_t>(nbt) * p->C);
     const size_t gran_floats = floats;
     const size_t pT_off = floats;     floats += align4(static_cast<size_t>(nbt) * HW * p->P);
+    const size_t wl_off = floats;     floats += static_cast<size_t>(tiles) * p->b_nw * kThreads * 32;
     if (floats > p->scratch_cap) {
         if (p->d_scratch) (void)hipFree(p->d_scratch);
         p->d_scratch = nullptr; p->scratch_cap = 0;
@@ -1844,6 +1943,7 @@ int fill_args_batched(basic_scanline_plan *p, ScanArgs &a, int batch, int h, int
         p->scratch_cap = floats;
     }
     BASIC_HIP_TRY(hipMemsetAsync(p->d_scratch, 0, gran_floats * sizeof(float), st));   // tag 0 = "not written in this launch"
+    a.wlate = p->d_scratch + wl_off;
     size_t ao = 0;
     for (int l = 0; l < p->nlayers; ++l) {
         a.rows[l] = p->rows[l]; a.kdim[l] = p->kdim[l]; a.act_after[l] = p->act_after[l];
@@ -1861,7 +1961,7 @@ int fill_args_batched(basic_scanline_plan *p, ScanArgs &a, int batch, int h, int
     a.priorT = nullptr;
     if (p->P > 0) {
         float *pT = p->d_scratch + pT_off;
-        const int64_t total = static_cast<int64_t>(nbt) * HW * p->P;
+        const int64_t total = static_cast<int64_t>(batch) * HW * p->P;
         int64_t g = (total + 255) / 256;
         hipLaunchKernelGGL(transpose_prior_batched_kernel, dim3(static_cast<unsigned>(g > 8192 ? 8192 : g)), dim3(256), 0, st, d_prior, pT, batch,
                            p->P, static_cast<int>(HW), nbt, total);
@@ -1898,6 +1998,17 @@ struct ScanProfile {
         (void)hipFree(d);
         d = nullptr;
         const double steps = static_cast<double>(a.H) * a.W;
+        if (a.nbt) {   // batched kernel: first context workgroup (late: wave 1, early: wave 0), first dense workgroup (wave 0)
+            fprintf(stderr, "scan-line %s profile, 10 ns ticks per coding step | context tile: wait for y %.1f, late block %.1f, barrier + finish %.1f, early half %.1f | ", what,
+                    h[0] / steps, h[1] / steps, h[2] / steps, h[3] / steps);
+            for (int l = 1; l < a.nlayers; ++l)
+                fprintf(stderr, "dense L%d: prior blocks + wait %.1f, loads + chains %.1f, barrier + finish %.1f | ", l, h[4 * l] / steps, h[4 * l + 1] / steps, h[4 * l + 2] / steps);
+            fprintf(stderr, "loop %.1f ticks per step, %.2f shader clocks per tick", h[4 * kMaxLayers + 1] / steps,
+                    h[4 * kMaxLayers + 1] ? static_cast<double>(h[4 * kMaxLayers]) / h[4 * kMaxLayers + 1] : 0.0);
+            if (h[4 * kMaxLayers + 3]) fprintf(stderr, " | decoder wave of stream 0: waiting %.1f, decoding %.1f", h[4 * kMaxLayers + 2] / steps, h[4 * kMaxLayers + 3] / steps);
+            fprintf(stderr, "\n");
+            return;
+        }
         fprintf(stderr, "scan-line %s profile (workgroup 0; 10 ns ticks per coding step: stage+wait / dots / finish / gauss): ", what);
         for (int l = 0; l < a.nlayers; ++l)
             fprintf(stderr, "L%d %.1f / %.1f / %.1f / %.1f | ", l, h[4 * l] / steps, h[4 * l + 1] / steps, h[4 * l + 2] / steps, h[4 * l + 3] / steps);
