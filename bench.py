@@ -48,8 +48,7 @@ def parse():
     ap.add_argument("--total", type=int, default=256, help="images per step over ALL GPUs in the strong-scaling leg (cfg-5)")
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--workers", type=int, default=None,
-                    help="concurrent stream workers per GPU (1 = plain sequential calls); default 6 for the headline and for --workload checkerboard, "
-                         "3 for --workload basic")
+                    help="concurrent stream workers per GPU (1 = plain sequential calls); default 6 (headline and AR workloads)")
     ap.add_argument("--shard-by", default="steps", choices=["steps", "images"],
                     help="how the K steps are spread over the workers: steps = every worker codes WHOLE batches, step k on worker k mod W "
                          "(W batches in flight; the reference's pool also hands whole dataset items to its workers); "
@@ -70,6 +69,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the pcie_inclusive and strong-scaling legs (profiling runs)")
     ap.add_argument("--no-dominant", action="store_true", help="skip the single-launch roofline (counter passes: keeps the launch mix = timed passes)")
+    ap.add_argument("--levels", type=int, nargs="*", default=None, help="--workload basic: complexity levels to time (default 0 3 7; the first is the line's value)")
+    ap.add_argument("--no-kodak-leg", action="store_true", help="--workload basic: skip the Kodak-shaped batch-1 leg through the harness (a child process)")
     ap.add_argument("--workload", default="hyperprior", choices=["hyperprior", "checkerboard", "basic"],
                     help="hyperprior = the headline (BASELINE configs[4] shape); checkerboard = configs[2] topo-group AR codec; "
                          "basic = configs[3] BaSIC slimmable scan-line codec at complexity level 0 (parity-test configurations, extra lines)")
@@ -194,7 +195,7 @@ def cpu_baseline(codec_cpu_state, n_images, size):
 def traffic_from_profiles():
     """HBM bytes per transform launch from the SEPARATE rocprofv3 --pmc passes committed under profiles/ (a profiler cannot
     run inside the timed process); (value, source) -- (None, None) when no file of this round exists."""
-    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             try:
@@ -229,16 +230,58 @@ def masked_conv_flops(plan_cin, plan_cout, k, topo_in, topo_out, allow_same, pos
     return 2 * macs
 
 
+def ar_traffic_from_profiles(workload):
+    """HBM-side bytes per launch of the AR workloads' dominant kernels from the separate rocprofv3 --pmc passes under profiles/
+    (TCC_EA0_RDREQ / WRREQ request counts x request size; scripts/pmc_ar_fold.py): (value, source) or (None, reason)."""
+    path = os.path.join(ROOT, "profiles", "r04_pmc_ar.json")
+    if not os.path.exists(path):
+        return None, "profiles/r04_pmc_ar.json not collected"
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        w = d["workloads"][workload]
+        return w["hbm_bytes_per_launch"], f"profiles/r04_pmc_ar.json (collected at git {d.get('git', '?')}; {d.get('note', '')})"
+    except Exception as e:
+        return None, f"profiles/r04_pmc_ar.json unreadable: {e!r}"
+
+
+def kodak_leg_child(workers):
+    """BASELINE configs[3]'s own test setting -- 24 Kodak-shaped images, batch 1 -- through the harness (tools/run_benchmark.py, the
+    analogue of the reference's tool) with `workers` stream workers, complexity level 0; a child process."""
+    import subprocess
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        cmd = [sys.executable, os.path.join(ROOT, "tools", "run_benchmark.py"), "--warmup", "--codec", "basic", "--synthetic", "24", "--height", "512",
+               "--width", "768", "--batch-size", "1", "--workers", str(workers), "--complexity-levels", "0", "--out", os.path.join(tmp, "run")]
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=400, cwd=ROOT)
+            if r.returncode != 0:
+                return dict(error=f"exit code {r.returncode}", stderr_tail=r.stderr[-300:])
+            m = json.loads(r.stdout[r.stdout.index("{"):])
+            wall = [v for k, v in m.items() if k.endswith("time_wall_dataset")][0]
+            tc = [v for k, v in m.items() if k.endswith("time_compress")][0]
+            td = [v for k, v in m.items() if k.endswith("time_decompress")][0]
+            return dict(value=24 * 512 * 768 / wall / 1e3, unit="Mpix/s", images=24, shape="3x512x768", batch_size=1, workers=workers, dataset_wall_ms=wall,
+                        item_compress_ms=tc, item_decompress_ms=td,
+                        note="tools/run_benchmark.py --codec basic --synthetic 24 --height 512 --width 768 --batch-size 1 (synthetic images of Kodak's shape, level 0); "
+                             "the harness's timed region: per-item compress() + decompress() incl. upload")
+        except Exception as e:
+            return dict(error=repr(e))
+
+
 def run_ar_workload(args):
-    """Extra bench lines for the AR parity configurations: one codec, one stream (module path), HIP-event time of every
-    masked-convolution launch of one measured encode + decode pass for the roofline of masked_conv_pos_kernel."""
-    # measured (profiles/r02_ar_codecs.txt): checkerboard 359 / 385 / 430 / 451 / 454 Mpix/s with 1 / 2 / 3 / 4 / 5 workers; round 3 (LDS-DMA
-    # masked convolution): 474 / 483 / 492-500 with 4 / 5 / 6; BaSIC at 64 images per step: 94 / 58 / 73 with 3 / 4 / 6; scan-line
-    # BaSIC 61 / 92 / 109 / 62 with 1 / 2 / 3 / 4 (four graph-replaying streams fall back to the one-stream rate)
-    workers = max(1, args.workers if args.workers is not None else (6 if args.workload == "checkerboard" else 3))
+    """Extra bench lines for the AR parity configurations (BASELINE configs[2] / [3]): whole batches in flight on concurrent stream
+    workers as in the headline; after each timed leg the last step's bytes are compared with one quiet single-stream compress();
+    the dominant kernels are then timed alone (HIP events per launch) against the algorithmic FLOPs of the reference's masks."""
+    # measured: checkerboard 474 / 483 / 492-500 Mpix/s with 4 / 5 / 6 workers (round 3); BaSIC at 64 images per step with the batched
+    # persistent scan-line kernel (round 4, profiles/r04_basic_workers.txt): 112 / 153 / 189 / 195 / 200 with 1 / 2 / 3 / 4 / 6
+    workers = max(1, args.workers if args.workers is not None else 6)
     if workers > 1:   # before HIP initialises: one hardware queue per stream; 8 image streams per rANS workgroup (CUs left to the others)
         os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
         os.environ.setdefault("BASIC_RANS_WPB", str(args.rans_waves if args.rans_waves > 0 else 8))
+    kodak = None
+    if args.workload == "basic" and not args.no_kodak_leg:   # a child process, before this one touches the GPU
+        kodak = kodak_leg_child(workers)
     import numpy as np
     import torch
     from cbench_basic_amd.nn import kernels as K
@@ -247,8 +290,10 @@ def run_ar_workload(args):
     torch.cuda.set_device(dev)
     if args.workload == "checkerboard":
         make, batch, name = (lambda: topogroup_ar_codec("checkerboard")), args.batch, "topo-group AR codec, checkerboard + expand-bottleneck merger (lossy_latent_graph_topogroup)"
+        levels = [None]
     else:
-        make, batch, name = basic_codec, min(args.batch, 64), "BaSIC slimmable scan-line codec, complexity level 0 (lossy_latent_graph_scalable_ar_models)"
+        make, batch, name = basic_codec, min(args.batch, 64), "BaSIC slimmable scan-line codec (lossy_latent_graph_scalable_ar_models)"
+        levels = list(args.levels) if args.levels else [0, 3, 7]
     cpu_state = {}
 
     def make_codec():
@@ -262,11 +307,9 @@ def run_ar_workload(args):
             cpu_state.update({k: v.detach().cpu().clone() for k, v in codec.entropy_coder.state_dict().items()})
         codec = codec.to(dev)
         codec.update_state()
-        if args.workload == "basic":
-            codec.set_complex_level(0)
         return codec
     # Whole batches in flight on concurrent stream workers, as in the headline: one worker's rANS chains run beside another's
-    # convolutions; the scan-line schedule's launch-bound step sequences (HIP graphs) of several workers interleave on the chip.
+    # convolutions; persistent scan-line launches of different workers sit side by side (64 - 80 compute units each).
     from cbench_basic_amd.benchmark.stream_workers import StreamWorkerPool
     pool = StreamWorkerPool(make_codec, workers, dev)
     codec = pool.codecs[0]
@@ -279,19 +322,39 @@ def run_ar_workload(args):
             out = (data, c.decompress(data))
         return out
     counts = [len(range(w, args.steps, workers)) for w in range(workers)]
-    if workers > 1:   # HIP-graph capture does not tolerate other threads' launches: first call of every replica alone
-        for c, st in zip(pool.codecs, pool.streams):
-            with torch.cuda.stream(st):
-                loop(c, 1)
-            torch.cuda.synchronize()
-    pool.map(lambda c, n: loop(c, max(1, -(-args.warmup // workers))), counts)
-    torch.cuda.synchronize()
-    t0 = time.time()
-    data, xhat = pool.map(loop, counts)[0]
-    torch.cuda.synchronize()
-    dt = time.time() - t0
+    per_level = {}
+    data = xhat = None
+    for lvl in levels:
+        if lvl is not None:
+            for c in pool.codecs:
+                c.set_complex_level(lvl)
+        if workers > 1:   # HIP-graph capture / plan building: first call of every replica (at this level) alone
+            for c, st in zip(pool.codecs, pool.streams):
+                with torch.cuda.stream(st):
+                    loop(c, 1)
+                torch.cuda.synchronize()
+        pool.map(lambda c, n: loop(c, max(1, -(-args.warmup // workers))), counts)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        d_l, xh_l = pool.map(loop, counts)[0]
+        torch.cuda.synchronize()
+        dt_l = time.time() - t0
+        # the timed schedule against ONE quiet call on the idle GPU: same bytes, same reconstruction, or the run fails
+        quiet = codec.compress(x)
+        xq = codec.decompress(quiet)
+        torch.cuda.synchronize()
+        same = bool(quiet == d_l and torch.equal(xq, xh_l))
+        if not same:
+            raise SystemExit(f"bench.py --workload {args.workload}: the bytes / reconstruction of the timed {workers}-worker schedule differ from a quiet single-stream call (level {lvl})")
+        mse_l = K.mse_per_image(xh_l, x)
+        per_level[lvl] = dict(value=batch * args.size ** 2 * args.steps / dt_l / 1e6, unit="Mpix/s", ms_per_step=dt_l / args.steps * 1e3,
+                              bpp=len(d_l) * 8 / (batch * args.size ** 2), psnr_db=float((-10 * torch.log10(mse_l.double())).mean()),
+                              bytes_match_single_stream=same)
+        if data is None:
+            data, xhat, dt = d_l, xh_l, dt_l
     pool.close()
-    pix = batch * args.size ** 2 * args.steps
+    if levels[0] is not None:
+        codec.set_complex_level(levels[0])
     # ---- one instrumented pass (HIP graphs off): events around every masked-convolution launch, FLOPs from the masks
     yc = codec.entropy_coder.latent_node_entropy_coders["y"]
     yc.use_hip_graphs = False
@@ -327,7 +390,7 @@ def run_ar_workload(args):
         orig_init(self, weight, bias, in_groups, out_groups, allow_same, act)
         self._same = bool(allow_same)
     K.MaskedConvPlan.__init__, K.MaskedConvPlan.__call__ = init, timed
-    yc.persistent_scanline_max_batch = 0
+    yc.use_persistent_scanline = False   # the per-step path: one masked-convolution launch sequence per coding step (counts the algorithmic FLOPs)
     try:
         yc._ready()
         d2 = codec.compress(x)
@@ -337,21 +400,82 @@ def run_ar_workload(args):
         K.MaskedConvPlan.__init__, K.MaskedConvPlan.__call__ = orig_init, orig
     mc_ms = sum(e0.elapsed_time(e1) for e0, e1 in events)
     ach = flops[0] / (mc_ms / 1e3) / 1e12 if mc_ms > 0 else 0.0
-    from cbench_basic_amd.nn import kernels as K2
-    mse = K2.mse_per_image(xhat, x)
-    out = dict(metric="encode+decode Mpix/s", value=pix / dt / 1e6, unit="Mpix/s", n_gpus=1, steps=args.steps, warmup=args.warmup,
-               ms_per_step=dt / args.steps * 1e3, higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
-               config=dict(workload=f"{name}, synthetic 3x{args.size}x{args.size} images, {batch} images per step resident in HBM, "
+    traffic, traffic_source = ar_traffic_from_profiles(args.workload)
+    roofline = dict(bound="mfma", achieved=ach, peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_FP32_MFMA_TFLOPS, traffic=traffic, traffic_source=traffic_source,
+                    kernel="masked_conv_dma_kernel / masked_conv_gather_kernel / masked_conv_block_kernel + reduce (csrc/mconv.hip): the masked-convolution launches of one encode + decode pass "
+                           "of the y-coder (context convolution + merger layers at the coded positions), HIP events per launch",
+                    flops_per_launch=flops[0] / max(1, len(events)), launches_per_pass=len(events), avg_launch_ms=mc_ms / max(1, len(events)),
+                    pass_ms=mc_ms, note="algorithmic FLOPs = 2 x the (output, input, tap) products the reference's masks keep at the positions a step codes",
+                    launches=None if len(events) > 64 else [
+                        dict(cin=ci, cout=co, k=kk, positions_per_image=npos, gflop=fl / 1e9, ms=e0.elapsed_time(e1),
+                             tflops=fl / 1e9 / max(e0.elapsed_time(e1), 1e-6)) for (ci, co, kk, npos, fl), (e0, e1) in zip(per_launch, events)])
+    if args.workload == "basic":
+        # the kernel that serves this workload: ONE persistent launch per direction (scanline_batched_kernel), timed alone with the
+        # persistent path switched back on; the per-step figures above stay as the fallback path's
+        fallback = dict(achieved=ach, frac=ach / PEAK_FP32_MFMA_TFLOPS, launches_per_pass=len(events), pass_ms=mc_ms, avg_launch_ms=mc_ms / max(1, len(events)))
+        yc.use_persistent_scanline = True
+        yc._layers = None
+        yc._ready()
+        sl_events = []
+        oenc, odec = K.ScanlinePlan.encode, K.ScanlinePlan.decode
+
+        def tenc(self, *a, **k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = oenc(self, *a, **k)
+            e1.record()
+            sl_events.append(("encode", e0, e1))
+            return r
+
+        def tdec(self, *a, **k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = odec(self, *a, **k)
+            e1.record()
+            sl_events.append(("decode", e0, e1))
+            return r
+        K.ScanlinePlan.encode, K.ScanlinePlan.decode = tenc, tdec
+        try:
+            codec.decompress(codec.compress(x))   # warm
+            sl_events.clear()
+            d3 = codec.compress(x)
+            codec.decompress(d3)
+            torch.cuda.synchronize()
+        finally:
+            K.ScanlinePlan.encode, K.ScanlinePlan.decode = oenc, odec
+        if d3 != data or not sl_events:
+            raise SystemExit("bench.py --workload basic: the persistent scan-line path did not serve the pass (or coded other bytes than the timed leg)")
+        enc_ms = sum(e0.elapsed_time(e1) for w, e0, e1 in sl_events if w == "encode")
+        dec_ms = sum(e0.elapsed_time(e1) for w, e0, e1 in sl_events if w == "decode")
+        sl_ms = enc_ms + dec_ms
+        ach2 = flops[0] / (sl_ms / 1e3) / 1e12
+        tiles = -(-batch // 32)
+        cus_enc, cus_dec = 32 * tiles, 32 * tiles + -(-batch // 4)
+        cus_chip = torch.cuda.get_device_properties(dev).multi_processor_count
+        occupied_peak = PEAK_FP32_MFMA_TFLOPS * (enc_ms * cus_enc + dec_ms * cus_dec) / (sl_ms * cus_chip)
+        roofline.update(achieved=ach2, frac=ach2 / PEAK_FP32_MFMA_TFLOPS, launches=None,
+                        kernel="scanline_batched_kernel<false> + <true> (csrc/scanline.hip): ONE persistent launch per direction walks all H*W coding steps of the batch -- masked context "
+                               "convolution + merger layers as v_mfma_f32_32x32x2_f32 tiles with the batch as N, weights resident in registers, tagged-granule exchange between the "
+                               "row tiles' compute units, in-kernel rANS decode; HIP events around each launch (incl. its 40 us of prior transpose + memset), alone on the GPU",
+                        flops_per_launch=flops[0] / len(sl_events), launches_per_pass=len(sl_events), avg_launch_ms=sl_ms / len(sl_events), pass_ms=sl_ms,
+                        encode_launch_ms=enc_ms, decode_launch_ms=dec_ms, compute_units=dict(encode=cus_enc, decode=cus_dec, chip=cus_chip),
+                        frac_of_occupied_units=ach2 / occupied_peak,
+                        note="algorithmic FLOPs = 2 x the (output, input, tap) products the reference's masks keep at the positions a step codes; `frac` is against the WHOLE chip's "
+                             "fp32 MFMA peak although a launch occupies compute_units of it (other workers' launches and transforms run beside it); frac_of_occupied_units = against the "
+                             "peak of the units the launches hold.  The decode launch is bound by its serial in-kernel rANS chain (192 symbols per step and stream)",
+                        per_step_fallback=fallback)
+    first = per_level[levels[0]]
+    cfg_levels = None if levels[0] is None else {str(l): v for l, v in per_level.items()}
+    out = dict(metric="encode+decode Mpix/s", value=first["value"], unit="Mpix/s", n_gpus=1, steps=args.steps, warmup=args.warmup,
+               ms_per_step=first["ms_per_step"], higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+               config=dict(workload=f"{name}{'' if levels[0] is None else f', complexity level {levels[0]}'}, synthetic 3x{args.size}x{args.size} images, {batch} images per step resident in HBM, "
                                         + (f"{workers} concurrent stream workers (step k on worker k mod W: whole batches in flight)" if workers > 1 else "one stream"),
-                           images_per_gpu=batch, workers=workers, bpp=len(data) * 8 / (batch * args.size ** 2), psnr_db=float((-10 * torch.log10(mse.double())).mean())),
-               roofline=dict(bound="mfma", achieved=ach, peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_FP32_MFMA_TFLOPS, traffic=None,
-                             kernel="masked_conv_dma_kernel / masked_conv_gather_kernel / masked_conv_block_kernel + reduce (csrc/mconv.hip): the masked-convolution launches of one encode + decode pass "
-                                    "of the y-coder (context convolution + merger layers at the coded positions), HIP events per launch",
-                             flops_per_launch=flops[0] / max(1, len(events)), launches_per_pass=len(events), avg_launch_ms=mc_ms / max(1, len(events)),
-                             pass_ms=mc_ms, note="algorithmic FLOPs = 2 x the (output, input, tap) products the reference's masks keep at the positions a step codes",
-                             launches=None if len(events) > 64 else [
-                                 dict(cin=ci, cout=co, k=kk, positions_per_image=npos, gflop=fl / 1e9, ms=e0.elapsed_time(e1),
-                                      tflops=fl / 1e9 / max(e0.elapsed_time(e1), 1e-6)) for (ci, co, kk, npos, fl), (e0, e1) in zip(per_launch, events)]))
+                           images_per_gpu=batch, workers=workers, bpp=first["bpp"], psnr_db=first["psnr_db"], bytes_match_single_stream=first["bytes_match_single_stream"]),
+               roofline=roofline)
+    if cfg_levels is not None:
+        out["levels"] = cfg_levels
+    if kodak is not None:
+        out["kodak_batch1"] = kodak
     if not args.no_cpu_baseline:
         from oracle.codec_oracle import BasicCodecOracle, TopoGroupCodecOracle
         from cbench_basic_amd.presets import BASIC_WIDTHS
@@ -393,7 +517,7 @@ def ar_workload_children(args):
                 continue
             d = json.loads(lines[-1])
             d.get("roofline", {}).pop("launches", None)
-            out[w] = {k: d[k] for k in ("value", "unit", "ms_per_step", "steps", "config", "roofline", "cpu_baseline") if k in d}
+            out[w] = {k: d[k] for k in ("value", "unit", "ms_per_step", "steps", "config", "roofline", "levels", "kodak_batch1", "cpu_baseline") if k in d}
         except Exception as e:   # a failed extra line must not take the headline down, but it must be visible
             out[w] = dict(error=repr(e))
     return out

@@ -150,8 +150,13 @@ class BasicLosslessCompressionBenchmark:
             mods = list(self.codec.named_modules()) if hasattr(self.codec, "named_modules") else [("", self.codec)]
             levels = tuple((n, a, repr(getattr(m, a))) for n, m in mods for a in level_attrs if hasattr(m, a))
             searched = tuple((n, id(getattr(m, "_complexity_param_all_levels", None)), getattr(m, "_num_complex_levels", None)) for n, m in mods)
-            state = tuple((k, t.data_ptr(), t._version) for k, t in self.codec.state_dict().items()) if hasattr(self.codec, "state_dict") else ()
-            return levels, searched, state
+            sd = self.codec.state_dict() if hasattr(self.codec, "state_dict") else {}
+            state = tuple((k, t.data_ptr(), t._version) for k, t in sd.items())
+            # ... and a content checksum (sum and sum of squares of every state tensor, one synchronisation per pass): edits that do
+            # not bump the version counter (`.data`, a checkpoint loader writing through views) are seen too
+            fl = [t.detach().double().reshape(-1) for t in sd.values() if torch.is_tensor(t) and t.numel() > 0]
+            content = tuple(torch.stack([torch.stack([f.sum(), (f * f).sum()]) for f in fl]).sum(0).tolist()) if fl else ()
+            return levels, searched, state, content
         fp = fingerprint()
         if getattr(self._pool, "_synced_to", None) == fp:
             return self._pool
@@ -178,6 +183,13 @@ class BasicLosslessCompressionBenchmark:
             r.update_state()
         self._pool._synced_to = fp
         return self._pool
+
+    def invalidate_replicas(self):
+        """Force the stream workers' codec replicas to be re-synchronised before the next pass.  The automatic check covers the
+        state_dict (storage, version counters, content checksum), the level attributes and the searched levels; call this after
+        changing anything ELSE on the main codec that the replicas must share (a tuning attribute set by hand, a module swapped in)."""
+        if self._pool is not None:
+            self._pool._synced_to = None
 
     def _run_dataset(self):
         logger = MetricLogger()

@@ -63,7 +63,6 @@ constexpr int stage_channels(int ntaps, int waves)
 // the transposed convolutions run faster as two 4-wave workgroups per CU.
 constexpr int plan_waves(int mt, int ntaps) { return (mt == 4 && ntaps > kFewTaps) ? 8 : 4; }
 constexpr int kMaxTaps = 25;  // 5x5
-constexpr int kThreads = 256;
 constexpr int kTilePos = 128;  // output positions per workgroup
 constexpr int kPSlots = 12;             // patch elements per thread and stage (patch <= 3072 floats) ...
 constexpr int kPSlotsNarrow = 24;       // ... and for launches of <= 2 M-tiles, which have the registers for more descriptors
@@ -1339,7 +1338,10 @@ LaunchChoice choose_launches(const basic_conv_plan *p, int batch, int oh, int ow
     const char *dbg_env = getenv("BASIC_CONV_DEBUG");
     // profiling ablations: 1 skip staging, 2 skip MFMA loop, 4 force slices, 8 forbid slices, 64 no persistent first layer,
     // 128 no 16-byte patch pieces, 512 no fused column phases
-    const int dbg = dbg_env ? atoi(dbg_env) : 0;
+    int dbg = dbg_env ? atoi(dbg_env) : 0;
+#ifndef BASIC_DEBUG_ABLATIONS
+    dbg &= ~(1 | 2 | 32);   // the timing ablations give WRONG results: only a library built with `make ABLATIONS=1` honours them
+#endif
     LaunchChoice c;
     c.dbg = dbg;
     c.use_split = !p->split.empty() && !(dbg & 8) && (pos_blocks < kSplitBelowBlocks || (dbg & 4));

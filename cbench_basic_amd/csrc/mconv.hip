@@ -780,7 +780,11 @@ static int mconv_forward(const basic_mconv_plan *p, const float *d_x, const int3
         g.w = p->d_wa;
         g.n_rchunks = p->cout / kDmaRows;
         g.x_bytes = static_cast<int>(x_bytes);
+#ifdef BASIC_DEBUG_ABLATIONS   // timing ablations (wrong results): only in a library built with `make ABLATIONS=1`
         { const char *e = std::getenv("BASIC_MCONV_DEBUG"); g.debug = e ? std::atoi(e) : 0; }
+#else
+        g.debug = 0;
+#endif
         // 4 waves (128 positions per workgroup, two workgroups per compute unit) or 8 (256 positions, one workgroup);
         // BASIC_MCONV_DMA_WAVES picks one
         // measured (scripts/mconv_probe.py, warm clocks): the 4-wave shape is never slower -- 0.899 vs 0.905 ms on the 1536 -> 1536

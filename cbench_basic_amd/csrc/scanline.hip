@@ -1583,26 +1583,29 @@ namespace {
 // Ordinary kernels of other streams are no hazard: they drain, and the barrier's spin bound (seconds) covers the wait.
 struct ScanChain {
     std::mutex mu;
-    hipEvent_t slot[3] = {nullptr, nullptr, nullptr};
-    int cursor = 0;
+    struct Dev { hipEvent_t slot[3] = {nullptr, nullptr, nullptr}; int cursor = 0; };
+    Dev dev[16];   // per device: launches on different GPUs of one process share nothing (they used to wait on each other's events)
 };
 ScanChain g_scan_chain;
 
 template <typename Launch> int chained_launch(basic_scanline_plan *p, hipStream_t st, int grid, int cus, Launch &&launch)
 {
+    int device = 0;
+    BASIC_HIP_TRY(hipGetDevice(&device));
     std::lock_guard<std::mutex> lock(g_scan_chain.mu);
+    ScanChain::Dev &d = g_scan_chain.dev[device & 15];
     if (!p->done) BASIC_HIP_TRY(hipEventCreateWithFlags(&p->done, hipEventDisableTiming));
     const int per_slot = cus / 3 > 0 ? cus / 3 : 1;
     const int need = std::min(3, (grid + per_slot - 1) / per_slot);
     for (int j = 0; j < need; ++j) {
-        hipEvent_t e = g_scan_chain.slot[(g_scan_chain.cursor + j) % 3];
+        hipEvent_t e = d.slot[(d.cursor + j) % 3];
         if (e && e != p->done) BASIC_HIP_TRY(hipStreamWaitEvent(st, e, 0));   // (its own previous launch: same stream, already ordered)
     }
     launch();
     BASIC_HIP_TRY(hipGetLastError());
     BASIC_HIP_TRY(hipEventRecord(p->done, st));
-    for (int j = 0; j < need; ++j) g_scan_chain.slot[(g_scan_chain.cursor + j) % 3] = p->done;
-    g_scan_chain.cursor = (g_scan_chain.cursor + need) % 3;
+    for (int j = 0; j < need; ++j) d.slot[(d.cursor + j) % 3] = p->done;
+    d.cursor = (d.cursor + need) % 3;
     return BASIC_OK;
 }
 
@@ -1619,11 +1622,12 @@ extern "C" void basic_scanline_plan_destroy(basic_scanline_plan *p)
     if (p->d_bar) (void)hipFree(p->d_bar);
     if (p->done) {
         std::lock_guard<std::mutex> lock(g_scan_chain.mu);
-        for (int i = 0; i < 3; ++i)
-            if (g_scan_chain.slot[i] == p->done) {
-                (void)hipEventSynchronize(p->done);   // whoever waits on it has been released
-                g_scan_chain.slot[i] = nullptr;
-            }
+        for (auto &d : g_scan_chain.dev)
+            for (int i = 0; i < 3; ++i)
+                if (d.slot[i] == p->done) {
+                    (void)hipEventSynchronize(p->done);   // whoever waits on it has been released
+                    d.slot[i] = nullptr;
+                }
         (void)hipEventDestroy(p->done);
     }
     delete p;
@@ -1888,7 +1892,11 @@ int fill_args(basic_scanline_plan *p, ScanArgs &a, int batch, int h, int w, cons
     }
     a.bar = p->d_bar;
     a.err = reinterpret_cast<int *>(p->d_bar + 1);
+#ifdef BASIC_DEBUG_ABLATIONS   // timing ablations (wrong results): only in a library built with `make ABLATIONS=1`
     { const char *e = getenv("BASIC_SCAN_DEBUG"); a.debug = e ? atoi(e) : 0; }
+#else
+    a.debug = 0;
+#endif
     BASIC_HIP_TRY(hipMemsetAsync(p->d_bar, 0, 2 * sizeof(unsigned), st));
     return BASIC_OK;
 }

@@ -151,7 +151,19 @@ class EntropyBottleneck(nn.Module):
             v = state_dict.get(prefix + name)
             if v is not None and v.shape != getattr(self, name).shape:
                 setattr(self, name, torch.zeros(v.shape, dtype=torch.int32, device=getattr(self, name).device))
+        # weights without their tables (a strict=False load of a file that carries no buffers): tables built from the OLD weights
+        # must not survive, or the next update(force=False) keeps them and z is coded with another model than the one loaded
+        loads_weights = any(k.startswith(prefix) and k[len(prefix):].lstrip("_").startswith(("matrix", "bias", "factor", "quantiles"))
+                            for k in state_dict)
+        if loads_weights and prefix + "_offset" not in state_dict:
+            self.reset_tables()
         super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
+    def reset_tables(self):
+        """Forget the coding tables (the next ``update()`` rebuilds them): to be called by whatever changes the weights after a
+        first ``update_state()`` -- loaded tables are otherwise kept, as upstream's ``update(force=False)`` does."""
+        for name in ("_offset", "_quantized_cdf", "_cdf_length"):
+            setattr(self, name, torch.zeros((0,), dtype=torch.int32, device=getattr(self, name).device))
 
     def _logits_cumulative(self, inputs):
         logits = inputs

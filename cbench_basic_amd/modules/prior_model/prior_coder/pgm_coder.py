@@ -142,11 +142,22 @@ _CAPTURE_LOCK = threading.Lock()
 def _capture(device, graph):
     """HIP-graph capture that is safe beside other host threads (stream workers with their own codec replicas): one capture at
     a time in the process, in thread-local capture mode -- in the default global mode a hipMalloc / hipFree issued by ANY other
-    thread while this one captures fails or invalidates the capture -- and only THIS thread's stream is drained first."""
+    thread while this one captures fails or invalidates the capture.  ``capture_begin`` / ``capture_end`` are called directly on a
+    private side stream: the ``torch.cuda.graph`` context manager would first synchronise the whole DEVICE and empty the caching
+    allocator (torch 2.10), i.e. drain every other worker's stream and free their cached blocks; here only THIS thread's stream
+    is drained."""
     with _CAPTURE_LOCK:
-        torch.cuda.current_stream(device).synchronize()
-        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-            yield
+        cur = torch.cuda.current_stream(device)
+        cur.synchronize()
+        side = torch.cuda.Stream(device)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            graph.capture_begin(capture_error_mode="thread_local")
+            try:
+                yield
+            finally:
+                graph.capture_end()
+        cur.wait_stream(side)
 
 
 class _GroupPlan:

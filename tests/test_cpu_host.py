@@ -574,6 +574,22 @@ def test_gaussian_conditional_buffers_travel_in_checkpoints():
         eb._bias0.add_(0.3)
     assert eb.update() is False and torch.equal(eb._quantized_cdf, first)
     assert eb.update(force=True) is True and not torch.equal(eb._quantized_cdf, first)
+    # weights loaded WITHOUT their table buffers (strict=False load of a weights-only file, `load_checkpoint`): the tables of the old
+    # weights must not survive -- the next update() rebuilds them and they equal a freshly built module's
+    other = EntropyBottleneck(4)
+    with torch.no_grad():
+        other._bias0.add_(-0.4)
+    weights_only = {k: v for k, v in other.state_dict().items() if k not in ("_offset", "_quantized_cdf", "_cdf_length")}
+    stale = eb._quantized_cdf.clone()
+    eb.load_state_dict(weights_only, strict=False)
+    assert eb._offset.numel() == 0
+    assert eb.update() is True and other.update() is True
+    assert torch.equal(eb._quantized_cdf, other._quantized_cdf) and not torch.equal(eb._quantized_cdf[:, : stale.shape[1]], stale[:, : eb._quantized_cdf.shape[1]])
+    # ... while a file that carries the buffers keeps them (upstream's update(force=False))
+    full = other.state_dict()
+    eb2 = EntropyBottleneck(4)
+    eb2.load_state_dict(full)
+    assert eb2.update() is False and torch.equal(eb2._quantized_cdf, other._quantized_cdf)
 
 
 def test_create_ar_ptrs_matches_reference_binding():
