@@ -717,6 +717,20 @@ def main():
         extra["strong"] = strong_first_result
     pool.close()
 
+    # ---- the timed schedule against ONE quiet call on this rank's idle GPU (no workers, no token, default rANS packing): the last
+    # step's bytes and reconstruction must be identical, or the run fails -- the overlapped schedule is what was timed
+    bytes_match = None
+    if by_steps and args.input == "hbm":
+        codec.entropy_coder.fused_transform_token = 0
+        codec.entropy_coder.fused_rans_waves = 0
+        quiet = codec.compress(x)
+        xq = codec.decompress(quiet)
+        torch.cuda.synchronize()
+        bytes_match = bool(quiet == last[0][0] and torch.equal(xq, last[0][1]))
+        if not bytes_match:
+            raise SystemExit(f"bench.py: rank {rank}: the bytes / reconstruction of the timed {workers}-worker schedule differ from a quiet single-stream call")
+        codec.entropy_coder.fused_rans_waves = waves
+
     if rank == 0:
         dt_max, n_img, n_bytes = red["time_s"], red["images"], red["bytes"]
         pix = n_img * args.size * args.size
@@ -740,7 +754,7 @@ def main():
                                  + ("(step k on worker k mod W: whole batches, W in flight)" if by_steps else "(each step's batch cut into W shards)"),
                         images_per_gpu=args.batch, workers=workers, rans_waves_per_workgroup=waves,
                         shard_by=args.shard_by if workers > 1 else None, batches_in_flight=workers if by_steps else 1,
-                        call_latency_ms=call_s * 1e3,
+                        call_latency_ms=call_s * 1e3, bytes_match_single_stream=bytes_match,
                         bpp=n_bytes * 8 / pix, psnr_db=red["psnr_sum"] / red["psnr_n"],
                         gathered_images=int(table.shape[0]),
                         gathered_bpp=float(table[:, 0].sum()) * 8 / (table.shape[0] * args.size * args.size),

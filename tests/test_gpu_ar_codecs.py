@@ -18,9 +18,7 @@ def _rand_params(codec, seed):
     return codec
 
 
-@pytest.mark.parametrize("method,G", [("checkerboard", 1), ("none", 1), ("raster2x2", 1), ("channelwise", 2), ("channelwise", 4), ("elic", 1),
-                                      ("scanline", 1)])
-def test_topogroup_codec_vs_oracle(method, G):
+def _codec_vs_oracle(method, G, h, w):
     from cbench_basic_amd.presets import topogroup_ar_codec
     from oracle.codec_oracle import TopoGroupCodecOracle, psnr
     codec = _rand_params(topogroup_ar_codec(method, channel_groups=G), 3).eval()
@@ -28,12 +26,12 @@ def test_topogroup_codec_vs_oracle(method, G):
     codec = codec.cuda()
     codec.update_state()
     torch.manual_seed(11)
-    x = torch.rand(1, 3, 64, 128)
+    x = torch.rand(1, 3, h, w)
     data = codec.compress(x)
     ref = oracle.compress(x)
     xhat = codec.decompress(data).cpu()
     xref = oracle.decompress(ref)
-    print(f"{method}: {len(data)} B vs oracle {len(ref)} B, identical={data == ref}")
+    print(f"{method} g{G} {h}x{w}: {len(data)} B vs oracle {len(ref)} B, identical={data == ref}")
     if data != ref:
         # An autoregressive coder amplifies an fp32 tie: one flipped rounding / table row changes every later parameter.
         # So the FIRST element (in coding order) where the GPU's integers leave the oracle's is located and must be a tie
@@ -44,6 +42,19 @@ def test_topogroup_codec_vs_oracle(method, G):
         # the oracle decodes the GPU stream (cross-decoding) to the GPU's reconstruction
         assert float((oracle.decompress(data) - xhat).abs().max()) < 1e-3
     assert float((psnr(xhat, x) - psnr(xref, x)).abs().max()) < 0.01
+
+
+@pytest.mark.parametrize("method,G", [("checkerboard", 1), ("none", 1), ("raster2x2", 1), ("channelwise", 2), ("channelwise", 4), ("elic", 1),
+                                      ("scanline", 1)])
+def test_topogroup_codec_vs_oracle(method, G):
+    _codec_vs_oracle(method, G, 64, 128)
+
+
+@pytest.mark.parametrize("method,G", [("checkerboard", 1), ("channelwise", 4), ("raster2x2", 1)])
+def test_topogroup_codec_vs_oracle_full_size(method, G):
+    """BASELINE configs[2] at the size the metric is quoted on (3 x 256 x 256: 49,152 latents per image) against the CPU oracle --
+    the oracle codes such an image in a fraction of a second, so the comparison need not stop at 64 x 128."""
+    _codec_vs_oracle(method, G, 256, 256)
 
 
 def _assert_first_divergence_is_a_tie(codec, oracle, x, tag):
@@ -324,7 +335,7 @@ def test_streams_do_not_depend_on_batch_or_launch_shape(kind):
 
 
 # ---------------------------------------------------------------- BASELINE configs[2] / [3] at the size the metric is quoted on
-@pytest.mark.parametrize("kind", ["checkerboard", "basic-l0", "basic-l7"])
+@pytest.mark.parametrize("kind", ["checkerboard", "basic-l0", "basic-l7", "raster2x2", "elic", "scanline"])
 def test_kodak_shaped_ar_codecs_full_size(kind):
     """One Kodak-shaped image (3 x 512 x 768: latent 192 x 32 x 48, 294,912 symbols; the scan-line schedule of BaSIC is 1,536
     coding steps = ~6,100 in-kernel device barriers of the persistent launch) through compress / decompress:
@@ -340,7 +351,7 @@ def test_kodak_shaped_ar_codecs_full_size(kind):
         codec.update_state()
         codec.set_complex_level(int(kind[-1]))
     else:
-        codec = seed_synthetic_weights(topogroup_ar_codec("checkerboard"), seed=0).eval().cuda()
+        codec = seed_synthetic_weights(topogroup_ar_codec(kind), seed=0).eval().cuda()   # "scanline": the in-coder merger's scan-line schedule
         codec.update_state()
     ec = codec.entropy_coder
     yc = ec.latent_node_entropy_coders["y"]
@@ -359,9 +370,9 @@ def test_kodak_shaped_ar_codecs_full_size(kind):
     ybytes = yc.encode(y, prior=prior)
     assert yc.encode(y, prior=prior) == ybytes
     assert torch.equal(yc.decode(ybytes, prior=prior), ybuf)
-    if kind.startswith("basic"):
+    if kind.startswith("basic") or kind == "scanline":
         sl = yc._layers["scanline"][0]
-        assert sl is not None and yc._scanline_plan(plan, prior, 1) is sl, "the BaSIC y-coder at batch 1 runs the persistent launch"
+        assert sl is not None and yc._scanline_plan(plan, prior, 1) is sl, "a scan-line y-coder at batch 1 runs the persistent launch"
         sl.check()
         assert len(plan.groups) == 32 * 48
         # the per-step path: same bytes, reads the persistent path's stream (and vice versa)

@@ -39,7 +39,9 @@ def _coder(kind, C):
                                            ("ctxmodel-k3", 192, 1, 4, 3), ("ctxmodel-k3", 48, 2, 5, 6),
                                            # the batched kernel (the batch as the N dimension of MFMA tiles): one and two column tiles, full and ragged
                                            ("ctxmodel", 192, 8, 3, 5), ("ctxmodel", 192, 24, 4, 4), ("ctxmodel", 192, 64, 3, 4), ("ctxmodel", 192, 33, 2, 6),
-                                           ("ctxmodel", 192, 3, 5, 7), ("ctxmodel", 192, 5, 1, 4), ("ctxmodel-k3", 192, 40, 3, 3)])
+                                           ("ctxmodel", 192, 3, 5, 7), ("ctxmodel", 192, 5, 1, 4), ("ctxmodel-k3", 192, 40, 3, 3),
+                                           # ... at the sizes bench.py times (64 images of 256 x 256) and the reference tests on (Kodak-shaped latents)
+                                           ("ctxmodel", 192, 64, 16, 16), ("ctxmodel", 192, 8, 32, 48)])
 def test_persistent_encode_equals_per_step_path(kind, C, B, H, W):
     coder = _coder(kind, C)
     g = torch.Generator().manual_seed(B * 100 + H * 10 + W)
