@@ -532,15 +532,17 @@ def strong_proxy_child(args):
     import subprocess
     sb, sw, lanes = max(1, args.total // 8), max(2, args.strong_workers), 4
     steps = max(8 * args.steps, 4 * sw)
-    cmd = [sys.executable, os.path.abspath(__file__), "--batch", str(sb), "--workers", str(sw), "--token-lanes", str(lanes), "--steps", str(steps),
-           "--warmup", str(sw), "--size", str(args.size), "--no-cpu-baseline", "--no-extra-legs", "--no-dominant"]
+    cmd = [sys.executable, os.path.abspath(__file__), "--batch", str(sb), "--token-lanes", str(lanes), "--steps", str(steps),
+           "--warmup", str(sw), "--size", str(args.size), "--no-cpu-baseline", "--no-extra-legs", "--no-dominant"]   # (no --workers: probed, 4 / 5 / 6)
     try:
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
         lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
         if r.returncode != 0 or not lines:
             return dict(error=f"exit code {r.returncode}", stderr_tail=r.stderr[-400:])
         d = json.loads(lines[-1])
-        return dict(value=d["value"], unit="Mpix/s", images_per_step=sb, steps=steps, workers=sw, batches_in_flight=sw, token_lanes=lanes,
+        sw = d["config"].get("workers", sw)
+        return dict(value=d["value"], unit="Mpix/s", images_per_step=sb, steps=steps, workers=sw, workers_probe_mpix_s=d["config"].get("workers_probe_mpix_s"),
+                    batches_in_flight=sw, token_lanes=lanes, bytes_match_single_stream=d["config"].get("bytes_match_single_stream"),
                     ms_per_step=d["ms_per_step"], call_latency_ms=d["config"].get("call_latency_ms"), predicted_8gpu_strong=8 * d["value"],
                     note=f"BASELINE configs[4] as written is {args.total} images per step over 8 GPUs = {sb} per GPU: this leg runs that share on one GPU "
                          "(image-sharded, no data-path collective, so the N = 8 strong figure is 8 x it up to launch jitter); own process, `bench.py " + " ".join(cmd[2:]) + "`")
@@ -571,6 +573,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # measured at 256 images per step (scripts/r03_session/r03_call53-55.sh): 3 workers / 1 token lane 671-675 Mpix/s, 4 / 3 676-689,
     # 6 / 4 683-695 (also at 5 timed steps); under-filled tails of one session's launches are filled by another session's
+    # The worker count is PROBED at start-up unless --workers names it (never above 6: seven or more stream workers fall off a
+    # cliff -- 65-83 Mpix/s whatever the batch, profiles/r03_batch32_sweep.txt -- because six workers x two streams already share the
+    # eight hardware queues): 4, 5 and 6 workers run a few steps each on this rank's batch and the fastest is kept (config.workers_probe).
+    probe_workers = args.workers is None and args.shard_by == "steps"
     workers = max(1, args.workers if args.workers is not None else 6)
     if workers > 1:  # one hardware queue per worker stream (+ its entropy side stream); HIP's default 4 make streams share
         os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
@@ -601,7 +607,9 @@ def main():
     # packing more image streams into one rANS workgroup frees compute units for the other workers' transforms at the
     # price of a longer chain (+2 % at 4, +10 % at 8, x2 at 16): with whole batches in flight the chain has slack
     waves = args.rans_waves if args.rans_waves >= 0 else (8 if by_steps else 4 if workers > 1 else 0)
-    token_lanes = args.token_lanes if args.token_lanes is not None else (4 if (args.batch < 128 or workers >= 5) else 3 if workers == 4 else 1)
+    def lanes_for(w):   # transform phases admitted at a time: measured best per worker count (profiles/r03_batch32_sweep.txt, r03 call 53-55)
+        return args.token_lanes if args.token_lanes is not None else (4 if (args.batch < 128 or w >= 5) else 3 if w == 4 else 1)
+    token_lanes = lanes_for(workers)
 
     def make_codec():
         c = seed_synthetic_weights(hyperprior_codec(), seed=0).eval().to(dev)   # every replica: the same seeded weights
@@ -610,17 +618,20 @@ def main():
         c.entropy_coder.fused_transform_token = token_lanes if workers > 1 else 0
         return c
 
+    run_workers, run_lanes = [workers], [token_lanes]   # what run_leg() uses by default (updated by the start-up probe)
+
     def barrier():
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
 
-    def run_leg(pool, batch, steps, warmup, workers=workers, lanes=None):
+    def run_leg(pool, batch, steps, warmup, workers=None, lanes=None):
         """Exactly K steps (K x the whole batch through compress + decompress) spread over the first `workers` workers of the
         pool; returns (seconds, bytes of one step, [(bytes, xhat)] of one whole batch in image order, mean seconds of one
         compress+decompress call).  lanes: transform phases admitted at a time in this leg (default: the run's setting)."""
+        workers = run_workers[0] if workers is None else workers
         for c in pool.codecs:
-            c.entropy_coder.fused_transform_token = (token_lanes if lanes is None else lanes) if workers > 1 else 0
+            c.entropy_coder.fused_transform_token = (run_lanes[0] if lanes is None else lanes) if workers > 1 else 0
         if by_steps:   # step k on worker k mod W: whole batches, W of them in flight
             work = [(batch, len(range(w, steps, workers)), max(1, len(range(w, warmup, workers))) if warmup else 0)
                     for w in range(workers)]
@@ -663,11 +674,12 @@ def main():
         xs = torch.stack([image(i, args.size) for i in ids]).to(dev)
         small = len(ids) < 128   # small batches: more of them in flight, four transform phases side by side
         ssteps = args.steps * (8 if small else 1)
-        sdt, _, _, _ = run_leg(pool, xs, ssteps, strong_w if small else 1, workers=strong_w if small else workers, lanes=4 if small else None)
+        sw, sprobe = (strong_w, None) if not small else (pick_workers(xs, lambda w: 4) if args.workers is None else (strong_w, None))
+        sdt, _, _, _ = run_leg(pool, xs, ssteps, sw if small else 1, workers=sw if small else workers, lanes=4 if small else None)
         sred = reduce_metric_sums(dict(time_s=sdt, images=float(len(ids) * ssteps)), device=dev)
         return dict(value=sred["images"] * args.size ** 2 / sred["time_s"] / 1e6, unit="Mpix/s", scaling="strong",
                     images_total_per_step=args.total, images_per_gpu=len(ids), steps=ssteps,
-                    workers=strong_w if small else workers, token_lanes=4 if small else token_lanes,
+                    workers=sw if small else workers, workers_probe_mpix_s=sprobe, token_lanes=4 if small else token_lanes,
                     ms_per_step=sred["time_s"] / ssteps * 1e3,
                     note="image i of the step's set on rank i mod world; compare with the N=1 line's value (256 images on one GPU)")
 
@@ -677,6 +689,25 @@ def main():
     # that leg makes three sessions create their copy streams, after which the entropy side streams of the three sessions
     # that first run in the strong leg land on hardware queues that already carry busy streams (15 HIP streams on 8 queues).
     # The 256-image legs are not affected by what ran before them (667 vs 673 Mpix/s, run-to-run spread).
+    def pick_workers(batch_t, lanes_of):
+        """Times 4, 5 and 6 workers on a few steps of `batch_t` and returns (best count, {count: Mpix/s}); every rank takes the same
+        count (the slowest rank's view decides).  Never more than six: see the comment at the top of main()."""
+        cand = [w for w in (4, 5, 6) if w <= len(pool.codecs)]
+        probe = {}
+        for w in cand:
+            pdt, _, _, _ = run_leg(pool, batch_t, 2 * w, w, workers=w, lanes=lanes_of(w))
+            probe[w] = batch_t.shape[0] * 2 * w * args.size ** 2 / pdt / 1e6
+        if dist is not None and world > 1:
+            t = torch.tensor([probe[w] for w in cand], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            probe = {w: float(v) for w, v in zip(cand, t.tolist())}
+        return max(probe, key=lambda w: (probe[w], w)), probe
+
+    workers_probe = None
+    if probe_workers and workers > 1:
+        workers, workers_probe = pick_workers(x if args.input == "hbm" else x_host, lanes_for)
+        token_lanes = lanes_for(workers)
+        run_workers[0], run_lanes[0] = workers, token_lanes
     strong_first = args.strong_first or world > 1
     strong_first_result = None
     if (world > 1 or args.strong_in_process) and strong_first and not args.no_extra_legs:
@@ -752,7 +783,8 @@ def main():
                                  + 
                                  f"compress+decompress incl. bitstream D2H/H2D, {workers} concurrent stream workers per GPU "
                                  + ("(step k on worker k mod W: whole batches, W in flight)" if by_steps else "(each step's batch cut into W shards)"),
-                        images_per_gpu=args.batch, workers=workers, rans_waves_per_workgroup=waves,
+                        images_per_gpu=args.batch, workers=workers, workers_probe_mpix_s=workers_probe, token_lanes=token_lanes if workers > 1 else 0,
+                        rans_waves_per_workgroup=waves,
                         shard_by=args.shard_by if workers > 1 else None, batches_in_flight=workers if by_steps else 1,
                         call_latency_ms=call_s * 1e3, bytes_match_single_stream=bytes_match,
                         bpp=n_bytes * 8 / pix, psnr_db=red["psnr_sum"] / red["psnr_n"],
@@ -770,6 +802,11 @@ def main():
                           dominant=None if args.no_dominant else measure_dominant_kernel(codec, x)),
         )
         out.update(extra)
+        out["value_per_gpu"] = out["value"] / world
+        if "strong" in extra and "value" in extra["strong"]:   # BASELINE configs[4] as written, beside the weak figure
+            out["strong_value"] = extra["strong"]["value"]
+            out["strong_value_per_gpu"] = extra["strong"]["value"] / world
+            out["strong_over_weak"] = extra["strong"]["value"] / out["value"]
         if strong_proxy is not None:
             if "value" in strong_proxy:
                 strong_proxy["frac_of_value"] = strong_proxy["value"] / out["value"]
