@@ -32,6 +32,7 @@ _SIGNATURES = {
     "basic_rans_tables_set_ar": (_I, [_P, _P, _I, _I, _I, _I]),
     "basic_rans_tables_set_ar_ops": (_I, [_P, _P, _I]),
     "basic_rans_encode_host_ex": (_I, [_P, _P, _P, _L, _P, _P, _P, _P, _P, _L, _P]),
+    "basic_rans_encode_host_rows": (_I, [_P, _P, _P, _L, _P, _L, _P]),
     "basic_rans_decode_host_ex": (_I, [_P, _P, _L, _P, _L, _P, _P, _P, _P, _P]),
     "basic_rans_tables_info": (_I, [_P, _P, _P]),
     "basic_rans_tables_get_cdfs": (_I, [_P, _P, _I]),

@@ -159,6 +159,7 @@ class _Rans64Base:
             raise ValueError("ANS not initialized!")
         _lib.check(_lib.lib().basic_rans_tables_set_ar(self._tables, tab.ctypes.data, tab.shape[0], tab.shape[1], order, tab.shape[2]))
         self._ar_order = order
+        self._ar_host = ("table", tab.copy())
 
     def init_custom_ar_ops(self, ops):
         """ANSBase::init_custom_ar_ops (csrc/ans/ans_interface.hpp:40-48): a list of ``ar_limited_scaled_add_linear_op`` (the
@@ -177,6 +178,7 @@ class _Rans64Base:
                                    dtype=np.float32)
         _lib.check(_lib.lib().basic_rans_tables_set_ar_ops(self._tables, arr.ctypes.data, arr.shape[0]))
         self._ar_order = -1   # custom ops: the arity is the number of ar_offsets rows of a call
+        self._ar_host = ("ops", arr.copy())
 
     def get_cdfs(self):
         if self._tables is None:
@@ -186,6 +188,48 @@ class _Rans64Base:
         out = np.zeros((rows.value, mx.value), dtype=np.int32)
         _lib.check(_lib.lib().basic_rans_tables_get_cdfs(self._tables, out.ctypes.data, mx.value))
         return out
+
+    def _ar_rows(self, symbols, indexes, ar_indexes, ar_offsets):
+        """ar_update_index (csrc/ans/ans_interface.hpp:58-104) for every element of a call, on the host: the table row an
+        element is coded with once its autoregressive neighbours -- earlier elements of the SAME call, ``off[j][i]`` positions
+        back (0 = none) -- are taken into account.  Table mode: row = ar_table[ar_index][index][v0 + 1]([v1 + 1]) with 0 for a
+        missing neighbour; custom ops: the limited scaled-add op on the raw neighbour symbols in float32, every product and
+        sum rounded on its own.  Indices are clamped like the device kernels clamp them (the reference reads out of range).
+        Used by the cached encode path, whose symbols are resolved when they are cached (rans64.cpp:258-263,343)."""
+        n = indexes.size
+        if ar_offsets is None:
+            raise ValueError("ar_offsets is required for ar coding!")
+        off = _i32(ar_offsets).reshape(-1, n) if self._ar_order < 0 else _i32(ar_offsets).reshape(self._ar_order, n)
+        if off.shape[0] > 3:
+            raise ValueError("Too many dimensions!")
+        a = _i32(ar_indexes).reshape(-1) if ar_indexes is not None else np.zeros(n, dtype=np.int32)
+        pos = np.arange(n, dtype=np.int64)
+        kind, data = self._ar_host
+        if kind == "table":
+            k, rows, s1 = data.shape[:3]
+
+            def nb(j):   # GET_AR_VALUE_DEFAULT: neighbour symbol + 1, 0 when there is none
+                o = off[j].astype(np.int64)
+                return np.clip(np.where(o > 0, symbols[np.clip(pos - o, 0, n - 1)].astype(np.int64) + 1, 0), 0, s1 - 1)
+            aa, rr = np.clip(a, 0, k - 1), np.clip(indexes, 0, rows - 1)
+            out = data[aa, rr, nb(0)] if data.ndim == 3 else data[aa, rr, nb(0), nb(1)]
+            return np.ascontiguousarray(out, dtype=np.int32)
+        f = np.float32
+        op = data[np.clip(a, 0, data.shape[0] - 1)]          # [n, 7]: w0 w1 w2 bias scale min max
+
+        def raw(j):    # GET_AR_VALUE_NORMAL: the raw neighbour symbol, 0 when there is none
+            o = off[j].astype(np.int64)
+            return np.where(o > 0, symbols[np.clip(pos - o, 0, n - 1)], 0).astype(f)
+        base = indexes.astype(f)
+        unscaled = np.floor((base / op[:, 4]).astype(f)).astype(f)
+        adder = (f(0) + (raw(0) * op[:, 0]).astype(f)).astype(f)
+        for j in range(1, off.shape[0]):
+            adder = (adder + (raw(j) * op[:, j]).astype(f)).astype(f)
+        adder = (adder + op[:, 3]).astype(f)
+        lim = np.maximum(op[:, 5], np.minimum((unscaled + adder).astype(f), op[:, 6])).astype(f)
+        rnd = (np.trunc(lim) + (np.abs(lim - np.trunc(lim)) >= f(0.5)) * np.sign(lim)).astype(f)   # roundf: halves away from zero
+        step = ((rnd - unscaled).astype(f) * op[:, 4]).astype(f)
+        return np.ascontiguousarray((base + step).astype(f).astype(np.int32))
 
     def _ar_args(self, ar_indexes, ar_offsets, n):
         """(ar_indexes, off0, off1, off2 addresses, keep-alive) of a call."""
@@ -212,11 +256,11 @@ class Rans64Encoder(_Rans64Base):
             raise ValueError("ANS not initialized!")
         symbols, indexes = _i32(symbols).reshape(-1), _i32(indexes).reshape(-1)
         if cache:
-            if self._ar_order:
-                raise NotImplementedError("cached AR encoding")
             # reference semantics (rans64.cpp:332,343): symbols are appended in REVERSE order and
-            # flush() codes the buffer front-to-back, i.e. last call's symbols are decoded first.
-            self._cache.append((symbols.copy(), indexes.copy()))
+            # flush() codes the buffer front-to-back, i.e. last call's symbols are decoded first.  An AR call's rows are
+            # resolved NOW, from this call's own symbols (:258-263): the cache holds (symbol, final row) pairs
+            rows = self._ar_rows(symbols, indexes, ar_indexes, ar_offsets) if self._ar_order else indexes.copy()
+            self._cache.append((symbols.copy(), rows))
             return b""
         n = indexes.size
         ai, o0, o1, o2, keep = self._ar_args(ar_indexes, ar_offsets, n)
@@ -239,7 +283,17 @@ class Rans64Encoder(_Rans64Base):
             indexes = np.concatenate([c[1] for c in chunks])
         else:
             symbols = indexes = np.zeros(0, dtype=np.int32)
-        return self.encode_with_indexes(symbols, indexes)
+        if not self._ar_order:
+            return self.encode_with_indexes(symbols, indexes)
+        # an AR table set: the cached rows are final, flush() codes them as they are (rans64.cpp:363-386 knows no AR)
+        n = indexes.size
+        symbols, indexes = np.ascontiguousarray(symbols), np.ascontiguousarray(indexes)
+        cap = _lib.lib().basic_rans_encode_bound(n)
+        out = np.empty(cap, dtype=np.uint8)
+        out_len = ctypes.c_int64()
+        _lib.check(_lib.lib().basic_rans_encode_host_rows(self._tables, symbols.ctypes.data, indexes.ctypes.data, n, out.ctypes.data, cap,
+                                                          ctypes.byref(out_len)))
+        return out[: out_len.value].tobytes()
 
     def peek_cache(self):
         """rans64.hpp:78-86: the cached rANS symbols as int32 [m, 3] rows (start, range, bypass flag) in the order flush()
@@ -391,6 +445,7 @@ class _TansBase:
             raise ValueError("ANS not initialized!")
         _lib.check(_lib.lib().basic_tans_tables_set_ar(self._tables, tab.ctypes.data, tab.shape[0], tab.shape[1], order, tab.shape[2]))
         self._ar_order = order
+        self._ar_host = ("table", tab.copy())
 
     def get_table_row(self, row):
         """(next_state, delta_bits, delta_state, decode entries) of one distribution -- not part of the reference's bound
@@ -405,6 +460,7 @@ class _TansBase:
         return nxt, db, ds, dec
 
     _ar_args = _Rans64Base._ar_args
+    _ar_rows = _Rans64Base._ar_rows
 
 
 class TansEncoder(_TansBase):

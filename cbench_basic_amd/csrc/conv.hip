@@ -953,6 +953,146 @@ __global__ __launch_bounds__(256) void deconv5s2_cout3_dma_kernel(const SmallLau
     }
 }
 
+// The same layer with TWO vertically adjacent strips per lane (a 2 x 4 block of input positions -> 4 x 8 output pixels x Cout):
+// a channel's 75 wave-uniform weights now feed 300 packed FMAs per lane instead of 150 -- the scalar loads per FMA halve (the
+// 40 KB of weights do not fit the scalar cache: counters of round 2 showed half of those loads missing) -- and the two strips
+// share two of their four patch rows (24 LDS values per 8 positions instead of 36).  Same FMA order per output as the kernel
+// above: identical results.  Tile = 32 x 64 input positions per workgroup.
+constexpr int kSm2TileH = 32;
+constexpr int kSm2PH = kSm2TileH + 2;
+constexpr int kSm2CK = 2;                                    // input channels per stage
+constexpr int kSm2Chunks = kSm2CK * kSm2PH * kSmDRow;        // 16-byte chunks per stage
+constexpr int kSm2Slots = (kSm2Chunks + 255) / 256;
+constexpr int kSm2Stage = kSm2Slots * 256 * 4;
+
+__global__ __launch_bounds__(256) void deconv5s2_cout3_dma2_kernel(const SmallLaunch g)
+{
+    __shared__ __attribute__((aligned(16))) float buf[2 * kSm2Stage];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int bid = xcd_tile(blockIdx.x, gridDim.x);
+    const int tx_i = bid % g.tiles_x; bid /= g.tiles_x;
+    const int ty_i = bid % g.tiles_y; bid /= g.tiles_y;
+    const int b = bid;
+    const int lxq = tid & 15, ly = tid >> 4;
+    const int my = ty_i * kSm2TileH + 2 * ly, mx0 = tx_i * kSmTileW + 4 * lxq;
+    const int64_t plane = static_cast<int64_t>(g.in_h) * g.in_w;
+    const float *inb = g.in + static_cast<int64_t>(b) * g.cin * plane;
+    const int nstages = (g.cin + kSm2CK - 1) / kSm2CK;
+
+    const float *pp[kSm2Slots];
+    int pstride[kSm2Slots];
+    unsigned lastmask = 0;
+#pragma unroll
+    for (int sl = 0; sl < kSm2Slots; ++sl) {
+        const int k = tid + sl * 256;
+        const float *ptr = basic_zero_page;
+        int stride = 0;
+        if (k < kSm2Chunks) {
+            const int j = k % kSmDRow, r = k / kSmDRow;
+            const int py = r % kSm2PH, ci = r / kSm2PH;
+            const int gy = ty_i * kSm2TileH - 1 + py, gx = tx_i * kSmTileW - 4 + 4 * j;
+            if (gy >= 0 && gy < g.in_h && gx >= 0 && gx < g.in_w && ci < g.cin) {
+                ptr = inb + ci * plane + static_cast<int64_t>(gy) * g.in_w + gx;
+                stride = static_cast<int>(kSm2CK * plane * 4);
+                if ((nstages - 1) * kSm2CK + ci >= g.cin) lastmask |= 1u << sl;
+            }
+        }
+        pp[sl] = ptr;
+        pstride[sl] = stride;
+    }
+#define BASIC_SM2_ISSUE(S)                                                                                     \
+    do {                                                                                                       \
+        if ((S) == nstages - 1 && lastmask) {                                                                  \
+            _Pragma("unroll") for (int sl = 0; sl < kSm2Slots; ++sl)                                           \
+                if ((lastmask >> sl) & 1u) pp[sl] = basic_zero_page;                                           \
+        }                                                                                                      \
+        float *dst_ = buf + ((S) & 1) * kSm2Stage + wave * 256;                                                \
+        _Pragma("unroll") for (int sl = 0; sl < kSm2Slots; ++sl) {                                             \
+            __builtin_amdgcn_global_load_lds((glb_cvoid *)pp[sl], (lds_void *)(dst_ + sl * 1024), 16, 0, 0);   \
+            pp[sl] = reinterpret_cast<const float *>(reinterpret_cast<const char *>(pp[sl]) + pstride[sl]);    \
+        }                                                                                                      \
+    } while (0)
+
+    f32x2 acc[2][2][2][2][3];  // [strip row][pair of strip positions][py][px][co]
+#pragma unroll
+    for (int sr = 0; sr < 2; ++sr)
+#pragma unroll
+        for (int qp = 0; qp < 2; ++qp)
+#pragma unroll
+            for (int py = 0; py < 2; ++py)
+#pragma unroll
+                for (int px = 0; px < 2; ++px)
+#pragma unroll
+                    for (int co = 0; co < 3; ++co) acc[sr][qp][py][px][co] = f32x2{0.f, 0.f};
+
+    BASIC_SM2_ISSUE(0);
+    for (int stg = 0; stg < nstages; ++stg) {
+        __syncthreads();
+        if (stg + 1 < nstages) BASIC_SM2_ISSUE(stg + 1);
+        const float *st = buf + (stg & 1) * kSm2Stage;
+        const int c0 = stg * kSm2CK;
+        const int cmax = (g.cin - c0 < kSm2CK) ? g.cin - c0 : kSm2CK;
+        for (int ci = 0; ci < cmax; ++ci) {
+            // rows 2 ly .. 2 ly + 3 of the patch = rows my - 1 .. my + 2 of the image: strip row sr uses patch rows sr .. sr + 2
+            f32x2 pr[4][5];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const float *row = st + ((ci * kSm2PH + 2 * ly + a) * kSmDRow + lxq) * 4 + 3;
+                const float v0 = row[0], v5 = row[5];
+                const f32x4 mid = *reinterpret_cast<const f32x4 *>(row + 1);
+                pr[a][0] = f32x2{v0, mid[0]};
+                pr[a][1] = f32x2{mid[0], mid[1]};
+                pr[a][2] = f32x2{mid[1], mid[2]};
+                pr[a][3] = f32x2{mid[2], mid[3]};
+                pr[a][4] = f32x2{mid[3], v5};
+            }
+            const cf32x16s *w16 = (const cf32x16s *)(g.wsm + static_cast<int64_t>(c0 + ci) * kSmWRow);
+            const f32x16s w0 = w16[0], w1 = w16[1], w2 = w16[2], w3 = w16[3], w4 = w16[4];
+#pragma unroll
+            for (int ky = 0; ky < 5; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 5; ++kx) {
+                    const int py = ky & 1, px = kx & 1;
+                    const int dy = (py + 2 - ky) / 2, dx = (px + 2 - kx) / 2;
+#pragma unroll
+                    for (int co = 0; co < 3; ++co) {
+                        const int wi = (ky * 5 + kx) * 3 + co;
+                        const float w = wi < 16 ? w0[wi & 15] : wi < 32 ? w1[wi & 15] : wi < 48 ? w2[wi & 15] : wi < 64 ? w3[wi & 15] : w4[wi & 15];
+                        const f32x2 ww = {w, w};
+#pragma unroll
+                        for (int sr = 0; sr < 2; ++sr)
+#pragma unroll
+                            for (int qp = 0; qp < 2; ++qp)
+                                acc[sr][qp][py][px][co] = __builtin_elementwise_fma(pr[sr + dy + 1][2 * qp + dx + 1], ww, acc[sr][qp][py][px][co]);
+                    }
+                }
+        }
+    }
+#undef BASIC_SM2_ISSUE
+    const int oh = 2 * g.in_h, ow = 2 * g.in_w;
+#pragma unroll
+    for (int sr = 0; sr < 2; ++sr) {
+        if (my + sr >= g.in_h) break;
+#pragma unroll
+        for (int co = 0; co < 3; ++co) {
+            if (co >= g.cout) break;
+            const float bv = g.bias[co];
+            float *o = g.out + (static_cast<int64_t>(b) * g.cout + co) * oh * ow + static_cast<int64_t>(2 * (my + sr)) * ow + 2 * mx0;
+#pragma unroll
+            for (int py = 0; py < 2; ++py)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (mx0 + q >= g.in_w) break;
+                    float2 r;
+                    r.x = apply_act(acc[sr][q >> 1][py][0][co][q & 1] + bv, g.act);
+                    r.y = apply_act(acc[sr][q >> 1][py][1][co][q & 1] + bv, g.act);
+                    *reinterpret_cast<float2 *>(o + py * ow + 2 * q) = r;
+                }
+        }
+    }
+}
+
 struct Phase {
     int ntaps = 0, dymin = 0, dxmin = 0, span_y = 1, span_x = 1;
     int oy0 = 0, ox0 = 0;
@@ -1379,7 +1519,12 @@ extern "C" int basic_conv_forward_dev(const basic_conv_plan *p, const float *d_i
         g.tiles_y = (in_h + kSmTileH - 1) / kSmTileH;
         g.tiles_x = (in_w + kSmTileW - 1) / kSmTileW;
         const int blocks = batch * g.tiles_y * g.tiles_x;
-        if (in_w % 4 == 0 && (reinterpret_cast<uintptr_t>(d_in) & 15) == 0)
+        const char *two = getenv("BASIC_CONV_LAST_2ROW");   // experiment switch: two strips per lane (identical results)
+        const bool dma_ok = in_w % 4 == 0 && (reinterpret_cast<uintptr_t>(d_in) & 15) == 0;
+        if (dma_ok && (two ? atoi(two) != 0 : in_h >= 64)) {
+            g.tiles_y = (in_h + kSm2TileH - 1) / kSm2TileH;
+            hipLaunchKernelGGL(deconv5s2_cout3_dma2_kernel, dim3(batch * g.tiles_y * g.tiles_x), dim3(256), 0, as_stream(hip_stream), g);
+        } else if (dma_ok)
             hipLaunchKernelGGL(deconv5s2_cout3_dma_kernel, dim3(blocks), dim3(256), 0, as_stream(hip_stream), g);
         else
             hipLaunchKernelGGL(deconv5s2_cout3_kernel, dim3(blocks), dim3(256), 0, as_stream(hip_stream), g);

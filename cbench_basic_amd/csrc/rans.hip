@@ -1441,9 +1441,31 @@ extern "C" int basic_rans_encode_host(const basic_rans_tables *t, const int32_t 
     return basic_rans_encode_host_ex(t, symbols, indexes, n, ar_indexes, ar_off0, ar_off1, nullptr, out, out_capacity, out_len);
 }
 
+namespace {
+int encode_host_impl(const basic_rans_tables *t, const int32_t *symbols, const int32_t *indexes, int64_t n, bool use_ar,
+                     const int32_t *ar_indexes, const int32_t *ar_off0, const int32_t *ar_off1, const int32_t *ar_off2, uint8_t *out,
+                     int64_t out_capacity, int64_t *out_len);
+}
+
 extern "C" int basic_rans_encode_host_ex(const basic_rans_tables *t, const int32_t *symbols, const int32_t *indexes,
                                          int64_t n, const int32_t *ar_indexes, const int32_t *ar_off0, const int32_t *ar_off1,
                                          const int32_t *ar_off2, uint8_t *out, int64_t out_capacity, int64_t *out_len)
+{
+    return encode_host_impl(t, symbols, indexes, n, true, ar_indexes, ar_off0, ar_off1, ar_off2, out, out_capacity, out_len);
+}
+
+// The same with the table rows taken as given even when the set carries an AR remap: what Rans64Encoder::flush() does with
+// symbols cached by AR calls -- their rows were remapped when they were cached (rans64.cpp:258-263,343,363-386).
+extern "C" int basic_rans_encode_host_rows(const basic_rans_tables *t, const int32_t *symbols, const int32_t *indexes, int64_t n,
+                                           uint8_t *out, int64_t out_capacity, int64_t *out_len)
+{
+    return encode_host_impl(t, symbols, indexes, n, false, nullptr, nullptr, nullptr, nullptr, out, out_capacity, out_len);
+}
+
+namespace {
+int encode_host_impl(const basic_rans_tables *t, const int32_t *symbols, const int32_t *indexes, int64_t n, bool use_ar,
+                     const int32_t *ar_indexes, const int32_t *ar_off0, const int32_t *ar_off1, const int32_t *ar_off2, uint8_t *out,
+                     int64_t out_capacity, int64_t *out_len)
 {
     if (!t) { set_error("ANS not initialized!"); return BASIC_ERR_NOT_INIT; }
     BASIC_REQUIRE(n >= 0 && out && out_len && (n == 0 || (symbols && indexes)), "encode_with_indexes: bad argument");
@@ -1461,8 +1483,8 @@ extern "C" int basic_rans_encode_host_ex(const basic_rans_tables *t, const int32
     }
     const int64_t seg[2] = {0, n};
     BASIC_HIP_TRY(hipMemcpy(b_seg.p, seg, sizeof(seg), hipMemcpyHostToDevice));
-    ArDev ar;
-    int rc = stage_ar(t, n, ar_indexes, ar_off0, ar_off1, ar_off2, b_ai, b_o0, b_o1, b_o2, ar);
+    ArDev ar{};
+    int rc = use_ar ? stage_ar(t, n, ar_indexes, ar_off0, ar_off1, ar_off2, b_ai, b_o0, b_o1, b_o2, ar) : BASIC_OK;
     if (rc) return rc;
     if (!ar.tab && t->fast_enc_ok)  // same kernel choice as the batched device entry point
         hipLaunchKernelGGL(rans_encode_fast_kernel<1>, dim3(1), dim3(64), static_cast<size_t>(t->rows) * sizeof(int2), nullptr,
@@ -1481,6 +1503,7 @@ extern "C" int basic_rans_encode_host_ex(const basic_rans_tables *t, const int32
     BASIC_HIP_TRY(hipMemcpy(out, b_out.as<uint32_t>() + (slot_words - nwords), nbytes, hipMemcpyDeviceToHost));
     return BASIC_OK;
 }
+}  // namespace
 
 struct basic_rans_stream {
     const basic_rans_tables *t = nullptr;

@@ -78,6 +78,10 @@ int basic_rans_encode_host(const basic_rans_tables *t, const int32_t *symbols, c
 int basic_rans_encode_host_ex(const basic_rans_tables *t, const int32_t *symbols, const int32_t *indexes, int64_t n,
                               const int32_t *ar_indexes, const int32_t *ar_off0, const int32_t *ar_off1,
                               const int32_t *ar_off2, uint8_t *out, int64_t out_capacity, int64_t *out_len);
+/* The same with the table rows taken as given even when the set carries an AR remap: Rans64Encoder::flush() of symbols that AR
+ * calls cached -- their rows were remapped when they were cached (rans64.cpp:258-263,343,363-386). */
+int basic_rans_encode_host_rows(const basic_rans_tables *t, const int32_t *symbols, const int32_t *indexes, int64_t n,
+                                uint8_t *out, int64_t out_capacity, int64_t *out_len);
 int basic_rans_decode_host_ex(const basic_rans_tables *t, const uint8_t *stream, int64_t stream_len, const int32_t *indexes,
                               int64_t n, const int32_t *ar_indexes, const int32_t *ar_off0, const int32_t *ar_off1,
                               const int32_t *ar_off2, int32_t *out_symbols);

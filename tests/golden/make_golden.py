@@ -1115,7 +1115,42 @@ def rans_cache_kats():
         out["p.positive_raises"] = np.array(0)
     except ValueError:
         out["p.positive_raises"] = np.array(1)
-    out["names"], out["npcases"] = np.array(names), np.array(len(pcases))
+    # cached encoding on AUTOREGRESSIVE table sets (rans64.cpp:237-361: an AR call's rows are resolved from that call's own
+    # symbols when it is cached; flush() codes the cached (start, range) pairs as they are): remap tables of order 1 and 2,
+    # and the custom limited scaled-add op with two predecessors; two or three cached calls each
+    arnames = []
+    for ai_, (mode, order, calls) in enumerate([("table", 1, [60, 35]), ("table", 2, [50, 20, 41]), ("ops", 2, [70, 45])]):
+        nd, ns = 8, 12
+        freqs = rng.integers(1, 500, (nd, ns)).astype(np.int32)
+        nsym, off = np.full(nd, ns, np.int32), np.zeros(nd, np.int32)
+        enc = ref_ans.Rans64Encoder(16, True, 4)
+        enc.init_params(freqs, nsym, off)
+        k = f"a{ai_}"
+        out.update({f"{k}.freqs": freqs, f"{k}.nsym": nsym, f"{k}.offsets": off, f"{k}.mode": np.array(mode), f"{k}.order": np.array(order),
+                    f"{k}.ncalls": np.array(len(calls))})
+        if mode == "table":
+            ktab = 2
+            tab = rng.integers(0, nd, (ktab, nd) + (ns + 1,) * order).astype(np.int32)
+            enc.init_ar_params(tab, np.zeros((ktab, order, 1), np.int32))
+            out[f"{k}.ar_table"] = tab
+        else:
+            ktab = 3
+            ops = [((rng.random(order) * 0.6 - 0.3).round(4).tolist(), float(np.round(rng.random() - 0.5, 4)), float([1.0, 2.0, 4.0][j]), 0.0,
+                    float(nd // int([1.0, 2.0, 4.0][j]) - 1)) for j in range(ktab)]
+            enc.init_custom_ar_ops([ref_ans.ar_limited_scaled_add_linear_op(*o) for o in ops])
+            out[f"{k}.ops"] = np.array([list(o[0]) + [0.0] * (3 - order) + list(o[1:]) for o in ops], np.float64)
+        for j, n in enumerate(calls):
+            idx = rng.integers(0, nd, n).astype(np.int32)
+            sym = rng.integers(0, ns, n).astype(np.int32)     # inside the remap table's range (the reference does not check)
+            ai = rng.integers(0, ktab, n).astype(np.int32)
+            aoff = np.stack([np.minimum(np.arange(n), 1 + 2 * q) for q in range(order)]).astype(np.int32)
+            assert enc.encode_with_indexes(sym, idx, ai, aoff, True) == b""
+            out.update({f"{k}.sym{j}": sym, f"{k}.idx{j}": idx, f"{k}.ai{j}": ai, f"{k}.aoff{j}": aoff,
+                        f"{k}.peek{j}": np.array(enc.peek_cache()).astype(np.int32)})
+        out[f"{k}.flush"] = b2a(enc.flush())
+        arnames.append(k)
+        print(f"  {k}: cached AR ({mode}, order {order}): {sum(calls)} symbols in {len(calls)} calls -> {out[f'{k}.flush'].size} bytes")
+    out["names"], out["npcases"], out["arnames"] = np.array(names), np.array(len(pcases)), np.array(arnames)
     save("rans_cache_kat.npz", **out)
 
 

@@ -123,6 +123,22 @@ def test_symbol_cache_peek_and_flush_vs_reference():
             assert np.array_equal(enc.peek_cache(), z[f"{k}.peek{j}"]), (k, j)
         assert enc.flush() == z[f"{k}.flush"].tobytes(), k
         assert enc.peek_cache().shape == (0, 3) and z[f"{k}.peek_after"].shape == (0, 3)
+    # cached encoding on autoregressive table sets (rans64.cpp:237-361): remap tables of order 1 / 2 and the custom op
+    for k in (str(n) for n in z["arnames"]):
+        enc = ans.Rans64Encoder(16, True, 4)
+        enc.init_params(z[f"{k}.freqs"], z[f"{k}.nsym"], z[f"{k}.offsets"])
+        order = int(z[f"{k}.order"])
+        if str(z[f"{k}.mode"]) == "table":
+            tab = z[f"{k}.ar_table"]
+            enc.init_ar_params(tab, np.zeros((tab.shape[0], order, 1), np.int32))
+        else:
+            enc.init_custom_ar_ops([ans.ar_limited_scaled_add_linear_op([float(v) for v in o[:order]], float(o[3]), float(o[4]), float(o[5]), float(o[6]))
+                                    for o in z[f"{k}.ops"]])
+        for j in range(int(z[f"{k}.ncalls"])):
+            assert enc.encode_with_indexes(z[f"{k}.sym{j}"], z[f"{k}.idx{j}"], z[f"{k}.ai{j}"], z[f"{k}.aoff{j}"], True) == b""
+            assert np.array_equal(enc.peek_cache(), z[f"{k}.peek{j}"]), (k, j)
+        assert enc.flush() == z[f"{k}.flush"].tobytes(), k
+        assert enc.peek_cache().shape == (0, 3)
 
 
 def test_masked_conv_reference_outputs_on_hip():
