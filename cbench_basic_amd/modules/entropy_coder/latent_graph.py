@@ -89,6 +89,20 @@ class ParamDictModuleWrapper(nn.Module):
         return out
 
 
+class BasicLatentGraphicalNodeAggregatorModel(nn.Module):
+    """latent_graph.py:55-60: folds the list of values several edges delivered to one node."""
+
+    def forward(self, input_list, *args, **kwargs):
+        raise NotImplementedError()
+
+
+class AverageNodeAggregatorModel(BasicLatentGraphicalNodeAggregatorModel):
+    """latent_graph.py:63-65."""
+
+    def forward(self, input_list, *args, **kwargs):
+        return torch.stack(input_list).mean(0)
+
+
 class LatentGraphicalANSEntropyCoder(HotPathModule, VariableRateCodecInterface, VariableComplexityCodecInterface,
                                      VariableTaskCodecInterface):
     DEFAULT_EDGE_SPLIT_SYMBOL = "_"
@@ -113,6 +127,8 @@ class LatentGraphicalANSEntropyCoder(HotPathModule, VariableRateCodecInterface, 
                  latent_generative_input_mapping: Optional[Dict[str, Dict[str, str]]] = None,
                  latent_node_inference_topo_order: Optional[List[str]] = None,
                  latent_node_generative_topo_order: Optional[List[str]] = None,
+                 latent_inference_node_aggregator_dict: Optional[Dict[str, nn.Module]] = None,
+                 latent_generative_node_aggregator_dict: Optional[Dict[str, nn.Module]] = None,
                  complexity_metric_list=None,
                  complexity_level_greedy_search=False,
                  complexity_level_greedy_search_dataset: Optional[Iterable] = None,
@@ -145,6 +161,10 @@ class LatentGraphicalANSEntropyCoder(HotPathModule, VariableRateCodecInterface, 
         self.latent_generative_modules = nn.ModuleDict(dict(latent_generative_dict or {}))
         self.latent_inference_input_mapping = dict(latent_inference_input_mapping or {})
         self.latent_generative_input_mapping = dict(latent_generative_input_mapping or {})
+        # multi-edge aggregators (latent_graph.py:343-344,467-468): a node fed by SEVERAL edges collects their outputs in a list,
+        # the node's aggregator folds it.  Same attribute names as the reference: they are state_dict prefixes
+        self.latent_inference_node_aggregator_modules = nn.ModuleDict(dict(latent_inference_node_aggregator_dict or {}))
+        self.latent_generative_node_aggregator_modules = nn.ModuleDict(dict(latent_generative_node_aggregator_dict or {}))
         self.latent_node_inference_topo_order = list(latent_node_inference_topo_order)
         self.latent_node_generative_topo_order = list(latent_node_generative_topo_order)
         self.complexity_level_greedy_search = complexity_level_greedy_search
@@ -282,9 +302,14 @@ class LatentGraphicalANSEntropyCoder(HotPathModule, VariableRateCodecInterface, 
                 inode, onode = edge.split(sym)
                 with self.profiler.start_time_profile(f"latent_inference_modules_{edge}"):
                     val = self.latent_inference_modules[edge](out[inode], **kw)
-                if onode in out:
-                    raise NotImplementedError("multi-edge aggregation is not on the hot path")
-                out[onode] = val
+                if onode in out:   # a second edge into the node: collect (latent_graph.py:741-746)
+                    if not isinstance(out[onode], list):
+                        out[onode] = [out[onode]]
+                    out[onode].append(val)
+                else:
+                    out[onode] = val
+            if node in self.latent_inference_node_aggregator_modules:   # (:748-749)
+                out[node] = self.latent_inference_node_aggregator_modules[node](out[node])
         return out
 
     # ---- generative pass (latent_graph.py:760-868)
@@ -298,6 +323,14 @@ class LatentGraphicalANSEntropyCoder(HotPathModule, VariableRateCodecInterface, 
             nodes.remove(self.DEFAULT_INPUT_NODE_NAME)
         for node in nodes:
             prior_dict.setdefault(node, dict())
+            if node in self.latent_generative_node_aggregator_modules:
+                # (:795-796) the reference replaces the node's prior DICT by the aggregator's result and then goes on treating it
+                # as a dict (len(), .values(), :806-819): only an aggregator that returns a mapping works there; same here
+                agg = self.latent_generative_node_aggregator_modules[node](list(prior_dict[node].values()))
+                if not isinstance(agg, dict):
+                    raise TypeError(f"latent_generative_node_aggregator of node {node} must return a dict of priors "
+                                    "(the reference's own traversal reads .values() of the result, latent_graph.py:806-819)")
+                prior_dict[node] = agg
             node_data = data.get(node)
             if node in self.latent_node_entropy_coders:
                 coder = self.latent_node_entropy_coders[node]

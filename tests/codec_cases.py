@@ -41,7 +41,22 @@ def build_codec(z, k, y_extra=None, **graph_extra):
     from cbench_basic_amd.modules.prior_model.prior_coder.compressai_coder import CompressAIEntropyBottleneckPriorCoder
     from cbench_basic_amd.modules.prior_model.prior_coder.pgm_coder import (GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder,
                                                                             TopoGroupDynamicMaskConv2dContextModel)
-    if k.startswith("h"):   # the plain hyperprior graph: exactly what presets.hyperprior_codec builds
+    if k.startswith("g"):   # multi-edge aggregation: z = mean(y_z(y), w_z(w)), w = a second, uncoded analysis of x (latent_graph.py:741-749)
+        from cbench_basic_amd.modules.entropy_coder.latent_graph import AverageNodeAggregatorModel
+        from cbench_basic_amd.modules.prior_model.prior_coder.compressai_coder import CompressAIGaussianConditionalCoder
+        from cbench_basic_amd.nn.models.google import (HyperpriorAnalysisModel, HyperpriorHyperAnalysisModel,
+                                                       HyperpriorHyperSynthesisModel, HyperpriorSynthesisModel)
+        c = hyper_cfg(z, k)
+        N, M = c["N"], c["M"]
+        ec = LatentGraphicalANSEntropyCoder(
+            latent_node_inference_topo_order=["x", "y", "w", "z"], latent_node_generative_topo_order=["z", "y", "x"],
+            latent_node_entropy_coder_dict=dict(x=LossyDummyEntropyCoder(lambda_rd=145.2225), y=CompressAIGaussianConditionalCoder(),
+                                                z=CompressAIEntropyBottleneckPriorCoder(entropy_bottleneck_channels=N, use_inner_aux_opt=True)),
+            latent_inference_dict=dict(x_y=HyperpriorAnalysisModel(N=N, M=M), x_w=HyperpriorAnalysisModel(N=N, M=M),
+                                       y_z=HyperpriorHyperAnalysisModel(N=N, M=M), w_z=HyperpriorHyperAnalysisModel(N=N, M=M)),
+            latent_generative_dict=dict(z_y=HyperpriorHyperSynthesisModel(N=N, M=M), y_x=HyperpriorSynthesisModel(N=N, M=M)),
+            latent_inference_node_aggregator_dict=dict(z=AverageNodeAggregatorModel()))
+    elif k.startswith("h"):   # the plain hyperprior graph: exactly what presets.hyperprior_codec builds
         from cbench_basic_amd.presets import hyperprior_codec
         c = hyper_cfg(z, k)
         ec = hyperprior_codec(N=c["N"], M=c["M"]).entropy_coder
@@ -100,7 +115,7 @@ def build_codec(z, k, y_extra=None, **graph_extra):
 
 
 def case_input(z, k):
-    c = hyper_cfg(z, k) if k.startswith("h") else topo_cfg(z, k) if k.startswith("t") else basic_cfg(z)
+    c = hyper_cfg(z, k) if k[0] in "hg" else topo_cfg(z, k) if k.startswith("t") else basic_cfg(z)
     return recipe_input(int(z[f"{k}.xseed"]), (c["B"], 3, c["H"], c["W"]))
 
 
@@ -118,7 +133,7 @@ def build_oracle(z, k, state_dict):
 
 def records(z, k):
     """Fixture record prefixes of case k: the case itself, or one per complexity level for the BaSIC graph."""
-    if k[0] in "th":
+    if k[0] in "thg":
         return [(k, None)]
     return [(f"b0.l{i}", i) for i in range(len(z["b0.levels"]))]
 

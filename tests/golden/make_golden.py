@@ -702,6 +702,60 @@ def codec_graph():
               f"prior_entropy {met.get('prior_entropy', float('nan')):.2f}")
         finish(k, codec, touched, seed, 820 + ci, calib)
 
+    # ---- multi-edge aggregation in the inference pass (latent_graph.py:741-749): the hyper-latent z is the AVERAGE of two
+    #      edges -- y_z(y) and w_z(w), with w a second analysis of x that is not coded itself -- folded by the reference's
+    #      AverageNodeAggregatorModel; everything else as in the plain hyperprior graph
+    from cbench.modules.entropy_coder.latent_graph import AverageNodeAggregatorModel
+    agg_keys = []
+    for ci, (B, H, W) in enumerate([(2, 64, 96)]):
+        k = f"g{ci}"
+        ec = LatentGraphicalANSEntropyCoder(
+            latent_node_inference_topo_order=["x", "y", "w", "z"], latent_node_generative_topo_order=["z", "y", "x"],
+            latent_node_entropy_coder_dict=dict(x=LossyDummyEntropyCoder(lambda_rd=145.2225),
+                                                y=CompressAIGaussianConditionalCoder(),
+                                                z=CompressAIEntropyBottleneckPriorCoder(entropy_bottleneck_channels=N, use_inner_aux_opt=True)),
+            latent_inference_dict=dict(x_y=HyperpriorAnalysisModel(N=N, M=M), x_w=HyperpriorAnalysisModel(N=N, M=M),
+                                       y_z=HyperpriorHyperAnalysisModel(N=N, M=M), w_z=HyperpriorHyperAnalysisModel(N=N, M=M)),
+            latent_generative_dict=dict(z_y=HyperpriorHyperSynthesisModel(N=N, M=M), y_x=HyperpriorSynthesisModel(N=N, M=M)),
+            latent_inference_node_aggregator_dict=dict(z=AverageNodeAggregatorModel()))
+        codec = GeneralCodec(entropy_coder=ec).eval()
+        seed = 740 + ci
+        pre = "entropy_coder.latent_inference_modules."
+        gen = "entropy_coder.latent_generative_modules."
+        calib = [(pre + "x_y.model.6.weight", 8.0, 0.0), (pre + "x_w.model.6.weight", 8.0, 0.0), (pre + "y_z.model.4.weight", 6.0, 0.0),
+                 (pre + "w_z.model.4.weight", 6.0, 0.0), (gen + "z_y.model.4.bias", 1.0, 1.5), (gen + "y_x.model.0.weight", 0.05, 0.0)]
+        touched = named_seed_weights(codec, seed, calib)
+        codec.update_state()
+        x = recipe_input(840 + ci, (B, 3, H, W))
+        log = []
+        undo = spy_native(log)
+        with torch.no_grad():
+            data = codec.compress(x)
+        undo()
+        assert len(log) == 2 * B
+        zs, ys = log[:B], log[B:]
+        with torch.no_grad():
+            xhat = codec.decompress(data)
+            node = ec._node_generate_process(**ec._get_default_node_dict(force_add_default_dynamic_nodes=True))
+            lat = ec._inference_process({"x": x, **node})
+            codec.reset_all_cache()
+            xfwd = codec(x)
+            met = {n.split("metric_dict/entropy_coder/")[-1]: float(v) for n, v in codec.get_cache("metric_dict").items()}
+        assert not isinstance(lat["z"], list)
+        out.update({f"{k}.bytes": b2a(data), f"{k}.symbols": np.stack([s_ for s_, _ in ys]), f"{k}.indexes": np.stack([i for _, i in ys]),
+                    f"{k}.z_symbols": np.stack([s_ for s_, _ in zs]), f"{k}.z_indexes": np.stack([i for _, i in zs]),
+                    f"{k}.xhat": xhat.numpy(), f"{k}.y": lat["y"].numpy(), f"{k}.w": lat["w"].numpy(), f"{k}.z": lat["z"].numpy(),
+                    f"{k}.xfwd_minus_xhat_max": np.float64((xfwd - xhat[..., :xfwd.shape[-2], :xfwd.shape[-1]]).abs().max()),
+                    f"{k}.xfwd_shape": np.array(xfwd.shape),
+                    f"{k}.metric_names": np.array(list(met)), f"{k}.metric_values": np.array(list(met.values()), np.float64),
+                    f"{k}.cfg": np.array([N, M, B, H, W])})
+        print(f"  {k}: {len(data)} bytes (z = mean of two edges), mse {met.get('mse', float('nan')):.4f}, z std {float(lat['z'].std()):.2f}, "
+              f"prior_entropy {met.get('prior_entropy', float('nan')):.2f}")
+        finish(k, codec, touched, seed, 840 + ci, calib)
+        keys.remove(k)          # (its own list: the oracle-driven tests walk `keys`)
+        agg_keys.append(k)
+    out["agg_keys"] = np.array(agg_keys)
+
     # ---- BaSIC slimmable graph
     codec, ec, levels, ctl, touched, calib, Wd, M = _basic_graph()
     log = []

@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 KNOWN_TIES = {}   # record prefix -> description of the flipped element; empty = every stream is byte-identical
 
 
-@pytest.mark.parametrize("k", ["t0", "t1", "t2", "b0", "h0", "h1", "h2"])
+@pytest.mark.parametrize("k", ["t0", "t1", "t2", "b0", "h0", "h1", "h2", "g0"])   # g0: two inference edges into z, averaged (multi-edge aggregation)
 def test_codec_bytes_latents_reconstruction_vs_reference(k):
     z = cc.load()
     codec, _ = cc.build_codec(z, k)

@@ -238,7 +238,7 @@ def test_codec_state_dict_contract_matches_reference():
     topo-group graph and the BaSIC slimmable graph; the recipe's checksum proves the same tensors got the same values."""
     import codec_cases as cc
     z = cc.load()
-    for k in (str(s) for s in z["keys"]):
+    for k in [str(s) for s in z["keys"]] + [str(s) for s in z["agg_keys"]]:   # agg_keys: the multi-edge aggregation graph
         codec, touched = cc.build_codec(z, k)
         ours = {n: ",".join(str(d) for d in v.shape) for n, v in codec.state_dict().items()}
         ref = dict(zip((str(s) for s in z[f"{k}.sd_keys"]), (str(s) for s in z[f"{k}.sd_shapes"])))
