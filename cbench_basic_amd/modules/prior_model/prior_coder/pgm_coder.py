@@ -456,7 +456,7 @@ class GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(HotPathModule):
         if t.dim() != 4:
             raise ValueError("pgm must be [1, G_c (* L), h, w]")
         if t.shape[0] != 1:
-            raise NotImplementedError("per-sample topo groups")
+            raise ValueError("_topo_from_pgm takes ONE map; a batch-sized pgm (per-sample topo groups) is split by _plans_for()")
         if torch.is_floating_point(t):
             if t.shape[1] % G:
                 raise ValueError("logits channels must be a multiple of channel_groups")
@@ -496,6 +496,19 @@ class GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(HotPathModule):
         if ident is not None:
             self._plans[ident] = self._plans[key]
         return self._plans[key]
+
+    def _plans_for(self, h, w, pgm, batch):
+        """Per-sample topo groups (pgm_coder.py:1340-1380 keep a pgm's batch dimension; the group masks then differ from image to
+        image, :885-890): the list of the images' plans when ``pgm`` carries the batch's leading dimension and the maps really
+        differ, else the ONE plan of the call.  Images are independent in the AR loop, so each is coded with its own schedule;
+        what the reference fixes is the ORDER of the single stream of a batch -- group-major over all images (data[mask]) --
+        which _encode_impl / _decode_impl keep."""
+        if torch.is_tensor(pgm) and pgm.dim() == 4 and pgm.shape[0] > 1:
+            if pgm.shape[0] != batch:
+                raise ValueError(f"pgm has batch {pgm.shape[0]}, the input {batch}")
+            plans = [self._plan(h, w, pgm[b:b + 1]) for b in range(batch)]
+            return plans[0] if all(pl is plans[0] for pl in plans) else plans
+        return self._plan(h, w, pgm)
 
     # ------------------------------------------------------------------ context model at one group's positions
     def _alloc(self, B, H, W, prior, plan):
@@ -610,7 +623,11 @@ class GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(HotPathModule):
 
     def _run_encode(self, y, prior, pgm=None):
         self._ready()
-        plan = self._plan(y.shape[2], y.shape[3], pgm)
+        plan = self._plans_for(y.shape[2], y.shape[3], pgm, y.shape[0])
+        if isinstance(plan, list):   # per-sample topo groups: every image with its own schedule (symbols in ITS coding order)
+            outs = [self._run_encode(y[b:b + 1].contiguous(), None if prior is None else prior[b:b + 1].contiguous(), pgm[b:b + 1])
+                    for b in range(y.shape[0])]
+            return (torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs]), torch.cat([o[2].clone() for o in outs]), plan)
         sl = self._scanline_plan(plan, prior, y.shape[0], width=y.shape[3])
         if sl is not None:
             sym, idx, ybuf = sl.encode(y, prior, self._scale_table_dev)
@@ -712,7 +729,14 @@ class GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(HotPathModule):
         q = input + (torch.rand_like(input) - 0.5) if noise else torch.round(input)
         if getattr(self, "estimate_rate", False):
             B, C, H, W = input.shape
-            plan = self._plan(H, W, pgm)   # logits are taken at their argmax here too (the coding-mode groups)
+            plan = self._plans_for(H, W, pgm, B)   # logits are taken at their argmax here too (the coding-mode groups)
+            if isinstance(plan, list):   # per-sample topo groups: image by image, the mean of their rates
+                saved, nlls = self.estimate_rate, []
+                for b in range(B):
+                    self._forward_impl(input[b:b + 1], prior=None if prior is None else prior[b:b + 1], pgm=pgm[b:b + 1], **kwargs)
+                    nlls.append(self.get_raw_cache("metric_dict")["prior_entropy"])
+                self.update_cache("metric_dict", prior_entropy=torch.stack([torch.as_tensor(v, device=self.device).float() for v in nlls]).mean())
+                return q
             ws = self._alloc(B, H, W, prior, plan)
             ws["ybuf"] = q
             allpos = torch.arange(B * H * W, device=self.device, dtype=torch.int32)
@@ -732,14 +756,24 @@ class GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(HotPathModule):
         prior = self._check_prior(input.shape, prior)
         B = input.shape[0]
         sym, idx, _, plan = self._run_encode(input, prior, pgm)
-        n = plan.per_image
+        plans = plan if isinstance(plan, list) else None
+        n = (plans[0] if plans else plan).per_image
         if self._per_image(B):
             host, off = self._tables.encode_batch_end(self._tables.encode_batch_begin(sym.reshape(-1), idx.reshape(-1), n))
             lens = (np.diff(off) * 4).astype("<u4")
             body = b"".join([struct.pack("<I", B), lens.tobytes(), memoryview(host[: int(off[-1])])])   # one copy of the words
         else:
             # reference order for a batch: group-major over ALL images (data[mask] spans the batch, :898-900)
-            if B > 1:
+            if plans:   # per-sample groups: group g of image 0, of image 1, ...; then group g + 1 (images with fewer groups drop out)
+                parts_s, parts_i = [], []
+                for g in range(max(len(pl.groups) for pl in plans)):
+                    for b, pl in enumerate(plans):
+                        if g < len(pl.groups):
+                            grp = pl.groups[g]
+                            parts_s.append(sym[b, grp["base"]: grp["base"] + grp["n"]])
+                            parts_i.append(idx[b, grp["base"]: grp["base"] + grp["n"]])
+                sym, idx = torch.cat(parts_s), torch.cat(parts_i)
+            elif B > 1:
                 parts_s, parts_i = [], []
                 for grp in plan.groups:
                     parts_s.append(sym[:, grp["base"]: grp["base"] + grp["n"]].reshape(-1))
@@ -767,7 +801,9 @@ class GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(HotPathModule):
         H, W = spatial
         prior = self._check_prior((B, self.in_channels, H, W), prior)
         body = byte_string[ptr:]
-        plan = self._plan(H, W, pgm)
+        plan = self._plans_for(H, W, pgm, B)
+        if isinstance(plan, list):
+            return self._decode_per_sample(body, prior, B, H, W, plan)
         n, C = plan.per_image, self.in_channels
         per_image = self._per_image(B)
         if per_image:
@@ -829,6 +865,67 @@ class GaussianChannelGroupMaskConv2DTopoGroupPGMPriorCoder(HotPathModule):
             sp.copy_(prior)
         graph.replay()
         return out.clone()
+
+    def _decode_per_sample(self, body, prior, B, H, W, plans):
+        """Decoding with per-sample topo groups.  One stream per image: every image decodes alone with its own schedule.  ONE stream
+        for the batch (the reference's layout, data[mask] over all images): the images advance in lock step, group by group --
+        parameters and table rows of group g for every image that has one, their symbols off the shared stream, then scatter."""
+        dev, C = self.device, self.in_channels
+        n = plans[0].per_image
+        if self._per_image(B):
+            (nb,) = struct.unpack("<I", body[:4])
+            assert nb == B
+            lens = np.frombuffer(body, dtype="<u4", count=B, offset=4).astype(np.int64)
+            off = 4 + 4 * B + np.concatenate([[0], np.cumsum(lens)])
+            outs = []
+            for b in range(B):
+                one = bytes(body[int(off[b]): int(off[b + 1])])
+                if len(one) < 8 or len(one) % 4:
+                    raise ValueError("rANS stream must hold >= 2 whole 32-bit words")
+                outs.append(self._decode_single_stream(one, None if prior is None else prior[b:b + 1].contiguous(), 1, H, W, plans[b]).clone())
+            return torch.cat(outs)
+        if len(body) < 8 or len(body) % 4:
+            raise ValueError("rANS stream must hold >= 2 whole 32-bit words")
+        words = torch.from_numpy(np.frombuffer(bytes(body), dtype=np.int32).copy()).to(dev)
+        woff = torch.tensor([0, len(body) // 4], device=dev, dtype=torch.int64)
+        state = torch.zeros((1,), device=dev, dtype=torch.int64)
+        pos = torch.full((1,), -1, device=dev, dtype=torch.int64)
+        pri = [None if prior is None else prior[b:b + 1].contiguous() for b in range(B)]
+        wss = [self._alloc(1, H, W, pri[b], plans[b]) for b in range(B)]
+        sym = torch.empty((B, n), device=dev, dtype=torch.int32)
+        idx = torch.empty((B, n), device=dev, dtype=torch.int32)
+        L = _lib.lib()
+        for g in range(max(len(pl.groups) for pl in plans)):
+            live, params = [], {}
+            for b, pl in enumerate(plans):
+                if g < len(pl.groups) and pl.groups[g]["n"] > 0:
+                    grp = pl.groups[g]
+                    params[b] = self._context(wss[b], pl, g, 1, pri[b])
+                    _lib.check(L.basic_pgm_gauss_index_group_dev(params[b].data_ptr(), 1, C, H * W, grp["elems"].data_ptr(), grp["n"],
+                                                                self._scale_table_dev.data_ptr(), self._scale_table_dev.numel(),
+                                                                idx[b:b + 1].data_ptr(), n, grp["base"], K._stream()))
+                    live.append(b)
+            if not live:
+                continue
+            gi = torch.cat([idx[b, plans[b].groups[g]["base"]: plans[b].groups[g]["base"] + plans[b].groups[g]["n"]] for b in live]).contiguous()
+            go = torch.empty_like(gi)
+            seg = torch.tensor([0, gi.numel()], device=dev, dtype=torch.int64)
+            self._tables.decode_batch(words, woff, gi, seg, out=go, state=state, pos=pos)
+            at = 0
+            for b in live:
+                grp = plans[b].groups[g]
+                sym[b, grp["base"]: grp["base"] + grp["n"]] = go[at: at + grp["n"]]
+                at += grp["n"]
+                _lib.check(L.basic_pgm_gauss_scatter_group_dev(sym[b:b + 1].data_ptr(), params[b].data_ptr(), 1, C, H * W, grp["elems"].data_ptr(), grp["n"],
+                                                              n, grp["base"], wss[b]["ybuf"].data_ptr(), K._stream()))
+        return torch.cat([ws["ybuf"] for ws in wss])
+
+    def _decode_single_stream(self, stream, prior, B, H, W, plan):
+        """One stream (bytes) of a whole call coded with ``plan`` -> the coded latent; the eager per-group loop."""
+        dev = self.device
+        words = torch.from_numpy(np.frombuffer(stream, dtype=np.int32).copy()).to(dev)
+        woff = torch.tensor([0, len(stream) // 4], device=dev, dtype=torch.int64)
+        return self._run_decode_impl(words, woff, prior, B, H, W, False, plan)
 
     def _run_decode_impl(self, d_words, d_woff, prior, B, H, W, per_image, plan):
         dev, C = self.device, self.in_channels

@@ -89,11 +89,12 @@ def masked_conv(x, weight, bias, topo, allow_same=False, channel_group_mask=None
     xu = F.unfold(x, (k, k), padding=pad).unsqueeze(1)
     tg = topo.type_as(x)
     off = tg - tg.max().ceil() - 1
-    centre = off.reshape(1, tg.shape[1], 1, -1)
+    centre = off.reshape(tg.shape[0], tg.shape[1], 1, -1)
     unf = F.unfold(off, (k, k), padding=pad).unsqueeze(1)
     m = (unf <= centre) if allow_same else (unf < centre)
     Gi = tg.shape[1]
-    m = m.reshape(1, Gi, Gi, k * k, -1).repeat(1, 1, 1, Cin // Gi, 1).reshape(1, Gi, Cin * k * k, -1)
+    Bt = tg.shape[0]   # topo groups per sample (masked_conv.py:119,171-173) or one map for the batch
+    m = m.reshape(Bt, Gi, Gi, k * k, -1).repeat(1, 1, 1, Cin // Gi, 1).reshape(Bt, Gi, Cin * k * k, -1)
     if channel_group_mask is not None:
         m = m[:, channel_group_mask]
     Go = m.shape[1]
@@ -131,11 +132,11 @@ def topo_from_pgm(pgm, G, h, w):
     t = torch.as_tensor(pgm)
     if torch.is_floating_point(t):
         t = t.reshape(t.shape[0], G, t.shape[1] // G, *t.shape[2:]).movedim(2, -1).argmax(-1)
-    assert t.shape[0] == 1 and t.shape[1] == G
+    assert t.shape[1] == G   # t.shape[0]: 1, or the batch size (per-sample topo groups)
     t = t[:, :, :h, :w].long()
     ph, pw = t.shape[2:]
     if ph < h or pw < w:
-        cols = t.reshape(1, -1, 1).repeat(1, 1, (h // ph) * (w // pw)).float()
+        cols = t.reshape(t.shape[0], -1, 1).repeat(1, 1, (h // ph) * (w // pw)).float()
         t = F.fold(cols, (h, w), (ph, pw), stride=(ph, pw)).long()
     return t
 

@@ -388,6 +388,14 @@ def ar_coder_pgm():
         (16, 2, False, (2, 4, 4), None, torch.randn(1, 2 * 3, 2, 2, generator=g)),                # predictor cache, B=2
         (16, 4, False, (1, 4, 8), None, torch.randint(0, 8, (1, 4, 2, 2), generator=g)),          # integer predictor cache
     ]
+    # per-sample topo groups: a pgm with the BATCH's leading dimension (pgm_coder.py:1340-1380 keep it; the masks of a group then
+    # differ from image to image, :885-890, and the masked convolutions take per-sample maps, masked_conv.py:119-173) -- full-size
+    # integer maps, and logits patches that are tiled, with a context model.  (Own generator: the draws above stay as they were.)
+    g2 = torch.Generator().manual_seed(78)
+    cases += [
+        (16, 2, False, (2, 4, 6), torch.stack([torch.randint(0, 5, (2, 4, 6), generator=g2), torch.randint(0, 3, (2, 4, 6), generator=g2)]), None),
+        (16, 1, True, (3, 4, 4), torch.randn(3, 1 * 3, 2, 2, generator=g2), None),
+    ]
     out, keys = {}, []
     for i, (C, G, ctxm, (B, H, W), pgm, pred) in enumerate(cases):
         kw = dict(in_channels=C, channel_groups=G)

@@ -131,7 +131,13 @@ def test_supplied_and_learned_topo_groups_vs_reference_golden():
         arg = None if from_pred else pgm.cuda()
         y, prior = torch.from_numpy(z[f"{k}.y"]).cuda(), torch.from_numpy(z[f"{k}.prior"]).cuda()
         sym, idx, ybuf, plan = coder._run_encode(y, prior, arg)
-        if B > 1:
+        if isinstance(plan, list):   # per-sample topo groups (batch-sized pgm): group g of every image, then group g + 1
+            assert len(plan) == B and pgm.shape[0] == B
+            order = [(b, pl.groups[g]) for g in range(max(len(pl.groups) for pl in plan)) for b, pl in enumerate(plan) if g < len(pl.groups)]
+            sym = torch.cat([sym[b, g["base"]: g["base"] + g["n"]] for b, g in order])
+            idx = torch.cat([idx[b, g["base"]: g["base"] + g["n"]] for b, g in order])
+            plan = plan[0]
+        elif B > 1:
             sym = torch.cat([sym[:, g["base"]: g["base"] + g["n"]].reshape(-1) for g in plan.groups])
             idx = torch.cat([idx[:, g["base"]: g["base"] + g["n"]].reshape(-1) for g in plan.groups])
         sym, idx = sym.reshape(-1).cpu().numpy(), idx.reshape(-1).cpu().numpy()
@@ -144,6 +150,16 @@ def test_supplied_and_learned_topo_groups_vs_reference_golden():
         assert torch.equal(yhat.cpu(), ybuf.cpu()), k
         yref = coder.decode(z[f"{k}.bytes"].tobytes(), prior=prior, pgm=arg)
         assert float((yref.cpu() - torch.from_numpy(z[f"{k}.yhat"])).abs().max()) < 1e-3, k
+        if B > 1 and arg is not None and arg.shape[0] == B:   # ... and with one stream per image (this library's batch layout)
+            coder.batch_stream_mode = "per_image"
+            d2 = coder.encode(y, prior=prior, pgm=arg)
+            assert torch.equal(coder.decode(d2, prior=prior, pgm=arg).cpu(), ybuf.cpu()), k
+            for b in range(B):   # image b's stream == its stream when it is coded alone
+                one = coder.encode(y[b:b + 1], prior=prior[b:b + 1], pgm=arg[b:b + 1])
+                lens = np.frombuffer(d2, dtype="<u4", count=B, offset=4)   # body: <I B><B x u32 lengths><streams>
+                start = 4 + 4 * B + int(lens[:b].sum())
+                assert d2[start: start + int(lens[b])] == one[8:], (k, b)   # (the one-image call's own <I 1><u32 length> header)
+            coder.batch_stream_mode = "reference"
 
     sd = pgm_case(z, "comb", 390)
     pred = torch.from_numpy(z["comb.pred"])
