@@ -41,13 +41,22 @@ class LossyDummyEntropyCoder(HotPathModule):
         """latent_graph.py:121-141: distortion metrics of the reconstruction (= prior).  metric_dict gets ``mse`` and
         ``weighted_distortion`` = lambda_rd * (sum of squared errors per image, averaged over the batch) (:83-88,:139)."""
         if isinstance(data, torch.Tensor) and isinstance(prior, torch.Tensor):
-            if self.distortion_type != "mse":
+            if self.distortion_type not in ("mse", "ms-ssim"):
                 raise NotImplementedError(f"distortion_type {self.distortion_type}")
             target = data if prior_target is None else prior_target
             rec = prior
             for dim, size in enumerate(target.shape[2:], 2):  # crop to the target size (:127-129)
                 if rec.shape[dim] != size:
                     rec = rec.narrow(dim, 0, size)
+            if self.distortion_type == "ms-ssim":
+                # :92-96 (the "...-ft-ssim" presets): loss = mean over the batch of (1 - MS-SSIM) x elements per image; the metric
+                # comes from benchmark/ms_ssim.py, a restatement of the absent pytorch_msssim package (parity-unpinned)
+                from ...benchmark.ms_ssim import ms_ssim
+                val = ms_ssim(rec, target, data_range=1.0, size_average=False)
+                loss_distortion = (1 - val).mean() * (target.numel() // target.shape[0])
+                self.update_cache("metric_dict", ms_ssim=val.mean(),
+                                  weighted_distortion=loss_distortion * (self.lambda_rd if lambda_rd is None else lambda_rd))
+                return rec
             from ...nn import kernels as K
             mse = K.mse_per_image(rec.contiguous(), target.contiguous())  # [B], HIP reduction
             loss_distortion = (mse * (target.numel() // target.shape[0])).mean()

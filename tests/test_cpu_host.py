@@ -607,3 +607,30 @@ def test_create_ar_ptrs_matches_reference_binding():
         assert int(z["p.positive_raises"]) == 1
         with pytest.raises(ValueError):
             c.create_ar_ptrs(np.zeros((1, 3, 3), np.int32), [[1, 0]])
+
+
+def test_ms_ssim_restatement_properties():
+    """benchmark/ms_ssim.py restates pytorch_msssim.ms_ssim (absent from /root/reference: parity-unpinned).  What can be checked
+    without it: identity = 1, symmetry, monotone under growing noise, invariance of the per-image values to the batch, the
+    package's size requirement, and the closed form of single-scale SSIM for constant images."""
+    from cbench_basic_amd.benchmark.ms_ssim import _gauss_window, _ssim_terms, ms_ssim
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(2, 3, 176, 192, generator=g)
+    assert torch.allclose(ms_ssim(x, x, size_average=False), torch.ones(2), atol=1e-6)
+    n1, n2 = x + 0.05 * torch.randn(x.shape, generator=g), x + 0.2 * torch.randn(x.shape, generator=g)
+    a, b = ms_ssim(n1, x, size_average=False), ms_ssim(n2, x, size_average=False)
+    assert bool((a > b).all()) and bool((a < 1).all()) and bool((b > 0).all())
+    assert torch.allclose(ms_ssim(n1, x, size_average=False), ms_ssim(x, n1, size_average=False), atol=1e-6)
+    assert torch.allclose(ms_ssim(n1[1:], x[1:], size_average=False), a[1:], atol=1e-6)
+    assert abs(float(ms_ssim(n1, x)) - float(a.mean())) < 1e-7
+    with pytest.raises(ValueError):
+        ms_ssim(x[..., :160, :], x[..., :160, :])
+    # constant images u, v: SSIM = (2uv + C1) / (u^2 + v^2 + C1), contrast-structure term = 1
+    u, v = torch.full((1, 1, 32, 32), 0.3), torch.full((1, 1, 32, 32), 0.5)
+    s, cs = _ssim_terms(u, v, _gauss_window(11, 1.5, u.device, u.dtype), 1.0, (0.01, 0.03))
+    assert abs(float(s) - (2 * 0.15 + 1e-4) / (0.09 + 0.25 + 1e-4)) < 1e-5 and abs(float(cs) - 1.0) < 1e-5
+    # the distortion metric and the dummy coder's "ms-ssim" distortion use it
+    from cbench_basic_amd.benchmark import PytorchBatchedDistortion
+    m = PytorchBatchedDistortion(metrics=["psnr", "ms-ssim"])
+    r = m(n1, x)
+    assert list(r) == ["psnr", "ms-ssim"] and abs(r["ms-ssim"] - float(a.mean())) < 1e-6
