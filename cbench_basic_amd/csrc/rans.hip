@@ -16,6 +16,7 @@
 // symbols and wide rows hide behind one rare-path test.  The generic kernels (AR remap, any table)
 // keep the state update on the scalar unit.
 #include "common.h"
+#include "wave_decoder.h"
 
 #include <algorithm>
 #include <cmath>
@@ -895,24 +896,9 @@ __global__ __launch_bounds__(64) void rans_decode_kernel(TablesDev T, ArDev ar, 
     if (lane == 0) { state[stream] = x; pos_io[stream] = rd.pos; }
 }
 
-// Fast decoder for the common case (no AR remap, search image resident in LDS, rows <= 4096 entries).
-// A single wavefront issues roughly one instruction every 4-5 cycles, so the serial loop is bound by its
-// INSTRUCTION COUNT.  Everything that does not depend on the coder state is therefore moved out of it:
-//   * the first-level probe of a symbol (rows <= 64 entries: the whole row) depends only on the table row,
-//     so it is read from LDS two symbols ahead with one broadcast + one add + one ds_read;
-//   * offsets are added lane-parallel after the chunk; row size / image offset travel in one packed word;
-//   * stream words are handed out from a 64-word register cache with 32-bit cursors.
-// compile-time loop over J = kBegin, kBegin + 2, ... < kEnd
-template <int kBegin, int kEnd, class F> __device__ __forceinline__ void static_pairs(F &&f)
-{
-    if constexpr (kBegin < kEnd) {
-        f(std::integral_constant<int, kBegin>{});
-        static_pairs<kBegin + 2, kEnd>(f);
-    }
-}
-
-// Per narrow-row symbol the chain is: mask, compare, ballot, two lane broadcasts, 64-bit multiply-add,
-// (rare) renormalisation.
+// Fast decoder for the common case (no AR remap, search image resident in LDS, rows <= 4096 entries): one wavefront per
+// stream runs the serial chain of wave_decoder.h (built for instruction count: a lone wave issues one instruction per ~8.5
+// clocks); table rows of a chunk's 64 symbols are gathered lane-parallel before the chain starts, offsets added after it.
 // WPB wavefronts (= streams) per workgroup share ONE LDS copy of the search image: a batch of streams then occupies
 // nstreams / WPB compute units instead of nstreams, and the units it leaves alone keep running the MFMA transforms of
 // another sub-batch on a second HIP stream (the image, not the wave slot, is what excludes a convolution workgroup).
@@ -955,45 +941,12 @@ __global__ __launch_bounds__(64 * WPB) void rans_decode_fast_kernel(TablesDev T,
     __syncthreads();
     if (!live) return;
 
-    const uint32_t *words = words_all + word_off[stream];
-    const int limit = static_cast<int>(word_off[stream + 1] - word_off[stream]);
-    int pos, wbase;          // next word / first cached word (uniform)
-    uint32_t cache;          // lane k holds word wbase + k
-    uint64_t x;              // coder state, uniform
+    wavedec::WaveDecoder d;
     {
-        const int64_t p0 = pos_io[stream];
-        pos = p0 < 0 ? 2 : static_cast<int>(p0);
-        wbase = pos & ~63;
-        cache = (wbase + lane < limit) ? words[wbase + lane] : 0u;
-        if (p0 < 0) {
-            // the head words may sit in an earlier cache line only when pos >= 64, which cannot happen for pos = 2
-            x = static_cast<uint64_t>(bcast_u32(cache, 0)) | (static_cast<uint64_t>(bcast_u32(cache, 1)) << 32);
-        } else {
-            x = uniform_u64(state[stream]);
-        }
+        const int64_t p0 = pos_io[stream];   // < 0: a fresh stream; otherwise resume behind an earlier call (state[], pos_io[])
+        d.init(img, words_all + word_off[stream], static_cast<int>(word_off[stream + 1] - word_off[stream]), T.precision, T.bypass_precision, T.bypass != 0,
+               p0 < 0 ? -1 : static_cast<int>(p0), p0 < 0 ? 0ull : uniform_u64(state[stream]), lane);
     }
-    const uint32_t prec = static_cast<uint32_t>(T.precision);
-    const uint32_t mask = (1u << prec) - 1u;
-    const uint32_t bprec = static_cast<uint32_t>(T.bypass_precision);
-    const uint32_t maxbv = (1u << bprec) - 1u;
-    const bool bypass = T.bypass != 0;
-
-    auto next_word = [&]() -> uint32_t {
-        if (pos - wbase >= 64) {
-            wbase = pos & ~63;
-            cache = (wbase + lane < limit) ? words[wbase + lane] : 0u;
-        }
-        const uint32_t w = bcast_u32(cache, pos - wbase);
-        ++pos;
-        return w;
-    };
-    auto get_bits = [&](uint32_t nbits) -> uint32_t {  // Rans64DecGetBits, rans64.cpp:49-65
-        const uint32_t v = static_cast<uint32_t>(x) & ((1u << nbits) - 1u);
-        x >>= nbits;
-        if (x < kRansL) x = (x << 32) | next_word();
-        return v;
-    };
-
     for (int c0 = 0; c0 < n; c0 += 64) {
         const int i = c0 + lane;
         uint32_t meta_l = 0;
@@ -1004,119 +957,14 @@ __global__ __launch_bounds__(64 * WPB) void rans_decode_fast_kernel(TablesDev T,
             off_l = T.offsets[row];
             size_l = T.sizes[row];
         }
-        int32_t result = 1;  // holds symbol + 1 (the selecting lane); the -1 is folded into the final store
         const int cnt = (n - c0) < 64 ? (n - c0) : 64;
-
-        // Per symbol, fetched two symbols ahead of its use: lane l's 16-byte image entry of the symbol's row
-        // (one ds_read_b128).  Lane l holds the start and frequency of symbol l - 1 and the search key entry l,
-        // so EVERY lane advances the state for its own symbol (three VALU ops) while one compare + ballot finds
-        // the first lane whose key exceeds the coded value -- the lane that is right.  A lone wave issues one
-        // instruction per ~8-11 cycles whatever it is (scripts/micro/lone_wave_latency.hip), so the common path
-        // is built for instruction count: the only test is "new state < 2^31", which covers renormalisation
-        // and, because their image frequency is 0, the bypass sentinel and wide rows as well.
-        auto fetch = [&](int jj, f32x4u &e) {
-            const uint32_t m = bcast_u32(meta_l, jj);
-            e = *reinterpret_cast<const f32x4u *>(reinterpret_cast<const char *>(img) + m + lane * 16);
-        };
-        auto decode_one = [&](auto jc, const f32x4u &e) {   // jc: int, or std::integral_constant (lane ids become immediates)
-            const int j = jc;
-            int32_t &res = result;  // named outside the if-constexpr below (generic lambda: implicit capture needs an odr-use)
-            const uint32_t cf = static_cast<uint32_t>(x) & mask;
-            const uint64_t t = x >> prec;
-            // x = freq * (x >> prec) + (cf - start)   (rans64.h:128-142), per lane for its own symbol
-            const uint64_t addend = static_cast<uint64_t>(cf - e[1]) |
-                                    (static_cast<uint64_t>(__umul24(e[2], static_cast<uint32_t>(t >> 32))) << 32);  // freq <= 2^16, t_hi < 2^15
-            uint64_t cand;  // = freq * t_lo + addend; spelled out so that the addend's halves are written in place
-            asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(cand) : "v"(e[2]), "s"(static_cast<uint32_t>(t)), "v"(addend) : "vcc");
-            int32_t first = __builtin_ctzll(__ballot(e[0] > cf));  // symbol + 1
-            x = bcast_u64(cand, first);
-            if (__builtin_expect(x < kRansL, 0)) {
-                const int32_t size = bcast_u32(static_cast<uint32_t>(size_l), j);
-                const uint32_t base = bcast_u32(meta_l, j) >> 2;
-                int32_t sym = first - 1;
-                if (size > 64) {
-                    // wide row: 64 block-end probes after the dummy lane, then the row; two-level search
-                    const uint32_t pr = img[base + 4 + lane];
-                    const int blk = __builtin_ctzll(__ballot(pr > cf));
-                    const int32_t step = (size + 63) >> 6;
-                    const int32_t lo = blk * step;
-                    const int32_t span = (lo + step <= size) ? step : (size - lo);
-                    const uint32_t va = (lane < span) ? img[base + 68 + lo + lane] : 0x7FFFFFFFu;
-                    const int tl = __builtin_ctzll(__ballot(va > cf));
-                    const uint32_t c_t = bcast_u32(va, tl);
-                    // entry lo-1 is the last entry of the previous block = that block's probe value
-                    const uint32_t c_s = tl > 0 ? bcast_u32(va, tl - 1) : bcast_u32(pr, blk - 1);
-                    sym = lo + tl - 1;
-                    x = static_cast<uint64_t>(c_t - c_s) * t + (cf - c_s);
-                } else if (bypass && sym == size - 2) {
-                    // the sentinel's image frequency is 0: redo its update with the true one
-                    const uint32_t c_t = bcast_u32(e[0], first), c_s = bcast_u32(e[1], first);
-                    x = static_cast<uint64_t>(c_t - c_s) * t + (cf - c_s);
-                }
-                if (x < kRansL) x = (x << 32) | next_word();
-                if (bypass && sym == size - 2) {
-                    uint32_t v = get_bits(bprec);
-                    uint32_t nb = v;
-                    while (v == maxbv) { v = get_bits(bprec); nb += v; }
-                    uint32_t raw = 0;
-                    for (uint32_t k = 0; k < nb; ++k) {
-                        const uint32_t nib = get_bits(bprec);
-                        if (k * bprec < 32u) raw |= nib << (k * bprec);
-                    }
-                    sym = static_cast<int32_t>(raw >> 1);
-                    if (raw & 1u) sym = -sym - 1; else sym += size - 2;
-                }
-                first = sym + 1;
-            }
-            // result[lane j] = first (one scalar operand per VALU instruction on gfx9: a run-time lane select goes through m0)
-            if constexpr (std::is_integral<decltype(jc)>::value)
-            {   // m0 is saved and restored inside the statement (a reserved register on a clobber list is not honoured reliably)
-                    uint32_t m0_save;
-                    asm volatile("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1"
-                                 : "+v"(res), "=&s"(m0_save) : "s"(first), "s"(j));
-                }
-            else
-                asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(res) : "s"(first), "n"(decltype(jc)::value));
-        };
-
-        f32x4u ea, eb;
-        fetch(0, ea);
-        fetch(cnt > 1 ? 1 : 0, eb);
-        if (cnt == 64) {
-            // a full chunk, fully unrolled: every lane id (row-entry prefetch, result lane) is an immediate -- two scalar
-            // instructions fewer per symbol than the run-time loop below
-            static_pairs<0, 64>([&](auto jc) {
-                constexpr int J = decltype(jc)::value;
-                decode_one(std::integral_constant<int, J>{}, ea);
-                if constexpr (J + 2 < 64) fetch(J + 2, ea);
-                decode_one(std::integral_constant<int, J + 1>{}, eb);
-                if constexpr (J + 3 < 64) fetch(J + 3, eb);
-            });
-            if (i < n) out[i] = result - 1 + off_l;
-            continue;
-        }
-        int j = 0;
-        for (; j + 17 < cnt; j += 16) {  // sixteen symbols per loop trip, no clamping of the prefetch index in here
-#pragma unroll
-            for (int u = 0; u < 16; u += 2) {
-                decode_one(j + u, ea);
-                fetch(j + u + 2, ea);  // two symbols ahead
-                decode_one(j + u + 1, eb);
-                fetch(j + u + 3, eb);
-            }
-        }
-        for (; j + 1 < cnt; j += 2) {
-            decode_one(j, ea);
-            fetch(j + 2 < cnt ? j + 2 : cnt - 1, ea);
-            decode_one(j + 1, eb);
-            fetch(j + 3 < cnt ? j + 3 : cnt - 1, eb);
-        }
-        if (j < cnt) decode_one(j, ea);
+        d.line_up(lane);
+        const int32_t result = d.decode_chunk(meta_l, size_l, cnt, lane);   // symbol + 1 on the symbol's lane
         if (i < n) out[i] = result - 1 + off_l;
     }
     if (lane == 0) {
-        state[stream] = x;
-        pos_io[stream] = pos;
+        state[stream] = d.x;
+        pos_io[stream] = d.position();
     }
 }
 

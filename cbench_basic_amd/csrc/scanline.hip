@@ -36,6 +36,7 @@
 // spinning): a launch whose grid is not fully resident gives up and reports it instead of hanging.  One workgroup per compute
 // unit (the LDS footprint guarantees it), as MI355X_MICROARCH.md's inter-workgroup visibility section requires of spin-waits.
 #include "common.h"
+#include "wave_decoder.h"
 
 #include <algorithm>
 #include <mutex>
@@ -53,7 +54,6 @@ constexpr int kThreads = 256;
 constexpr int kMaxLayers = 5;   // context convolution + up to four dense layers
 constexpr int kMaxTaps = 24;    // causal taps of a k x k window: (k/2) * k + k/2  (k = 7 -> 24)
 constexpr unsigned kSpinLimit = 4000000u;
-constexpr uint64_t kRansLow = 1ull << 31;   // RANS64_L
 
 struct ScanArgs {
     const float *y;       // [B][C][HW]   (encoder input)
@@ -267,145 +267,8 @@ __device__ __forceinline__ float block_dot(const float *wr, const float *xr, int
 //      all hide behind the single test "new state < 2^31")
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-template <int kBegin, int kEnd, class F> __device__ __forceinline__ void static_pairs(F &&f)
-{
-    if constexpr (kBegin < kEnd) {
-        f(std::integral_constant<int, kBegin>{});
-        static_pairs<kBegin + 2, kEnd>(f);
-    }
-}
-
-struct WaveDecoder {
-    const uint32_t *img;     // LDS
-    const uint32_t *words;
-    int limit, pos, wbase;
-    uint32_t cache;
-    uint64_t x;
-    uint32_t prec, mask, bprec, maxbv;
-    bool bypass;
-    __device__ __forceinline__ uint32_t bc32(uint32_t v, int l) const { return __builtin_amdgcn_readlane(v, l); }
-    __device__ __forceinline__ uint64_t bc64(uint64_t v, int l) const
-    {
-        return static_cast<uint64_t>(bc32(static_cast<uint32_t>(v), l)) | (static_cast<uint64_t>(bc32(static_cast<uint32_t>(v >> 32), l)) << 32);
-    }
-    __device__ __forceinline__ void init(const RansFastView &tv, const uint32_t *image_lds, const uint32_t *w, int nwords, int lane)
-    {
-        img = image_lds; words = w; limit = nwords;
-        prec = static_cast<uint32_t>(tv.precision); mask = (1u << prec) - 1u;
-        bprec = static_cast<uint32_t>(tv.bypass_precision); maxbv = (1u << bprec) - 1u; bypass = tv.bypass != 0;
-        pos = 2; wbase = 0;
-        cache = (lane < limit) ? words[lane] : 0u;
-        x = static_cast<uint64_t>(bc32(cache, 0)) | (static_cast<uint64_t>(bc32(cache, 1)) << 32);
-    }
-    __device__ __forceinline__ uint32_t next_word(int lane)
-    {
-        if (pos - wbase >= 64) {
-            wbase = pos & ~63;
-            cache = (wbase + lane < limit) ? words[wbase + lane] : 0u;
-        }
-        const uint32_t w = bc32(cache, pos - wbase);
-        ++pos;
-        return w;
-    }
-    __device__ __forceinline__ uint32_t get_bits(uint32_t nbits, int lane)   // Rans64DecGetBits, rans64.cpp:49-65
-    {
-        const uint32_t v = static_cast<uint32_t>(x) & ((1u << nbits) - 1u);
-        x >>= nbits;
-        if (x < kRansLow) x = (x << 32) | next_word(lane);
-        return v;
-    }
-    // the rare path of a symbol whose candidate state came out below 2^31: renormalisation, bypass sentinel, wide row.
-    // `first` = narrow-row symbol + 1 found by the ballot; returns the symbol + 1
-    __device__ __forceinline__ int32_t slow_path(const u32x4 &e, int32_t first, uint32_t meta, int32_t size, uint32_t cf, uint64_t t, int lane)
-    {
-        const uint32_t base = meta >> 2;
-        int32_t sym = first - 1;
-        if (size > 64) {   // wide row: 64 block-end probes after the dummy lane, then the row; two-level search
-            const uint32_t pr = img[base + 4 + lane];
-            const int blk = __builtin_ctzll(__ballot(pr > cf));
-            const int32_t step = (size + 63) >> 6;
-            const int32_t lo = blk * step;
-            const int32_t span = (lo + step <= size) ? step : (size - lo);
-            const uint32_t va = (lane < span) ? img[base + 68 + lo + lane] : 0x7FFFFFFFu;
-            const int tl = __builtin_ctzll(__ballot(va > cf));
-            const uint32_t c_t = bc32(va, tl);
-            const uint32_t c_s = tl > 0 ? bc32(va, tl - 1) : bc32(pr, blk - 1);   // blk, tl == 0 together never happens: cdf[0] = 0 <= cf
-            sym = lo + tl - 1;
-            x = static_cast<uint64_t>(c_t - c_s) * t + (cf - c_s);
-        } else if (bypass && sym == size - 2) {   // the sentinel's image frequency is 0: redo its update with the true one
-            const uint32_t c_t = bc32(e[0], first), c_s = bc32(e[1], first);
-            x = static_cast<uint64_t>(c_t - c_s) * t + (cf - c_s);
-        }
-        if (x < kRansLow) x = (x << 32) | next_word(lane);
-        if (bypass && sym == size - 2) {   // bypass value: count nibbles, then the payload low-first (rans64.cpp:466-487)
-            uint32_t v = get_bits(bprec, lane);
-            uint32_t nb = v;
-            while (v == maxbv) { v = get_bits(bprec, lane); nb += v; }
-            uint32_t raw = 0;
-            for (uint32_t k = 0; k < nb; ++k) {
-                const uint32_t nib = get_bits(bprec, lane);
-                if (k * bprec < 32u) raw |= nib << (k * bprec);
-            }
-            sym = static_cast<int32_t>(raw >> 1);
-            if (raw & 1u) sym = -sym - 1; else sym += size - 2;
-        }
-        return sym + 1;
-    }
-    // `cnt` symbols (1..64); lane j holds symbol j's image offset (meta, bytes) and row size.  Returns symbol j + 1 on lane j.
-    __device__ __forceinline__ int32_t decode_chunk(uint32_t meta_l, int32_t size_l, int cnt, int lane)
-    {
-        int32_t result = 1;
-        auto fetch = [&](int jj, u32x4 &e) {
-            const uint32_t m = bc32(meta_l, jj);
-            e = *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(img) + m + lane * 16);
-        };
-        auto decode_one = [&](auto jc, const u32x4 &e) {   // jc: int, or std::integral_constant (lane ids become immediates)
-            const int j = jc;
-            int32_t &res = result;
-            const uint32_t cf = static_cast<uint32_t>(x) & mask;
-            const uint64_t t = x >> prec;
-            // x = freq * (x >> prec) + (cf - start)   (rans64.h:128-142), per lane for its own candidate
-            const uint64_t addend = static_cast<uint64_t>(cf - e[1]) |
-                                    (static_cast<uint64_t>(__umul24(e[2], static_cast<uint32_t>(t >> 32))) << 32);   // freq <= 2^16, t_hi < 2^15
-            uint64_t cand;
-            asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(cand) : "v"(e[2]), "s"(static_cast<uint32_t>(t)), "v"(addend) : "vcc");
-            int32_t first = __builtin_ctzll(__ballot(e[0] > cf));   // symbol + 1
-            x = bc64(cand, first);
-            if (__builtin_expect(x < kRansLow, 0))
-                first = slow_path(e, first, bc32(meta_l, j), static_cast<int32_t>(bc32(static_cast<uint32_t>(size_l), j)), cf, t, lane);
-            if constexpr (std::is_integral<decltype(jc)>::value)
-            {   // m0 is saved and restored inside the statement (a reserved register on a clobber list is not honoured reliably)
-                    uint32_t m0_save;
-                    asm volatile("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1"
-                                 : "+v"(res), "=&s"(m0_save) : "s"(first), "s"(j));
-                }
-            else
-                asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(res) : "s"(first), "n"(decltype(jc)::value));
-        };
-        u32x4 ea, eb;
-        fetch(0, ea);
-        fetch(cnt > 1 ? 1 : 0, eb);
-        if (cnt == 64) {   // a full chunk, fully unrolled: every lane id is an immediate
-            static_pairs<0, 64>([&](auto jc) {
-                constexpr int J = decltype(jc)::value;
-                decode_one(std::integral_constant<int, J>{}, ea);
-                if constexpr (J + 2 < 64) fetch(J + 2, ea);
-                decode_one(std::integral_constant<int, J + 1>{}, eb);
-                if constexpr (J + 3 < 64) fetch(J + 3, eb);
-            });
-            return result;
-        }
-        int j = 0;
-        for (; j + 1 < cnt; j += 2) {
-            decode_one(j, ea);
-            fetch(j + 2 < cnt ? j + 2 : cnt - 1, ea);
-            decode_one(j + 1, eb);
-            fetch(j + 3 < cnt ? j + 3 : cnt - 1, eb);
-        }
-        if (j < cnt) decode_one(j, ea);
-        return result;
-    }
-};
+using wavedec::static_pairs;
+using wavedec::WaveDecoder;   // the serial rANS chain of one stream (wave_decoder.h)
 
 // ================= decoder workgroups: one wavefront per image stream, the search image in LDS =================
 __device__ __forceinline__ void decoder_workgroup(const ScanArgs &a, float *lds)
@@ -426,7 +289,7 @@ __device__ __forceinline__ void decoder_workgroup(const ScanArgs &a, float *lds)
     WaveDecoder d;
     {
         const int64_t w0 = a.word_off[b];
-        d.init(a.tv, img, a.words + w0, static_cast<int>(a.word_off[b + 1] - w0), lane);
+        d.init(img, a.words + w0, static_cast<int>(a.word_off[b + 1] - w0), a.tv.precision, a.tv.bypass_precision, a.tv.bypass != 0, -1, 0ull, lane);
     }
     const uint64_t *pi0 = a.idx_step + static_cast<int64_t>(b) * a.C, *pm0 = a.mu + static_cast<int64_t>(b) * a.C;
     for (int p = 0; p < HW; ++p) {
@@ -438,6 +301,7 @@ __device__ __forceinline__ void decoder_workgroup(const ScanArgs &a, float *lds)
         for (int c0 = 0; c0 < a.C; c0 += 64) {
             const int c = c0 + lane;
             bool ok = true;
+            d.line_up(lane);   // the chunk's 64 stream words, cut while the step's parameters are still on their way
             const long long tw0 = a.prof ? wall_clock64() : 0;
             if (c < a.C) ok = wait_gran(a, pi0 + c, tag, gi) && wait_gran(a, pm0 + c, tag, gm);
             if (__ballot(!ok) != 0ull) return;   // poisoned launch: wave-uniform exit
@@ -449,7 +313,9 @@ __device__ __forceinline__ void decoder_workgroup(const ScanArgs &a, float *lds)
             row = row < 0 ? 0 : (row >= a.tv.rows ? a.tv.rows - 1 : row);
             const u32x4 rt = rowtab[row];
             const int cnt = (a.C - c0) < 64 ? (a.C - c0) : 64;
+            const long long tc2 = a.prof ? clock64() : 0;
             const int32_t mine = d.decode_chunk(rt[0], static_cast<int32_t>(rt[1]), cnt, lane) - 1;
+            const long long tc3 = a.prof ? clock64() : 0;
             if (c < a.C) {
                 const int32_t value = mine + static_cast<int32_t>(rt[2]);
                 const float v = static_cast<float>(value) + mu;           // pgm_coder.py:973-978
@@ -461,6 +327,9 @@ __device__ __forceinline__ void decoder_workgroup(const ScanArgs &a, float *lds)
             if (a.prof && b == 0 && lane == 0) {   // first stream: ticks waiting for the step's parameters / decoding and publishing
                 a.prof[4 * kMaxLayers + 2] += tw1 - tw0;
                 a.prof[4 * kMaxLayers + 3] += wall_clock64() - tw1;
+                a.prof[4 * kMaxLayers + 4] += tc3 - tc2;            // shader clocks inside decode_chunk
+                a.prof[4 * kMaxLayers + 5] += clock64() - tc3;      // ... publishing
+                a.prof[4 * kMaxLayers + 6] = d.position();
             }
         }
     }
@@ -1987,7 +1856,7 @@ int fill_args_batched(basic_scanline_plan *p, ScanArgs &a, int batch, int h, int
 
 // BASIC_SCAN_PROFILE=1 (debugging aid): where does workgroup 0 spend a coding step?  Synchronises the stream.
 struct ScanProfile {
-    static constexpr int kSlots = 4 * kMaxLayers + 4;
+    static constexpr int kSlots = 4 * kMaxLayers + 8;
     long long *d = nullptr;
     int begin(ScanArgs &a, hipStream_t st)
     {
@@ -2013,7 +1882,9 @@ struct ScanProfile {
                 fprintf(stderr, "dense L%d: prior blocks + wait %.1f, loads + chains %.1f, barrier + finish %.1f | ", l, h[4 * l] / steps, h[4 * l + 1] / steps, h[4 * l + 2] / steps);
             fprintf(stderr, "loop %.1f ticks per step, %.2f shader clocks per tick", h[4 * kMaxLayers + 1] / steps,
                     h[4 * kMaxLayers + 1] ? static_cast<double>(h[4 * kMaxLayers]) / h[4 * kMaxLayers + 1] : 0.0);
-            if (h[4 * kMaxLayers + 3]) fprintf(stderr, " | decoder wave of stream 0: waiting %.1f, decoding %.1f", h[4 * kMaxLayers + 2] / steps, h[4 * kMaxLayers + 3] / steps);
+            if (h[4 * kMaxLayers + 3])
+                fprintf(stderr, " | decoder wave of stream 0: waiting %.1f, decoding %.1f (shader clocks per step: decode_chunk %.0f, publishing %.0f; stream words per step %.1f)", h[4 * kMaxLayers + 2] / steps,
+                        h[4 * kMaxLayers + 3] / steps, h[4 * kMaxLayers + 4] / steps, h[4 * kMaxLayers + 5] / steps, h[4 * kMaxLayers + 6] / steps);
             fprintf(stderr, "\n");
             return;
         }
@@ -2022,7 +1893,9 @@ struct ScanProfile {
             fprintf(stderr, "L%d %.1f / %.1f / %.1f / %.1f | ", l, h[4 * l] / steps, h[4 * l + 1] / steps, h[4 * l + 2] / steps, h[4 * l + 3] / steps);
         fprintf(stderr, "loop %.1f ticks per step, %.2f shader clocks per tick", h[4 * kMaxLayers + 1] / steps,
                 h[4 * kMaxLayers + 1] ? static_cast<double>(h[4 * kMaxLayers]) / h[4 * kMaxLayers + 1] : 0.0);
-        if (h[4 * kMaxLayers + 3]) fprintf(stderr, " | decoder wave of stream 0: waiting %.1f, decoding %.1f", h[4 * kMaxLayers + 2] / steps, h[4 * kMaxLayers + 3] / steps);
+        if (h[4 * kMaxLayers + 3])
+            fprintf(stderr, " | decoder wave of stream 0: waiting %.1f, decoding %.1f (shader clocks per step: decode_chunk %.0f, publishing %.0f; stream words per step %.1f)", h[4 * kMaxLayers + 2] / steps,
+                    h[4 * kMaxLayers + 3] / steps, h[4 * kMaxLayers + 4] / steps, h[4 * kMaxLayers + 5] / steps, h[4 * kMaxLayers + 6] / steps);
         fprintf(stderr, "\n");
     }
 };

@@ -14,7 +14,12 @@ with torch.no_grad():
 codec = codec.cuda()
 codec.update_state()
 codec.set_complex_level(0)
-x = torch.stack([image(i, 256) for i in range(int(os.environ.get("B", "64")))]).cuda()
+if os.environ.get("SIZE"):   # one Kodak-shaped image
+    hh, ww = (int(v) for v in os.environ["SIZE"].split("x"))
+    torch.manual_seed(0)
+    x = torch.rand(int(os.environ.get("B", "1")), 3, hh, ww).cuda()
+else:
+    x = torch.stack([image(i, 256) for i in range(int(os.environ.get("B", "64")))]).cuda()
 for _ in range(2):
     data = codec.compress(x)
     codec.decompress(data)
