@@ -292,6 +292,11 @@ __device__ __forceinline__ void decoder_workgroup(const ScanArgs &a, float *lds)
         d.init(img, a.words + w0, static_cast<int>(a.word_off[b + 1] - w0), a.tv.precision, a.tv.bypass_precision, a.tv.bypass != 0, -1, 0ull, lane);
     }
     const uint64_t *pi0 = a.idx_step + static_cast<int64_t>(b) * a.C, *pm0 = a.mu + static_cast<int64_t>(b) * a.C;
+    // where a chunk's results go: a uniform pointer per (step, chunk) + a lane term that never changes (channel c0 + lane; the
+    // batched exchange layout is linear in c0: bm_gran(c0 + l) = bm_gran(l) + c0 * nbt for chunk starts c0)
+    const int64_t bC = static_cast<int64_t>(b) * a.C;
+    const uint32_t lane_g = a.nbt ? static_cast<uint32_t>(bm_gran(lane, b, a.nbt)) : static_cast<uint32_t>(lane);
+    const uint32_t lane_y = static_cast<uint32_t>(lane) * static_cast<uint32_t>(HW);
     for (int p = 0; p < HW; ++p) {
         const uint32_t tag = static_cast<uint32_t>(p + 1);
         // this step's (table row, mean) granules come from the compute workgroups that own the channels; the next chunk's
@@ -319,10 +324,12 @@ __device__ __forceinline__ void decoder_workgroup(const ScanArgs &a, float *lds)
             if (c < a.C) {
                 const int32_t value = mine + static_cast<int32_t>(rt[2]);
                 const float v = static_cast<float>(value) + mu;           // pgm_coder.py:973-978
-                st_gran(a.yT + (a.nbt ? static_cast<int64_t>(p) * a.C * a.nbt + bm_gran(c, b, a.nbt) : (static_cast<int64_t>(b) * HW + p) * a.C + c), v, tag);   // first: the compute workgroups wait for it
-                a.sym[static_cast<int64_t>(b) * a.C * HW + static_cast<int64_t>(p) * a.C + c] = value;
-                a.idx[static_cast<int64_t>(b) * a.C * HW + static_cast<int64_t>(p) * a.C + c] = row;
-                a.ybuf[(static_cast<int64_t>(b) * a.C + c) * HW + p] = v;
+                const int64_t at = bC * HW + static_cast<int64_t>(p) * a.C + c0;   // [b][p][c0] of sym / idx
+                uint64_t *yt = a.yT + (a.nbt ? (static_cast<int64_t>(p) * a.C + c0) * a.nbt : (static_cast<int64_t>(b) * HW + p) * a.C + c0);
+                st_gran(yt + lane_g, v, tag);   // first: the compute workgroups wait for it
+                (a.sym + at)[lane] = value;
+                (a.idx + at)[lane] = row;
+                (a.ybuf + ((bC + c0) * HW + p))[lane_y] = v;
             }
             if (a.prof && b == 0 && lane == 0) {   // first stream: ticks waiting for the step's parameters / decoding and publishing
                 a.prof[4 * kMaxLayers + 2] += tw1 - tw0;

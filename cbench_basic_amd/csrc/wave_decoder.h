@@ -32,6 +32,84 @@ template <int kBegin, int kEnd, class F> __device__ __forceinline__ void static_
     }
 }
 
+
+// ---- the common path of one symbol at precision 16, spelled out (see WaveDecoder::decode_chunk) ----
+// Registers are named literally so that halves of pairs and single entries of a 16-byte row can be addressed: the state
+// lives in s[52:53], x >> 16 of the previous state in s[54:55], the ballot's lane in s57; four row buffers v[10:13] ..
+// v[22:25] in rotation (symbol J reads buffer J & 3 and fetches symbol J + 3's row into the buffer symbol J - 1 is done
+// with); v26-v28, s56 are scratch.  13 instructions (12 for odd J: one LDS wait covers two symbols) + the compiler's
+// scalar compare and branch on the new state's high word:
+//   x >> 16; candidate = freq * (x >> 16) + (x & 0xffff) - start on every lane (the low 16 bits come straight from the state
+//   register: src0_sel:WORD_0); compare + ballot; the row address of symbol J + 3; two broadcasts; the row fetch; the
+//   provisional result into lane J.
+#ifndef WD_NO_SDWA
+#define WD_STEP_HEAD(WAIT, KEY, START, FREQ)                                                                              \
+    WAIT                                                                                                                  \
+    "s_lshr_b64 s[54:55], s[52:53], 16\n\t"                                                                               \
+    "v_sub_u32_sdwa v26, s52, " START " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD\n\t"           \
+    "v_mul_u32_u24 v27, s55, " FREQ "\n\t"                                                                                \
+    "v_mad_u64_u32 v[26:27], vcc, " FREQ ", s54, v[26:27]\n\t"                                                            \
+    "v_cmp_lt_u32_sdwa vcc, s52, " KEY " src0_sel:WORD_0 src1_sel:DWORD\n\t"
+#else
+#define WD_STEP_HEAD(WAIT, KEY, START, FREQ)                                                                              \
+    WAIT                                                                                                                  \
+    "s_and_b32 s56, s52, 0xffff\n\t"                                                                                      \
+    "s_lshr_b64 s[54:55], s[52:53], 16\n\t"                                                                               \
+    "v_sub_u32 v26, s56, " START "\n\t"                                                                                   \
+    "v_mul_u32_u24 v27, s55, " FREQ "\n\t"                                                                                \
+    "v_mad_u64_u32 v[26:27], vcc, " FREQ ", s54, v[26:27]\n\t"                                                            \
+    "v_cmp_lt_u32 vcc, s56, " KEY "\n\t"
+#endif
+#define WD_STEP_FETCH(NEXT)                                                                                               \
+    "v_readlane_b32 s56, %[meta], %[jf]\n\t"                                                                              \
+    "s_ff1_i32_b64 s57, vcc\n\t"                                                                                          \
+    "v_readlane_b32 s53, v27, s57\n\t"                                                                                    \
+    "v_readlane_b32 s52, v26, s57\n\t"                                                                                    \
+    "v_add_u32 v28, s56, %[lane16]\n\t"                                                                                   \
+    "ds_read_b128 " NEXT ", v28\n\t"                                                                                      \
+    "v_writelane_b32 %[res], s57, %[jw]"
+#define WD_STEP_TAIL                                                                                                      \
+    "s_ff1_i32_b64 s57, vcc\n\t"                                                                                          \
+    "v_readlane_b32 s53, v27, s57\n\t"                                                                                    \
+    "v_readlane_b32 s52, v26, s57\n\t"                                                                                    \
+    "v_writelane_b32 %[res], s57, %[jw]"
+#define WD_STEP_OPERANDS(J)                                                                                               \
+    : "={s52}"(xlo), "={s53}"(xhi), "={s[54:55]}"(t), "={s57}"(first), [res] "+v"(res), "={v[10:13]}"(b0),                \
+      "={v[14:17]}"(b1), "={v[18:21]}"(b2), "={v[22:25]}"(b3)                                                             \
+    : "0"(xlo), "1"(xhi), "5"(b0), "6"(b1), "7"(b2), "8"(b3), [meta] "v"(meta_l), [lane16] "v"(lane16),                   \
+      [jf] "n"((J) + 3 < 64 ? (J) + 3 : 0), [jw] "n"(J)                                                                   \
+    : "s56", "vcc", "scc", "v26", "v27", "v28"
+
+template <int J>
+__device__ __forceinline__ void step_precision16(uint32_t &xlo, uint32_t &xhi, uint64_t &t, int32_t &first, int32_t &res, u32x4 &b0, u32x4 &b1,
+                                                 u32x4 &b2, u32x4 &b3, uint32_t meta_l, uint32_t lane16)
+{
+    constexpr int R = J & 3;
+    constexpr bool kFetch = J + 3 < 64;
+    if constexpr (R == 0) {
+        if constexpr (kFetch) asm volatile(WD_STEP_HEAD("s_waitcnt lgkmcnt(1)\n\t", "v10", "v11", "v12") WD_STEP_FETCH("v[22:25]") WD_STEP_OPERANDS(J));
+        else                  asm volatile(WD_STEP_HEAD("s_waitcnt lgkmcnt(0)\n\t", "v10", "v11", "v12") WD_STEP_TAIL WD_STEP_OPERANDS(J));
+    } else if constexpr (R == 1) {
+        if constexpr (kFetch) asm volatile(WD_STEP_HEAD("", "v14", "v15", "v16") WD_STEP_FETCH("v[10:13]") WD_STEP_OPERANDS(J));
+        else                  asm volatile(WD_STEP_HEAD("s_waitcnt lgkmcnt(0)\n\t", "v14", "v15", "v16") WD_STEP_TAIL WD_STEP_OPERANDS(J));
+    } else if constexpr (R == 2) {
+        if constexpr (kFetch) asm volatile(WD_STEP_HEAD("s_waitcnt lgkmcnt(1)\n\t", "v18", "v19", "v20") WD_STEP_FETCH("v[14:17]") WD_STEP_OPERANDS(J));
+        else                  asm volatile(WD_STEP_HEAD("s_waitcnt lgkmcnt(0)\n\t", "v18", "v19", "v20") WD_STEP_TAIL WD_STEP_OPERANDS(J));
+    } else {
+        if constexpr (kFetch) asm volatile(WD_STEP_HEAD("", "v22", "v23", "v24") WD_STEP_FETCH("v[18:21]") WD_STEP_OPERANDS(J));
+        else                  asm volatile(WD_STEP_HEAD("s_waitcnt lgkmcnt(0)\n\t", "v22", "v23", "v24") WD_STEP_TAIL WD_STEP_OPERANDS(J));
+    }
+}
+
+// compile-time loop over J = kBegin .. kEnd - 1
+template <int kBegin, int kEnd, class F> __device__ __forceinline__ void static_each(F &&f)
+{
+    if constexpr (kBegin < kEnd) {
+        f(std::integral_constant<int, kBegin>{});
+        static_each<kBegin + 1, kEnd>(f);
+    }
+}
+
 struct WaveDecoder {
     const uint32_t *img;     // LDS
     const uint32_t *words;
@@ -146,6 +224,39 @@ struct WaveDecoder {
     __device__ __forceinline__ int32_t decode_chunk(uint32_t meta_l, int32_t size_l, int cnt, int lane)
     {
         int32_t result = 1;
+        if (cnt == 64 && prec == 16u) {   // a full chunk at the usual precision: the spelled-out common path
+            const uint32_t lane16 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(img)) + static_cast<uint32_t>(lane) * 16u;
+            auto row = [&](int jj) { return *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(img) + bc32(meta_l, jj) + lane * 16); };
+            u32x4 b0 = row(0), b1 = row(1), b2 = row(2), b3 = b2;
+            uint32_t xlo = static_cast<uint32_t>(x), xhi = static_cast<uint32_t>(x >> 32);
+            uint64_t t = 0;
+            int32_t first = 0;
+            static_each<0, 64>([&](auto jc) {
+                constexpr int J = decltype(jc)::value;
+                step_precision16<J>(xlo, xhi, t, first, result, b0, b1, b2, b3, meta_l, lane16);
+                if (__builtin_expect(xhi == 0u, 0)) {
+                    // rows in flight land before any compiler-generated code may touch their registers
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3));
+                    if (xlo < static_cast<uint32_t>(kLow)) {
+                        const u32x4 &e = (J & 3) == 0 ? b0 : (J & 3) == 1 ? b1 : (J & 3) == 2 ? b2 : b3;
+                        if (__builtin_expect(bc32(e[2], first) != 0u, 1)) {
+                            // x = (x << 32) | word k  (the high half is early-clobber: no input may share its register)
+                            asm volatile("s_mov_b32 s53, s52\n\tv_readlane_b32 s52, %2, %3" : "={s52}"(xlo), "=&{s53}"(xhi) : "v"(cur), "s"(k), "0"(xlo));
+                            ++k;
+                        } else {
+                            // image frequency 0: the lane's candidate is the coded value minus its start (nothing was multiplied)
+                            const uint32_t cf = xlo + bc32(e[1], first);
+                            first = rare_symbol(e, first, bc32(meta_l, J), static_cast<int32_t>(bc32(static_cast<uint32_t>(size_l), J)), cf, t, lane);
+                            xlo = static_cast<uint32_t>(x); xhi = static_cast<uint32_t>(x >> 32);
+                            asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(result) : "s"(first), "n"(J));
+                        }
+                    }
+                    asm volatile("" : "={s52}"(xlo), "={s53}"(xhi) : "0"(xlo), "1"(xhi));   // (the state stays in its registers on every path)
+                }
+            });
+            x = static_cast<uint64_t>(xlo) | (static_cast<uint64_t>(xhi) << 32);
+            return result;
+        }
         auto fetch = [&](int jj, u32x4 &e) {
             const uint32_t m = bc32(meta_l, jj);
             e = *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(img) + m + lane * 16);
@@ -183,16 +294,6 @@ struct WaveDecoder {
         u32x4 ea, eb;
         fetch(0, ea);
         fetch(cnt > 1 ? 1 : 0, eb);
-        if (cnt == 64) {   // a full chunk, fully unrolled: every lane id is an immediate
-            static_pairs<0, 64>([&](auto jc) {
-                constexpr int J = decltype(jc)::value;
-                decode_one(std::integral_constant<int, J>{}, ea);
-                if constexpr (J + 2 < 64) fetch(J + 2, ea);
-                decode_one(std::integral_constant<int, J + 1>{}, eb);
-                if constexpr (J + 3 < 64) fetch(J + 3, eb);
-            });
-            return result;
-        }
         int j = 0;
         for (; j + 17 < cnt; j += 16) {   // sixteen symbols per loop trip, no clamping of the prefetch index in here
 #pragma unroll
