@@ -331,12 +331,15 @@ __device__ __forceinline__ void decoder_workgroup(const ScanArgs &a, float *lds)
                 (a.idx + at)[lane] = row;
                 (a.ybuf + ((bC + c0) * HW + p))[lane_y] = v;
             }
-            if (a.prof && b == 0 && lane == 0) {   // first stream: ticks waiting for the step's parameters / decoding and publishing
-                a.prof[4 * kMaxLayers + 2] += tw1 - tw0;
-                a.prof[4 * kMaxLayers + 3] += wall_clock64() - tw1;
-                a.prof[4 * kMaxLayers + 4] += tc3 - tc2;            // shader clocks inside decode_chunk
-                a.prof[4 * kMaxLayers + 5] += clock64() - tc3;      // ... publishing
-                a.prof[4 * kMaxLayers + 6] = d.position();
+            if (a.prof) {   // first stream: ticks waiting for the step's parameters / decoding and publishing
+                const long long tc4 = clock64(), tw4 = wall_clock64();   // (read before the slots are touched: their updates wait for memory)
+                if (b == 0 && lane == 0) {
+                    a.prof[4 * kMaxLayers + 2] += tw1 - tw0;
+                    a.prof[4 * kMaxLayers + 3] += tw4 - tw1;
+                    a.prof[4 * kMaxLayers + 4] += tc3 - tc2;            // shader clocks inside decode_chunk
+                    a.prof[4 * kMaxLayers + 5] += tc4 - tc3;            // ... publishing
+                    a.prof[4 * kMaxLayers + 6] = d.position();
+                }
             }
         }
     }
