@@ -471,6 +471,32 @@ struct Emitter {
     }
 };
 
+// The fast encoder's emitter: words are parked in lane k of a register and leave with ONE coalesced store per chunk of 64
+// symbols (and behind every bypass value), so a renormalisation on the serial chain issues no memory instruction.  The
+// stream is written towards lower addresses: parked word i lands at p[-1 - i].
+struct WaveEmitter {
+    uint32_t *p;   // next free word is p[-1]; wave-uniform
+    uint32_t *lo;  // slot start
+    bool overflow;
+    uint32_t parked;   // lane i: i-th word since the last flush
+    int k;             // words parked (uniform)
+    __device__ __forceinline__ void flush(int lane)
+    {
+        if (k == 0) return;
+        if (p - lo < k) { overflow = true; k = 0; return; }
+        if (lane < k) p[-1 - lane] = parked;
+        p -= k;
+        k = 0;
+    }
+    __device__ __forceinline__ void push(uint32_t w, int lane)   // anywhere (the final state): flushes a full register
+    {
+        uint32_t m0_save;
+        w = __builtin_amdgcn_readfirstlane(w);   // uniform already; the bypass path's loops leave it in a vector register
+        asm volatile("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1" : "+v"(parked), "=&s"(m0_save) : "s"(w), "s"(k));
+        if (++k == 64) flush(lane);
+    }
+};
+
 // x = C(s, x) with renormalisation (rans64.h:65-84).  All operands are wave-uniform.
 __device__ __forceinline__ void put_symbol(uint64_t &x, Emitter &em, int lane, uint32_t start, uint32_t freq,
                                            uint64_t rcp, uint32_t post_shift, uint32_t precision)
@@ -483,11 +509,37 @@ __device__ __forceinline__ void put_symbol(uint64_t &x, Emitter &em, int lane, u
     x = x + start + q * ((1u << precision) - freq);  // (q << prec) + (x - q*freq) + start
 }
 
-__device__ __forceinline__ void put_raw(uint64_t &x, Emitter &em, int lane, uint32_t val, uint32_t nbits)
+template <class Em> __device__ __forceinline__ void put_raw(uint64_t &x, Em &em, int lane, uint32_t val, uint32_t nbits)
 { /* rans64.cpp:29-47 */
     const uint64_t x_max = 1ull << (63u - nbits);  // ((L>>16)<<32) << (16-nbits)
     if (x >= x_max) { em.push(static_cast<uint32_t>(x), lane); x >>= 32; }
     x = (x << nbits) | val;
+}
+
+// A bypass value's escape code in front of its sentinel symbol (written reversed: the decoder reads the sentinel, the count
+// nibbles, then the payload low-first; rans64.cpp:312-339), straight to memory behind the words parked so far;
+// then the sentinel's own renormalisation.  Not inlined, everything by value: the fast encoder keeps its state in named
+// scalar registers, and these loops would pull it into vector registers (their integer division runs on the vector unit).
+struct EscapeResult { uint64_t x; uint32_t *p; int overflow; };
+__device__ __noinline__ EscapeResult encode_escape(uint64_t x, uint32_t *p, uint32_t *lo, int lane, uint32_t parked, int parked_n, uint32_t r, uint32_t bprec,
+                                                   uint32_t maxbv, uint32_t x_max_high)
+{
+    Emitter direct{p, lo, false};
+    if (parked_n > 0) {   // the words parked so far leave first (WaveEmitter::flush)
+        if (p - lo < parked_n) return EscapeResult{x, p, 1};
+        if (lane < parked_n) p[-1 - lane] = parked;
+        direct.p = p - parked_n;
+    }
+    int nb = 0;
+    while (nb * bprec < 32u && (r >> (nb * bprec)) != 0u) ++nb;
+    for (int k = nb - 1; k >= 0; --k) put_raw(x, direct, lane, (r >> (k * bprec)) & maxbv, bprec);
+    put_raw(x, direct, lane, static_cast<uint32_t>(nb) % maxbv, bprec);
+    for (uint32_t k = 0; k < static_cast<uint32_t>(nb) / maxbv; ++k) put_raw(x, direct, lane, maxbv, bprec);
+    if (static_cast<uint32_t>(x >> 32) >= x_max_high) {
+        direct.push(static_cast<uint32_t>(x), lane);
+        x >>= 32;
+    }
+    return EscapeResult{x, direct.p, direct.overflow ? 1 : 0};
 }
 
 // One wavefront per stream.  Symbols are consumed last-to-first in chunks of 64: the lanes
@@ -625,8 +677,8 @@ __global__ __launch_bounds__(64 * WPB) void rans_encode_fast_kernel(TablesDev T,
     const int32_t *sym = symbols + beg;
     const int32_t *idx = indexes + beg;
     uint32_t *slot = out_words + static_cast<int64_t>(stream) * slot_words;
-    Emitter em{slot + slot_words, slot, false};
-    uint64_t x = kRansL;
+    WaveEmitter em{slot + slot_words, slot, false, 0u, 0};
+    uint32_t xlo_ = static_cast<uint32_t>(kRansL), xhi_ = 0u;   // the state, in s[52:53] across the spelled-out steps
     const uint32_t xs = 31u - static_cast<uint32_t>(T.precision);  // x >= freq << (63-p)  <=>  (x >> 32) >= freq << (31-p)
     const uint32_t bprec = static_cast<uint32_t>(T.bypass_precision);
     const uint32_t maxbv = (1u << bprec) - 1u;
@@ -635,7 +687,7 @@ __global__ __launch_bounds__(64 * WPB) void rans_encode_fast_kernel(TablesDev T,
     int64_t i1 = n - 64 + lane;               // element of this lane in the chunk being prepared
     int32_t row1 = 0, s1 = 0;
     if (i1 >= 0) { row1 = idx[i1]; s1 = sym[i1]; }
-    EncLane cur = enc_prepare(T, rowinfo_lds, i1 >= 0, row1, s1);
+    EncLane cur_ = enc_prepare(T, rowinfo_lds, i1 >= 0, row1, s1);
     int64_t i2 = i1 - 64;
     int32_t row2 = 0, s2 = 0;
     if (i2 >= 0) { row2 = idx[i2]; s2 = sym[i2]; }
@@ -647,74 +699,89 @@ __global__ __launch_bounds__(64 * WPB) void rans_encode_fast_kernel(TablesDev T,
         int32_t row3 = 0, s3 = 0;
         if (i3 >= 0) { row3 = idx[i3]; s3 = sym[i3]; }
 
-        // Lane j owns symbol j of the chunk and already holds its frequency, start and exact-division
-        // constants, so C(s, x) is evaluated by ALL lanes for their own symbol against the current uniform
-        // state (11 VALU ops) and only the new state of lane j is broadcast back: no per-symbol operand
-        // broadcasts, no scalar 64x64 multiply.  A lone wave issues one instruction per ~8-11 cycles whatever
-        // it is (scripts/micro/lone_wave_latency.hip), so what counts is the instruction count per symbol.
-        // Renormalisation and bypass symbols (x_max forced to 0) hide behind one ballot-bit test.
-        const uint32_t fq = cur.a & 0xFFFFu, cm = cur.a >> 16, sh = cur.b & 63u, st = cur.b >> 8;
-        const uint32_t xm = (cur.b & 0x80u) ? 0u : (fq << xs);  // renormalise when (x >> 32) >= xm
-#define BASIC_ENC_STEP(J)                                                                                       \
-        do {                                                                                                   \
-            if (__builtin_expect(static_cast<uint32_t>(x >> 32) >= bcast_u32(xm, (J)), 0)) {                   \
-                const uint32_t b_ = bcast_u32(cur.b, (J));                                                     \
-                if (b_ & 0x80u) {                                                                              \
-                    /* decode order: sentinel, count nibbles, payload low-first  =>  written reversed */      \
-                    const uint32_t r = bcast_u32(cur.raw, (J));                                                \
-                    int nb = 0;                                                                                \
-                    while (nb * bprec < 32u && (r >> (nb * bprec)) != 0u) ++nb;                                \
-                    for (int k = nb - 1; k >= 0; --k) put_raw(x, em, lane, (r >> (k * bprec)) & maxbv, bprec); \
-                    put_raw(x, em, lane, static_cast<uint32_t>(nb) % maxbv, bprec);                            \
-                    for (uint32_t k = 0; k < static_cast<uint32_t>(nb) / maxbv; ++k) put_raw(x, em, lane, maxbv, bprec); \
-                }                                                                                              \
-                if (static_cast<uint32_t>(x >> 32) >= (bcast_u32(fq, (J)) << xs)) {                            \
-                    em.push(static_cast<uint32_t>(x), lane);                                                   \
-                    x >>= 32;                                                                                  \
-                }                                                                                              \
-            }                                                                                                  \
-            const uint32_t xl_ = static_cast<uint32_t>(x), xh_ = static_cast<uint32_t>(x >> 32);              \
-            /* q = mulhi64(x, rcp) >> shift  (== x / freq, Alverson; q = x - 1 for freq 1, see the encoder image): */ \
-            /* mid = xh*rl + hi32(xl*rl) + xl*rh as a 64-bit value + carry, high = xh*rh + (mid >> 32)              */ \
-            const uint64_t t_ = static_cast<uint64_t>(xh_) * cur.rl + __umulhi(xl_, cur.rl);                   \
-            uint64_t mid_, cy_;                                                                                \
-            asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(mid_), "=s"(cy_) : "s"(xl_), "v"(cur.rh), "v"(t_));  \
-            uint32_t ch_;                                                                                      \
-            asm("v_addc_co_u32 %0, vcc, 0, 0, %1" : "=v"(ch_) : "s"(cy_) : "vcc");                             \
-            const uint64_t hadd_ = (mid_ >> 32) | (static_cast<uint64_t>(ch_) << 32);                          \
-            uint64_t h_;                                                                                       \
-            asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(h_) : "s"(xh_), "v"(cur.rh), "v"(hadd_) : "vcc");   \
-            const uint64_t q_ = h_ >> sh;                                                                      \
-            /* x' = (q << p) + (x - q*freq) + start = x + start' + q * (2^p - freq) */                         \
-            const uint64_t base_ = x + st;                                                                     \
-            const uint64_t nadd_ = static_cast<uint32_t>(base_) |                                              \
-                (static_cast<uint64_t>(static_cast<uint32_t>(base_ >> 32) + __umul24(static_cast<uint32_t>(q_ >> 32), cm)) << 32); \
-            uint64_t nx_;                                                                                      \
-            asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(nx_) : "v"(static_cast<uint32_t>(q_)), "v"(cm), "v"(nadd_) : "vcc"); \
-            x = bcast_u64(nx_, (J));                                                                           \
-        } while (0)
+        // Lane j owns symbol j of the chunk and already holds its frequency, start and exact-division constants, so C(s, x)
+        // is evaluated by ALL lanes for their own symbol against the current uniform state and only the new state of lane j
+        // is broadcast back: no per-symbol operand broadcasts, no scalar 64x64 multiply.  A lone wave issues one instruction
+        // per ~8.4 clocks whatever it is (scripts/r04_chain_probe.hip), so what counts is the instruction count per symbol: 13
+        // spelled out below + the compiler's scalar compare and branch for "renormalise?" (x_max forced to 0 for a bypass
+        // symbol: the same test covers it).  A plain renormalisation parks the low word in lane k of a register (one coalesced
+        // store per chunk) and shifts the state: no memory instruction, no bounds test behind the branch.
+        const uint32_t fq = cur_.a & 0xFFFFu, cm_ = cur_.a >> 16, sh_ = cur_.b & 63u;
+        const uint64_t st_ = cur_.b >> 8;
+        const uint32_t xm_ = (cur_.b & 0x80u) ? 0u : (fq << xs);  // renormalise when (x >> 32) >= xm
         const int j_lo = hi >= 64 ? 0 : static_cast<int>(64 - hi);
-#define BASIC_ENC_STEP4(J) BASIC_ENC_STEP(J); BASIC_ENC_STEP((J) - 1); BASIC_ENC_STEP((J) - 2); BASIC_ENC_STEP((J) - 3)
-#define BASIC_ENC_STEP16(J) BASIC_ENC_STEP4(J); BASIC_ENC_STEP4((J) - 4); BASIC_ENC_STEP4((J) - 8); BASIC_ENC_STEP4((J) - 12)
-        if (j_lo == 0) {
-            // a full chunk, fully unrolled: the lane ids of the broadcasts are immediates (one scalar instruction fewer
-            // per symbol than the run-time loop below)
-            BASIC_ENC_STEP16(63); BASIC_ENC_STEP16(47); BASIC_ENC_STEP16(31); BASIC_ENC_STEP16(15);
-        } else {
-            int j = 63;
-            for (; j - 15 >= j_lo; j -= 16) {  // sixteen symbols per loop trip: the loop bookkeeping is issue slots too
-                BASIC_ENC_STEP16(j);
+        uint32_t xmj_ = bcast_u32(xm_, 63);
+        uint64_t low_pair_ = 0ull;   // v[30:31]: {mulhi(x_lo, rcp_lo), 0}
+        auto renormalise = [&](auto jc) {
+            constexpr int J = decltype(jc)::value;
+            if (xmj_ == 0u) {   // a bypass symbol: its escape code goes first (the decoder reads sentinel, count nibbles, payload low-first)
+                const EscapeResult er = encode_escape(static_cast<uint64_t>(xlo_) | (static_cast<uint64_t>(xhi_) << 32), em.p, em.lo, lane, em.parked, em.k,
+                                                      bcast_u32(cur_.raw, J), bprec, maxbv, bcast_u32(fq, J) << xs);
+                em.p = er.p;
+                em.k = 0;
+                if (er.overflow) em.overflow = true;
+                const uint64_t x = er.x;
+                {   // back into s[52:53] through vector registers: the loops above may leave the (uniform) state in them, and a
+                    // copy from there to a NAMED scalar register is something the compiler cannot legalise itself
+                    uint32_t &xlo = xlo_, &xhi = xhi_;
+                    asm volatile("v_readfirstlane_b32 s52, %2\n\tv_readfirstlane_b32 s53, %3" : "={s52}"(xlo), "={s53}"(xhi)
+                                 : "v"(static_cast<uint32_t>(x)), "v"(static_cast<uint32_t>(x >> 32)));
+                }
+            } else {           // park the low word in lane k, x >>= 32 (m0 carries the lane: one scalar operand per VALU instruction)
+                uint32_t m0_save;
+                uint32_t &xlo = xlo_, &xhi = xhi_;   // (generic lambda: an asm operand alone is no odr-use, the capture needs one)
+                uint32_t &parked = em.parked;
+                const int &parked_n = em.k;
+                asm volatile("s_mov_b32 %3, m0\n\ts_mov_b32 m0, %4\n\tv_writelane_b32 %2, s52, m0\n\ts_mov_b32 m0, %3\n\ts_mov_b32 s52, s53\n\ts_mov_b32 s53, 0"
+                             : "={s52}"(xlo), "={s53}"(xhi), "+v"(parked), "=&s"(m0_save) : "s"(parked_n), "0"(xlo), "1"(xhi));
+                ++em.k;
             }
-            for (; j >= j_lo; --j) BASIC_ENC_STEP(j);
+            {
+                uint32_t &xlo = xlo_, &xhi = xhi_;
+                asm volatile("" : "={s52}"(xlo), "={s53}"(xhi) : "0"(xlo), "1"(xhi));   // (the state stays in its registers on every path)
+            }
+        };
+        auto step = [&](auto jc) {
+            constexpr int J = decltype(jc)::value;
+            uint32_t &xlo = xlo_, &xhi = xhi_, &xmj = xmj_;
+            uint64_t &low_pair = low_pair_;
+            const EncLane &cur = cur_;
+            const uint32_t &sh = sh_, &cm = cm_, &xm = xm_;
+            const uint64_t &st = st_;
+            if (__builtin_expect(xhi >= xmj, 0)) renormalise(jc);
+            // q = mulhi64(x, rcp) >> shift (== x / freq, Alverson; q = x - 1 for freq 1, see the encoder image):
+            //   t = xh*rl + hi32(xl*rl); mid = xl*rh + t with its carry; h = xh*rh + (mid >> 32 | carry << 32); q = h >> shift
+            // x' = (q << p) + (x - q*freq) + start = x + start' + q * (2^p - freq); then the next symbol's x_max and the new state
+            asm volatile("v_mul_hi_u32 v30, s52, %[rl]\n\t"
+                         "v_mad_u64_u32 v[32:33], s[54:55], s53, %[rl], v[30:31]\n\t"
+                         "v_mad_u64_u32 v[32:33], s[54:55], s52, %[rh], v[32:33]\n\t"
+                         "v_lshl_add_u64 v[34:35], s[52:53], 0, %[st]\n\t"
+                         "v_addc_co_u32 v37, vcc, 0, 0, s[54:55]\n\t"
+                         "v_mov_b32 v36, v33\n\t"
+                         "v_mad_u64_u32 v[32:33], vcc, s53, %[rh], v[36:37]\n\t"
+                         "v_lshrrev_b64 v[32:33], %[sh], v[32:33]\n\t"
+                         "v_mad_u32_u24 v35, v33, %[cm], v35\n\t"
+                         "v_mad_u64_u32 v[32:33], vcc, v32, %[cm], v[34:35]\n\t"
+                         "v_readlane_b32 s56, %[xm], %[jn]\n\t"
+                         "v_readlane_b32 s52, v32, %[j]\n\t"
+                         "v_readlane_b32 s53, v33, %[j]"
+                         : "={s52}"(xlo), "={s53}"(xhi), "={s56}"(xmj), "={v[30:31]}"(low_pair)
+                         : "0"(xlo), "1"(xhi), "3"(low_pair), [rl] "v"(cur.rl), [rh] "v"(cur.rh), [st] "v"(st), [sh] "v"(sh), [cm] "v"(cm), [xm] "v"(xm),
+                           [j] "n"(J), [jn] "n"(J > 0 ? J - 1 : 0)
+                         : "s54", "s55", "vcc", "v32", "v33", "v34", "v35", "v36", "v37");
+        };
+        if (j_lo == 0) {   // a full chunk
+            wavedec::static_down<63>(step);
+        } else {           // the stream's first symbols: lanes j_lo .. 63
+            wavedec::static_down<63>([&](auto jc) { if (decltype(jc)::value >= j_lo) step(jc); });
         }
-#undef BASIC_ENC_STEP16
-#undef BASIC_ENC_STEP4
-#undef BASIC_ENC_STEP
-        cur = nxt;
+        em.flush(lane);
+        cur_ = nxt;
         i2 = i3; row2 = row3; s2 = s3;
     }
-    em.push(static_cast<uint32_t>(x >> 32), lane);  // flush, rans64.h:87-94
-    em.push(static_cast<uint32_t>(x), lane);
+    em.push(xhi_, lane);  // flush, rans64.h:87-94
+    em.push(xlo_, lane);
+    em.flush(lane);
     if (lane == 0) out_nwords[stream] = em.overflow ? -1 : static_cast<int32_t>((slot + slot_words) - em.p);
 }
 

@@ -101,6 +101,13 @@ __device__ __forceinline__ void step_precision16(uint32_t &xlo, uint32_t &xhi, u
     }
 }
 
+// compile-time loop over J = kFrom, kFrom - 1, ..., 0
+template <int kFrom, class F> __device__ __forceinline__ void static_down(F &&f)
+{
+    f(std::integral_constant<int, kFrom>{});
+    if constexpr (kFrom > 0) static_down<kFrom - 1>(f);
+}
+
 // compile-time loop over J = kBegin .. kEnd - 1
 template <int kBegin, int kEnd, class F> __device__ __forceinline__ void static_each(F &&f)
 {

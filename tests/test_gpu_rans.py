@@ -218,3 +218,41 @@ def test_batched_streams_fuzz(oracle, seed):
             assert strs[i] == eo.encode_with_indexes(sym[i * n:(i + 1) * n], idx[i * n:(i + 1) * n])
         back = T.decode_batch_from_bytes(strs, torch.from_numpy(idx[: k * n]).cuda(), n)
         assert np.array_equal(back.cpu().numpy(), sym[: k * n])
+
+
+@pytest.mark.parametrize("prec,every", [(16, 1), (16, 2), (14, 1), (16, 5)])
+def test_bypass_heavy_chunks(oracle, prec, every):
+    """Chunks of 64 symbols that read far more stream words than symbols: every `every`-th value is a bypass value of up to
+    31 bits (eight payload nibbles + count + sentinel), so a chunk of the wave decoder (csrc/wave_decoder.h) runs through its
+    64-word register and the blocks behind it and has to line its words up again after every one of them; the values between
+    take the common path at precision 16 and the generic one at 14."""
+    import torch
+    from cbench_basic_amd.nn.kernels import RansTables
+    rng = np.random.default_rng(prec * 10 + every)
+    nd, ns = 5, 40
+    freqs = rng.integers(1, 300, (nd, ns)).astype(np.int32)
+    nsym, off = np.full(nd, ns, np.int32), np.full(nd, -20, np.int32)
+    T = RansTables(freqs=freqs, nsym=nsym, offsets=off, precision=prec, bypass=True, bypass_precision=4)
+    eo = oracle.Rans64Encoder(prec, True, 4)
+    eo.init_params(freqs, nsym, off)
+    lens = [64, 640, 1000, 4096, 63]
+    seg = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    tot = int(seg[-1])
+    idx = rng.integers(0, nd, tot).astype(np.int32)
+    sym = rng.integers(-20, 18, tot).astype(np.int32)
+    big = rng.integers(1 << 20, (1 << 30) - 1, sym[::every].size) * rng.choice([-1, 1], sym[::every].size)
+    sym[::every] = big.astype(np.int32)
+    slot = max(lens) * 3 + 4
+    words, nwords = T.encode_batch(torch.from_numpy(sym).cuda(), torch.from_numpy(idx).cuda(), torch.from_numpy(seg).cuda(), slot)
+    words, nwords = words.cpu().numpy().view(np.uint32), nwords.cpu().numpy()
+    streams = []
+    for i, L in enumerate(lens):
+        b = words[i, slot - nwords[i]:].tobytes()
+        assert b == eo.encode_with_indexes(sym[seg[i]:seg[i + 1]], idx[seg[i]:seg[i + 1]]), (i, L)
+        streams.append(np.frombuffer(b, np.uint32))
+    assert streams[3].size > 4096 * (1.2 if every == 1 else 0.2)   # more words than the one-per-symbol the common path can read
+    woff = np.concatenate([[0], np.cumsum([s.size for s in streams])]).astype(np.int64)
+    allw = np.concatenate(streams).view(np.int32)
+    out, _, _ = T.decode_batch(torch.from_numpy(allw).cuda(), torch.from_numpy(woff).cuda(), torch.from_numpy(idx).cuda(),
+                               torch.from_numpy(seg).cuda())
+    assert np.array_equal(out.cpu().numpy(), sym)
