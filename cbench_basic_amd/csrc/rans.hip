@@ -714,7 +714,15 @@ __global__ __launch_bounds__(64 * WPB) void rans_encode_fast_kernel(TablesDev T,
         uint64_t low_pair_ = 0ull;   // v[30:31]: {mulhi(x_lo, rcp_lo), 0}
         auto renormalise = [&](auto jc) {
             constexpr int J = decltype(jc)::value;
-            if (xmj_ == 0u) {   // a bypass symbol: its escape code goes first (the decoder reads sentinel, count nibbles, payload low-first)
+            if (__builtin_expect(xmj_ != 0u, 1)) {           // park the low word in lane k, x >>= 32 (m0 carries the lane: one scalar operand per VALU instruction)
+                uint32_t m0_save;
+                uint32_t &xlo = xlo_, &xhi = xhi_;   // (generic lambda: an asm operand alone is no odr-use, the capture needs one)
+                uint32_t &parked = em.parked;
+                const int &parked_n = em.k;
+                asm volatile("s_mov_b32 %3, m0\n\ts_mov_b32 m0, %4\n\tv_writelane_b32 %2, s52, m0\n\ts_mov_b32 m0, %3\n\ts_mov_b32 s52, s53\n\ts_mov_b32 s53, 0"
+                             : "={s52}"(xlo), "={s53}"(xhi), "+v"(parked), "=&s"(m0_save) : "s"(parked_n), "0"(xlo), "1"(xhi));
+                ++em.k;
+            } else {   // a bypass symbol: its escape code goes first (the decoder reads sentinel, count nibbles, payload low-first)
                 const EscapeResult er = encode_escape(static_cast<uint64_t>(xlo_) | (static_cast<uint64_t>(xhi_) << 32), em.p, em.lo, lane, em.parked, em.k,
                                                       bcast_u32(cur_.raw, J), bprec, maxbv, bcast_u32(fq, J) << xs);
                 em.p = er.p;
@@ -727,14 +735,6 @@ __global__ __launch_bounds__(64 * WPB) void rans_encode_fast_kernel(TablesDev T,
                     asm volatile("v_readfirstlane_b32 s52, %2\n\tv_readfirstlane_b32 s53, %3" : "={s52}"(xlo), "={s53}"(xhi)
                                  : "v"(static_cast<uint32_t>(x)), "v"(static_cast<uint32_t>(x >> 32)));
                 }
-            } else {           // park the low word in lane k, x >>= 32 (m0 carries the lane: one scalar operand per VALU instruction)
-                uint32_t m0_save;
-                uint32_t &xlo = xlo_, &xhi = xhi_;   // (generic lambda: an asm operand alone is no odr-use, the capture needs one)
-                uint32_t &parked = em.parked;
-                const int &parked_n = em.k;
-                asm volatile("s_mov_b32 %3, m0\n\ts_mov_b32 m0, %4\n\tv_writelane_b32 %2, s52, m0\n\ts_mov_b32 m0, %3\n\ts_mov_b32 s52, s53\n\ts_mov_b32 s53, 0"
-                             : "={s52}"(xlo), "={s53}"(xhi), "+v"(parked), "=&s"(m0_save) : "s"(parked_n), "0"(xlo), "1"(xhi));
-                ++em.k;
             }
             {
                 uint32_t &xlo = xlo_, &xhi = xhi_;
