@@ -471,29 +471,36 @@ struct Emitter {
     }
 };
 
-// The fast encoder's emitter: words are parked in lane k of a register and leave with ONE coalesced store per chunk of 64
-// symbols (and behind every bypass value), so a renormalisation on the serial chain issues no memory instruction.  The
-// stream is written towards lower addresses: parked word i lands at p[-1 - i].
+// The fast encoder's emitter: the word a symbol's renormalisation emits is parked in THAT SYMBOL'S lane of a register (an
+// immediate lane: no m0, no counter) and a bit of a 64-bit mask is set; the words leave with one coalesced store per chunk of
+// 64 symbols (and in front of a bypass value's escape code), so a renormalisation on the serial chain issues no memory
+// instruction.  Symbols are folded from lane 63 down and the stream is written towards lower addresses: the word parked in
+// lane l lands at p[-1 - (number of parked lanes above l)].
 struct WaveEmitter {
     uint32_t *p;   // next free word is p[-1]; wave-uniform
     uint32_t *lo;  // slot start
     bool overflow;
-    uint32_t parked;   // lane i: i-th word since the last flush
-    int k;             // words parked (uniform)
+    uint32_t parked;   // lane j: the word symbol j emitted (where its mask bit is set)
+    uint64_t mask;     // uniform
+    __device__ __forceinline__ static uint32_t *store_parked(uint32_t *p, uint32_t *lo, uint32_t parked, uint64_t mask, int lane, bool &overflow)
+    {
+        const int n = __builtin_popcountll(mask);
+        if (p - lo < n) { overflow = true; return p; }
+        const uint64_t above = (mask >> lane) >> 1;   // parked lanes above this one: emitted earlier
+        if ((mask >> lane) & 1ull) p[-1 - __builtin_popcountll(above)] = parked;
+        return p - n;
+    }
     __device__ __forceinline__ void flush(int lane)
     {
-        if (k == 0) return;
-        if (p - lo < k) { overflow = true; k = 0; return; }
-        if (lane < k) p[-1 - lane] = parked;
-        p -= k;
-        k = 0;
+        if (mask == 0ull) return;
+        p = store_parked(p, lo, parked, mask, lane, overflow);
+        mask = 0ull;
     }
-    __device__ __forceinline__ void push(uint32_t w, int lane)   // anywhere (the final state): flushes a full register
+    __device__ __forceinline__ void push_direct(uint32_t w, int lane)   // straight to memory; nothing may be parked (the final state)
     {
-        uint32_t m0_save;
-        w = __builtin_amdgcn_readfirstlane(w);   // uniform already; the bypass path's loops leave it in a vector register
-        asm volatile("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1" : "+v"(parked), "=&s"(m0_save) : "s"(w), "s"(k));
-        if (++k == 64) flush(lane);
+        if (p == lo) { overflow = true; return; }
+        --p;
+        if (lane == 0) *p = w;
     }
 };
 
@@ -521,14 +528,14 @@ template <class Em> __device__ __forceinline__ void put_raw(uint64_t &x, Em &em,
 // then the sentinel's own renormalisation.  Not inlined, everything by value: the fast encoder keeps its state in named
 // scalar registers, and these loops would pull it into vector registers (their integer division runs on the vector unit).
 struct EscapeResult { uint64_t x; uint32_t *p; int overflow; };
-__device__ __noinline__ EscapeResult encode_escape(uint64_t x, uint32_t *p, uint32_t *lo, int lane, uint32_t parked, int parked_n, uint32_t r, uint32_t bprec,
+__device__ __noinline__ EscapeResult encode_escape(uint64_t x, uint32_t *p, uint32_t *lo, int lane, uint32_t parked, uint64_t parked_mask, uint32_t r, uint32_t bprec,
                                                    uint32_t maxbv, uint32_t x_max_high)
 {
     Emitter direct{p, lo, false};
-    if (parked_n > 0) {   // the words parked so far leave first (WaveEmitter::flush)
-        if (p - lo < parked_n) return EscapeResult{x, p, 1};
-        if (lane < parked_n) p[-1 - lane] = parked;
-        direct.p = p - parked_n;
+    if (parked_mask != 0ull) {   // the words parked so far leave first (WaveEmitter::flush)
+        bool overflow = false;
+        direct.p = WaveEmitter::store_parked(p, lo, parked, parked_mask, lane, overflow);
+        if (overflow) return EscapeResult{x, p, 1};
     }
     int nb = 0;
     while (nb * bprec < 32u && (r >> (nb * bprec)) != 0u) ++nb;
@@ -677,7 +684,7 @@ __global__ __launch_bounds__(64 * WPB) void rans_encode_fast_kernel(TablesDev T,
     const int32_t *sym = symbols + beg;
     const int32_t *idx = indexes + beg;
     uint32_t *slot = out_words + static_cast<int64_t>(stream) * slot_words;
-    WaveEmitter em{slot + slot_words, slot, false, 0u, 0};
+    WaveEmitter em{slot + slot_words, slot, false, 0u, 0ull};
     uint32_t xlo_ = static_cast<uint32_t>(kRansL), xhi_ = 0u;   // the state, in s[52:53] across the spelled-out steps
     const uint32_t xs = 31u - static_cast<uint32_t>(T.precision);  // x >= freq << (63-p)  <=>  (x >> 32) >= freq << (31-p)
     const uint32_t bprec = static_cast<uint32_t>(T.bypass_precision);
@@ -704,8 +711,8 @@ __global__ __launch_bounds__(64 * WPB) void rans_encode_fast_kernel(TablesDev T,
         // is broadcast back: no per-symbol operand broadcasts, no scalar 64x64 multiply.  A lone wave issues one instruction
         // per ~8.4 clocks whatever it is (scripts/r04_chain_probe.hip), so what counts is the instruction count per symbol: 13
         // spelled out below + the compiler's scalar compare and branch for "renormalise?" (x_max forced to 0 for a bypass
-        // symbol: the same test covers it).  A plain renormalisation parks the low word in lane k of a register (one coalesced
-        // store per chunk) and shifts the state: no memory instruction, no bounds test behind the branch.
+        // symbol: the same test covers it).  A plain renormalisation parks the low word in the symbol's own lane of a register (one
+        // coalesced store per chunk) and shifts the state: four instructions, no memory instruction, no bounds test behind the branch.
         const uint32_t fq = cur_.a & 0xFFFFu, cm_ = cur_.a >> 16, sh_ = cur_.b & 63u;
         const uint64_t st_ = cur_.b >> 8;
         const uint32_t xm_ = (cur_.b & 0x80u) ? 0u : (fq << xs);  // renormalise when (x >> 32) >= xm
@@ -714,19 +721,17 @@ __global__ __launch_bounds__(64 * WPB) void rans_encode_fast_kernel(TablesDev T,
         uint64_t low_pair_ = 0ull;   // v[30:31]: {mulhi(x_lo, rcp_lo), 0}
         auto renormalise = [&](auto jc) {
             constexpr int J = decltype(jc)::value;
-            if (__builtin_expect(xmj_ != 0u, 1)) {           // park the low word in lane k, x >>= 32 (m0 carries the lane: one scalar operand per VALU instruction)
-                uint32_t m0_save;
+            if (__builtin_expect(xmj_ != 0u, 1)) {   // park the low word in this symbol's lane, x >>= 32
                 uint32_t &xlo = xlo_, &xhi = xhi_;   // (generic lambda: an asm operand alone is no odr-use, the capture needs one)
                 uint32_t &parked = em.parked;
-                const int &parked_n = em.k;
-                asm volatile("s_mov_b32 %3, m0\n\ts_mov_b32 m0, %4\n\tv_writelane_b32 %2, s52, m0\n\ts_mov_b32 m0, %3\n\ts_mov_b32 s52, s53\n\ts_mov_b32 s53, 0"
-                             : "={s52}"(xlo), "={s53}"(xhi), "+v"(parked), "=&s"(m0_save) : "s"(parked_n), "0"(xlo), "1"(xhi));
-                ++em.k;
+                uint64_t &parked_mask = em.mask;
+                asm volatile("v_writelane_b32 %2, s52, %4\n\ts_bitset1_b64 %3, %4\n\ts_mov_b32 s52, s53\n\ts_mov_b32 s53, 0"
+                             : "={s52}"(xlo), "={s53}"(xhi), "+v"(parked), "+s"(parked_mask) : "n"(J), "0"(xlo), "1"(xhi));
             } else {   // a bypass symbol: its escape code goes first (the decoder reads sentinel, count nibbles, payload low-first)
-                const EscapeResult er = encode_escape(static_cast<uint64_t>(xlo_) | (static_cast<uint64_t>(xhi_) << 32), em.p, em.lo, lane, em.parked, em.k,
+                const EscapeResult er = encode_escape(static_cast<uint64_t>(xlo_) | (static_cast<uint64_t>(xhi_) << 32), em.p, em.lo, lane, em.parked, em.mask,
                                                       bcast_u32(cur_.raw, J), bprec, maxbv, bcast_u32(fq, J) << xs);
                 em.p = er.p;
-                em.k = 0;
+                em.mask = 0ull;
                 if (er.overflow) em.overflow = true;
                 const uint64_t x = er.x;
                 {   // back into s[52:53] through vector registers: the loops above may leave the (uniform) state in them, and a
@@ -779,9 +784,8 @@ __global__ __launch_bounds__(64 * WPB) void rans_encode_fast_kernel(TablesDev T,
         cur_ = nxt;
         i2 = i3; row2 = row3; s2 = s3;
     }
-    em.push(xhi_, lane);  // flush, rans64.h:87-94
-    em.push(xlo_, lane);
-    em.flush(lane);
+    em.push_direct(xhi_, lane);  // flush, rans64.h:87-94 (every chunk has flushed its parked words)
+    em.push_direct(xlo_, lane);
     if (lane == 0) out_nwords[stream] = em.overflow ? -1 : static_cast<int32_t>((slot + slot_words) - em.p);
 }
 
